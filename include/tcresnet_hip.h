@@ -1,0 +1,204 @@
+/*
+ * tcresnet_hip.h -- C ABI of the MI355X-native (gfx950) TC-ResNet keyword-spotting hot path.
+ *
+ * The reference (hyperconnect/TC-ResNet, TF 1.13 graph code) has no FFI/plugin boundary for this
+ * path: every number is produced by TensorFlow ops reached from a handful of Python call sites.
+ * Each entry point below replaces the TF ops behind one of those call sites (cited per function,
+ * paths relative to the reference tree).  The Python host package (tc-resnet_amd/) binds this
+ * header with ctypes and exposes the reference's own class/argument names on top of it.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative tcr_status otherwise; tcr_last_error()
+ *     returns a thread-local message.  Nothing throws, nothing allocates device memory:
+ *     all device buffers (including workspaces) are caller-owned, contiguous float32.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, asynchronously.
+ *   - activations are planar per utterance with a zero halo on the time axis:
+ *       act[b][c][TCR_HALO + t],  row length Tp = T + 2*TCR_HALO  (tcr_padded_len(T)).
+ *     The halo implements TF "SAME" zero padding without per-tap bounds checks.
+ *   - conv weights keep the reference checkpoint layout [k][Cin][Cout] (= TF HWIO [k,1,Cin,Cout]).
+ */
+#ifndef TCRESNET_HIP_H
+#define TCRESNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCR_ABI_VERSION 1
+#define TCR_HALO 4
+#define TCR_MAX_BLOCKS 16
+
+typedef enum tcr_status {
+    TCR_OK = 0,
+    TCR_ERR_ARG = -1,          /* invalid argument / unsupported configuration */
+    TCR_ERR_HIP = -2,          /* a HIP call or kernel launch failed */
+    TCR_ERR_WORKSPACE = -3     /* workspace too small */
+} tcr_status;
+
+int tcr_abi_version(void);
+const char* tcr_last_error(void);
+static inline int tcr_padded_len(int t) { return t + 2 * TCR_HALO; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Front-end: MFCC / log-mel (datasets/preprocessors.py:54-96,183-194; window/stride samples   */
+/* from factory/audio_nets.py:62-64; flags from datasets/audio_data_wrapper.py:61-110).        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct tcr_frontend_cfg {
+    int32_t sample_rate;        /* --sample_rate 16000 */
+    int32_t n_samples;          /* sample_rate * clip_duration_ms / 1000 */
+    int32_t win;                /* window_size_samples  */
+    int32_t hop;                /* window_stride_samples */
+    int32_t nfft;               /* out: enclosing power of two of win (tf.contrib.signal.stft) */
+    int32_t n_frames;           /* out: 1 + (n_samples - win) / hop (signal.frame, pad_end=False) */
+    int32_t n_mel;              /* --num_mel_bins (64) */
+    int32_t n_coef;             /* --num_mfccs for mfcc; ignored (== n_mel) for log-mel */
+    float lower_hz;             /* --lower_edge_hertz 80 */
+    float upper_hz;             /* --upper_edge_hertz 7600 */
+    int32_t method;             /* 0 = mfcc (power spectrum + DCT-II), 1 = log_mel_spectrogram (magnitude) */
+} tcr_frontend_cfg;
+
+/* Fills nfft / n_frames and validates the configuration. */
+int tcr_frontend_resolve(tcr_frontend_cfg* cfg);
+/* Size in bytes of the constant tables (Hann window, FFT twiddles, HTK mel slopes, DCT-II). */
+size_t tcr_frontend_plan_bytes(const tcr_frontend_cfg* cfg);
+/* Builds the tables in HOST memory (computed in float64, stored float32); the caller uploads
+ * them once to a device buffer of the same size and passes that pointer to tcr_frontend_fwd. */
+int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_plan);
+/* Dense [n_bins][n_mel] mel matrix / [n_mel][n_coef] DCT matrix reconstructed from a plan
+ * (host side; for tests and for exporting the constants). */
+int tcr_frontend_plan_mel_matrix(const tcr_frontend_cfg* cfg, const void* host_plan, float* out);
+int tcr_frontend_plan_dct_matrix(const tcr_frontend_cfg* cfg, const void* host_plan, float* out);
+
+/* wav [batch][n_samples] -> feat [batch][n_coef][Tp] (halo zeroed), Tp = tcr_padded_len(n_frames).
+ * Replaces tf.contrib.signal.stft / linear_to_mel_weight_matrix / tensordot / log /
+ * mfccs_from_log_mel_spectrograms (datasets/preprocessors.py:68-94,191-193). */
+int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_dev, const float* wav, int batch,
+                     float* feat, void* stream);
+
+/* "no_preprocessing" (datasets/preprocessors.py:45-49): re-layout a reference-shaped feature
+ * tensor [batch][T][F] into the planar halo layout [batch][F][Tp], and back. */
+int tcr_features_to_planar(const float* ntf, int batch, int t, int f, float* planar, void* stream);
+int tcr_features_from_planar(const float* planar, int batch, int t, int f, float* ntf, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Network: TC-ResNet (audio_nets/tc_resnet.py:6-70, arg scope :102-123)                       */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct tcr_tcresnet_cfg {
+    char scope[32];                 /* "TCResNet8" / "TCResNet14": TF variable scope (tc_resnet.py:57,65) */
+    int32_t in_channels;            /* MFCC coefficients (become channels, tc_resnet.py:17) */
+    int32_t t_in;                   /* number of frames L */
+    int32_t num_classes;
+    int32_t n_blocks;
+    int32_t channels[TCR_MAX_BLOCKS + 1];   /* n_channels after width_multiplier (tc_resnet.py:59-60) */
+    float bn_decay;                 /* 0.997 (tc_resnet.py:107) */
+    float bn_eps;                   /* 0.001 (slim.batch_norm default) */
+} tcr_tcresnet_cfg;
+
+typedef struct tcr_net tcr_net;     /* opaque, host-only (no device allocations) */
+
+int tcr_tcresnet_create(const tcr_tcresnet_cfg* cfg, tcr_net** out);
+void tcr_net_destroy(tcr_net* net);
+
+/* Parameter arena layout.  Trainables live in ONE flat float32 arena (so that the optimiser step
+ * and the data-parallel gradient all-reduce are one call each): all conv/fc weights first
+ * (these are the L2-regularised variables of factory/audio_nets.py:175-180), then BN gamma/beta.
+ * Moving statistics live in a second arena.  Offsets are in floats. */
+typedef enum tcr_tensor_kind {
+    TCR_WEIGHT = 0, TCR_GAMMA = 1, TCR_BETA = 2, TCR_MOVING_MEAN = 3, TCR_MOVING_VAR = 4
+} tcr_tensor_kind;
+
+typedef struct tcr_tensor_info {
+    char name[96];          /* TF variable name, e.g. "TCResNet8/block0/conv0_0/BatchNorm/gamma" */
+    int32_t kind;           /* tcr_tensor_kind */
+    int32_t arena;          /* 0 = trainable arena, 1 = moving-stat arena */
+    int64_t offset;         /* floats */
+    int64_t size;           /* floats */
+    int32_t shape[4];       /* TF shape, e.g. [9,1,16,24] */
+    int32_t rank;
+} tcr_tensor_info;
+
+int64_t tcr_net_param_floats(const tcr_net* net);      /* trainable arena size (padded) */
+int64_t tcr_net_decay_floats(const tcr_net* net);      /* prefix of the arena that is L2-regularised */
+int64_t tcr_net_stat_floats(const tcr_net* net);       /* moving-stat arena size */
+int tcr_net_num_tensors(const tcr_net* net);
+int tcr_net_tensor_info(const tcr_net* net, int index, tcr_tensor_info* out);
+int tcr_net_out_frames(const tcr_net* net);            /* L' after the last block */
+int tcr_net_feat_channels(const tcr_net* net);         /* channels into fc */
+
+/* Workspace size for a batch; train != 0 includes saved activations and gradient scratch. */
+size_t tcr_net_workspace_bytes(const tcr_net* net, int batch, int train);
+
+/* Eval-mode forward (is_training=False: BN uses moving stats, dropout off):
+ * tc_resnet() + slim.softmax (audio_nets/tc_resnet.py:6-54, factory/audio_nets.py:147-156),
+ * i.e. what Base.run_inference fetches (helper/base.py:86-104).
+ * feat [batch][Cin][Tp]; logits/probs [batch][num_classes]; ranges [batch][2] (may be NULL). */
+int tcr_net_forward_infer(const tcr_net* net, const float* params, const float* stats, const float* feat,
+                          int batch, void* workspace, size_t workspace_bytes,
+                          float* logits, float* probs, float* ranges, void* stream);
+
+/* Train-mode forward (is_training=True): batch-statistics BN with moving-stat update
+ * (decay, Bessel-corrected variance), inverted dropout after the global pool, softmax,
+ * mean cross-entropy (factory/audio_nets.py:161-173).  Saves what backward needs in `workspace`.
+ *   labels      [batch][num_classes] one-hot float (datasets/audio_data_wrapper.py:114-118)
+ *   keep_prob   --dropout_keep_prob; the mask for sample i, channel c is a pure function of
+ *               (seed, sample_offset + i, c) so that a sharded batch draws the same mask
+ *   loss_out    device float[2]: {sum over the batch of -sum_k y log softmax, unused}
+ *   global_batch  divisor of the mean loss / of dlogits (== batch on one GPU) */
+int tcr_net_forward_train(const tcr_net* net, const float* params, float* stats, const float* feat,
+                          const float* labels, int batch, int global_batch, float keep_prob,
+                          uint64_t seed, int64_t sample_offset, float label_smoothing,
+                          void* workspace, size_t workspace_bytes,
+                          float* logits, float* probs, float* loss_out, void* stream);
+
+/* Backward of the model loss wrt every trainable (tf.gradients inside
+ * slim.learning.create_train_op, helper/trainer.py:205-211).  Must follow a forward_train on
+ * the same workspace.  grads: arena-shaped, overwritten.  The L2 term is NOT added here
+ * (it is folded into tcr_sgd_momentum_step / reported by tcr_l2_loss). */
+int tcr_net_backward(const tcr_net* net, const float* params, const float* feat, int batch,
+                     void* workspace, size_t workspace_bytes, float* grads, void* stream);
+
+/* Cross-replica (sync) BN.  forward_train / backward can be run stage by stage: stage s ends right
+ * after the per-channel partial sums of its BN layer ({sum y, sum y^2} forward, {sum dz, sum dz*xhat}
+ * backward; 2*C floats) have been written to a contiguous device buffer, which the host
+ * all-reduces (sum) across replicas before calling stage s+1.  Statistics then span global_batch,
+ * exactly as in the single-device reference.  Stages 0 .. tcr_net_num_stages()-1; the last stage
+ * has no hand-off.  See DESIGN.md "Data parallel". */
+int tcr_net_num_stages(const tcr_net* net, int backward);
+int tcr_net_stage_sums(const tcr_net* net, int backward, int stage, void* workspace, int batch,
+                       float** sums_dev, int64_t* n_floats);
+int tcr_net_forward_train_stage(const tcr_net* net, const float* params, float* stats, const float* feat,
+                                const float* labels, int batch, int global_batch, float keep_prob,
+                                uint64_t seed, int64_t sample_offset, float label_smoothing,
+                                void* workspace, size_t workspace_bytes,
+                                float* logits, float* probs, float* loss_out, int stage, void* stream);
+int tcr_net_backward_stage(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch,
+                           void* workspace, size_t workspace_bytes, float* grads, int stage, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Optimiser (helper/trainer.py:171-197) and L2 (factory/audio_nets.py:175-182)                */
+/* ------------------------------------------------------------------------------------------ */
+/* tf.train.MomentumOptimizer, use_nesterov=False:  g' = g*grad_scale + wd*w (first n_decay floats)
+ * a <- mu*a + g' ; w <- w - lr*a. */
+int tcr_sgd_momentum_step(float* params, const float* grads, float* momentum, int64_t n, int64_t n_decay,
+                          float lr, float mu, float weight_decay, float grad_scale, void* stream);
+/* tf.train.AdamOptimizer (beta1 .9, beta2 .999, eps 1e-8 defaults); t = 1-based step. */
+int tcr_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t n_decay,
+                  float lr, float beta1, float beta2, float eps, int64_t t, float weight_decay,
+                  float grad_scale, void* stream);
+/* out[0] = weight_decay * sum_{i<n_decay} 0.5*w_i^2 (device float). */
+int tcr_l2_loss(const float* params, int64_t n_decay, float weight_decay, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Instrumentation                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+/* Name of the n-th kernel family in this library (NULL past the end); used by bench.py to match
+ * rocprofv3 kernel-trace rows. */
+const char* tcr_kernel_name(int index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCRESNET_HIP_H */

@@ -1,0 +1,133 @@
+"""TEST INFRASTRUCTURE ONLY -- generates the committed fixtures under tests/golden/.
+
+    python -m oracle.make_golden
+
+The reference holds no golden vectors and cannot be executed here (TF 1.13.1), so these fixtures are
+produced by the float64 NumPy restatement (oracle/numpy_ref.py) after cross-checking it against the
+independent PyTorch implementation (oracle/torch_ref.py); "parity unpinned" applies (oracle/__init__.py).
+Every fixture stores inputs AND expected outputs, so tests never need /root/reference.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import numpy_ref as R
+from . import torch_ref as TR
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def dropout_uniform(seed: int, index: np.ndarray) -> np.ndarray:
+    """Bit-exact NumPy mirror of tcr::uniform01 (tc-resnet_amd/csrc/tcr_common.h)."""
+    def mix32(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        x = (x.astype(np.uint64) * np.uint64(0x7feb352d) & np.uint64(0xffffffff)).astype(np.uint32)
+        x ^= x >> np.uint32(15)
+        x = (x.astype(np.uint64) * np.uint64(0x846ca68b) & np.uint64(0xffffffff)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        return x
+    index = np.asarray(index, np.uint64)
+    lo = (index & np.uint64(0xffffffff)).astype(np.uint32)
+    hi = (index >> np.uint64(32)).astype(np.uint32)
+    s0 = np.array([seed & 0xffffffff], np.uint32)
+    s1 = np.array([(seed >> 32) & 0xffffffff], np.uint32)
+    s1c = ((s1.astype(np.uint64) + np.uint64(0x9e3779b9)) & np.uint64(0xffffffff)).astype(np.uint32)
+    h = mix32(lo ^ mix32(hi ^ mix32(s0 ^ mix32(s1c))))
+    return (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def dropout_mask(seed: int, sample_offset: int, batch: int, channels: int, keep_prob: float) -> np.ndarray:
+    idx = (sample_offset + np.arange(batch, dtype=np.uint64)[:, None]) * np.uint64(channels) + np.arange(channels, dtype=np.uint64)[None, :]
+    return (dropout_uniform(seed, idx) < np.float32(keep_prob)).astype(np.float64)
+
+
+FRONTENDS = {"3010": R.FRONTEND_3010, "4020": R.FRONTEND_4020}
+
+
+def make_frontend():
+    for tag, cfg in FRONTENDS.items():
+        wav = R.synth_waveforms(2, seed=1234)
+        # edge rows: digital silence and a full-scale square-ish signal
+        wav = np.concatenate([wav, np.zeros((1, 16000), np.float32), np.sign(np.sin(np.arange(16000) * 0.05)).astype(np.float32)[None] * 0.99])
+        m64 = R.mfcc(wav, cfg)
+        mt = TR.mfcc(__import__("torch").tensor(wav, dtype=__import__("torch").float64), cfg).numpy()
+        assert np.abs(m64 - mt).max() < 1e-9
+        lm = R.log_mel_spectrogram(wav, cfg, magnitude_squared=False)
+        np.savez_compressed(os.path.join(OUT, f"frontend_{tag}.npz"), wav=wav, mfcc=m64, log_mel_magnitude=lm,
+                            win=cfg.win, hop=cfg.hop)
+
+
+def _keep(name: str, full: bool, key: str) -> bool:
+    """Large nets store only the small tensors + a few weight tensors (weights are regenerated from the seeds)."""
+    if full:
+        return True
+    return ("BatchNorm" in key) or key.endswith("conv0/weights") or key.endswith("fc/weights") or ("block5/" in key) or ("block2/down" in key)
+
+
+def make_net(name: str, width: float, tag: str, batch: int = 4, seed: int = 0, full: bool = True):
+    cfg = FRONTENDS[tag]
+    arch = R.make_tcresnet(name, width)
+    p, s = R.init_params(arch, seed)
+    R.randomize_bn(arch, p, s, seed + 1)
+    wav = R.synth_waveforms(batch, seed=4321)
+    labels = R.synth_labels(batch).astype(np.float64)
+    x = R.mfcc(wav, cfg)
+    ev = R.forward(arch, p, s, x, False)
+    # cross-check eval against torch
+    import torch
+    tev = TR.forward(arch, {k: torch.tensor(v) for k, v in p.items()}, {k: torch.tensor(v) for k, v in s.items()}, torch.tensor(x), False)
+    assert np.abs(tev["logits"].numpy() - ev["logits"]).max() < 1e-10
+    out = {"wav": wav, "labels": labels, "mfcc": x, "eval_logits": ev["logits"], "eval_probs": ev["probs"], "eval_ranges": ev["ranges"],
+           "width": width, "win": cfg.win, "hop": cfg.hop}
+    out.update(init_seed=seed, bn_seed=seed + 1, full=full)
+    if full:        # otherwise: R.init_params(arch, init_seed) + R.randomize_bn(arch, p, s, bn_seed)
+        for k, v in p.items():
+            out["param:" + k] = v
+        for k, v in s.items():
+            out["stat:" + k] = v
+    # training: 3 momentum steps, keep_prob 0.5 with the kernel's own counter-based mask
+    keep, wd, lr, mu, dseed, off = 0.5, 0.001, 0.1, 0.9, 99, 5
+    pp, ss = dict(p), dict(s)
+    mm = {k: np.zeros_like(v) for k, v in p.items()}
+    for step in range(3):
+        mask = dropout_mask(dseed + step, off, batch, arch.fc.cin, keep)
+        if step == 0:
+            tg, ttot, tmodel, tns = TR.grads(arch, pp, ss, x, labels, wd, keep, mask)
+        pp, ss, mm, info = R.train_step(arch, pp, ss, mm, x, labels, lr, wd, mu, keep, mask)
+        if step == 0:
+            assert max(np.abs(info["grads"][k] - tg[k]).max() for k in tg) < 1e-9
+            out["train_logits"] = info["logits"]
+            out["train_model_loss"] = info["model_loss"]
+            out["train_l2_loss"] = info["l2_loss"]
+            for k, v in info["grads"].items():
+                if _keep(name, full, k):
+                    out["grad:" + k] = v            # includes the L2 term wd * w
+            for k, v in ss.items():
+                out["stat1:" + k] = v
+            for k, v in pp.items():
+                if _keep(name, full, k) and full:
+                    out["param1:" + k] = v
+    for k, v in pp.items():
+        if _keep(name, full, k):
+            out["param3:" + k] = v
+    for k, v in ss.items():
+        out["stat3:" + k] = v
+    out.update(train_keep_prob=keep, train_weight_decay=wd, train_lr=lr, train_momentum=mu, train_seed=dseed, train_sample_offset=off)
+    np.savez_compressed(os.path.join(OUT, f"{name.lower()}_{width}_{tag}.npz"), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    make_frontend()
+    make_net("TCResNet8", 1.0, "4020")
+    make_net("TCResNet8", 1.0, "3010", batch=3)
+    make_net("TCResNet14", 1.5, "4020", batch=3, full=False)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,220 @@
+// Batch normalisation for the planar halo layout: eval-mode folding, train-mode batch statistics
+// (per-channel reduction over batch x time), normalise + ReLU + residual, and the backward pass.
+//
+// Replaces slim.batch_norm(fused=True) -> FusedBatchNorm / FusedBatchNormGrad as configured by
+// TCResNet_arg_scope (audio_nets/tc_resnet.py:102-123): decay 0.997, epsilon 1e-3, center, scale;
+// training normalises with the biased batch variance and moves the running variance towards the
+// Bessel-corrected one.  tf.nn.relu and the residual add of tc_resnet.py:40-41 are fused here.
+//
+// Per-channel reductions: lane == position (coalesced along time), CT channels per lane in
+// registers, 64-lane shuffle reduction, LDS across the 4 waves, one partial row per workgroup that
+// a single-workgroup kernel sums in double precision in a FIXED order (bitwise reproducible).
+#include "kernels.h"
+
+namespace tcr {
+
+// Eval mode: y = gamma * (x - mm) / sqrt(mv + eps) + beta  ==  x * scale + shift
+__global__ __launch_bounds__(128) void bn_fold_kernel(const BnFoldArgs a) {
+    const int l = blockIdx.x;
+    for (int c = threadIdx.x; c < a.c[l]; c += 128) {
+        const float g = a.params[a.gamma_off[l] + c], b = a.params[a.beta_off[l] + c];
+        const float mm = a.stats[a.mean_off[l] + c], mv = a.stats[a.var_off[l] + c];
+        const float sc = g / sqrtf(mv + a.eps);
+        a.out[a.out_off[l] + c] = sc;
+        a.out[a.out_off[l] + a.c_pad[l] + c] = fmaf(-mm, sc, b);
+    }
+}
+
+int launch_bn_fold(const BnFoldArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(a.n), dim3(128), 0, s, a);
+    return check_launch("bn_fold_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic per-channel reduction of up to two quantities over [B][C][Tp].
+//   MODE 0 (forward stats):   q1 = y, q2 = y*y
+//   MODE 1 (backward sums):   dz = dA * [m1 > 0] * [m2 > 0];  q1 = dz, q2 = dz * (y - mean) * invstd
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a) {
+    constexpr int CT = 8;
+    __shared__ float s_red[4][2 * CT];
+    const int c0 = blockIdx.y * CT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float q1[CT], q2[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { q1[c] = 0.f; q2[c] = 0.f; }
+    float mu[CT], is[CT];
+    if (MODE == 1) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int cc = min(c0 + c, a.c - 1);
+            mu[c] = a.mean[cc];
+            is[c] = a.invstd[cc];
+        }
+    }
+    const int blk0 = blockIdx.x * a.pos_per_block;
+    const int blk1 = min(blk0 + a.pos_per_block, a.npos);
+    for (int p = blk0 + threadIdx.x; p < blk1; p += 256) {
+        const int n = p / a.t, t = p - n * a.t;
+        const size_t base = ((size_t)n * a.c + c0) * a.tp + kHalo + t;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (c0 + c >= a.c) continue;
+            const size_t o = base + (size_t)c * a.tp;
+            const float yv = a.y[o];
+            if (MODE == 0) {
+                q1[c] += yv;
+                q2[c] = fmaf(yv, yv, q2[c]);
+            } else {
+                float dz = a.bcast ? a.da[(size_t)n * a.c + c0 + c] : a.da[o];
+                if (a.m1 && !(a.m1[o] > 0.f)) dz = 0.f;
+                if (a.m2 && !(a.m2[o] > 0.f)) dz = 0.f;
+                q1[c] += dz;
+                q2[c] = fmaf(dz, (yv - mu[c]) * is[c], q2[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        q1[c] = wave_sum(q1[c]);
+        q2[c] = wave_sum(q2[c]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { s_red[wave][c] = q1[c]; s_red[wave][CT + c] = q2[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * CT) {
+        const int c = threadIdx.x % CT, which = threadIdx.x / CT;
+        if (c0 + c < a.c) {
+            const float v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+            a.partial[((size_t)blockIdx.x * 2 + which) * a.c + c0 + c] = v;
+        }
+    }
+}
+
+int chan_reduce_chunks(int npos) {
+    int n = ceil_div(npos, 2048);
+    if (n > 128) n = 128;
+    if (n < 1) n = 1;
+    return n;
+}
+
+int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t s) {
+    const int nchunk = chan_reduce_chunks(a.npos);
+    a.pos_per_block = ceil_div(a.npos, nchunk);
+    const dim3 grid(ceil_div(a.npos, a.pos_per_block), ceil_div(a.c, 8));
+    *nchunk_out = (int)grid.x;
+    if (mode == 0) hipLaunchKernelGGL((chan_reduce_kernel<0>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((chan_reduce_kernel<1>), grid, dim3(256), 0, s, a);
+    return check_launch("chan_reduce_kernel");
+}
+
+// sums[2][C] = sum over chunks (double accumulation, fixed order).  Used on its own when the
+// host all-reduces the sums across replicas (sync BN) before the finalize kernels.
+__global__ __launch_bounds__(128) void chan_sums_kernel(const float* __restrict__ partial, int nchunk, int c, float* __restrict__ sums) {
+    for (int i = threadIdx.x; i < 2 * c; i += 128) {
+        const int which = i / c, ch = i % c;
+        double acc = 0.0;
+        for (int k = 0; k < nchunk; ++k) acc += (double)partial[((size_t)k * 2 + which) * c + ch];
+        sums[i] = (float)acc;
+    }
+}
+
+int launch_chan_sums(const float* partial, int nchunk, int c, float* sums, hipStream_t s) {
+    hipLaunchKernelGGL(chan_sums_kernel, dim3(1), dim3(128), 0, s, partial, nchunk, c, sums);
+    return check_launch("chan_sums_kernel");
+}
+
+// Train-mode forward finalize from sums[2][C] over `count` elements.
+__global__ __launch_bounds__(128) void bn_finalize_kernel(const BnFinalizeArgs a) {
+    for (int c = threadIdx.x; c < a.c; c += 128) {
+        const double m = (double)a.sums[c] / a.count;
+        double var = (double)a.sums[a.c + c] / a.count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)m, varf = (float)var;
+        const float inv = 1.0f / sqrtf(varf + a.eps);
+        const float sc = a.gamma[c] * inv;
+        a.scale[c] = sc;
+        a.shift[c] = fmaf(-meanf, sc, a.beta[c]);
+        a.mean[c] = meanf;
+        a.invstd[c] = inv;
+        // assign_moving_average: v -= (1 - decay) * (v - value); variance is Bessel-corrected
+        const float unbiased = (float)(var * (a.count / (a.count > 1.0 ? a.count - 1.0 : 1.0)));
+        const float om = 1.0f - a.decay;
+        a.moving_mean[c] -= om * (a.moving_mean[c] - meanf);
+        a.moving_var[c] -= om * (a.moving_var[c] - unbiased);
+    }
+}
+
+int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, s, a);
+    return check_launch("bn_finalize_kernel");
+}
+
+// a = [relu](y * scale + shift)            (res == nullptr)
+// a = relu(y * scale + shift + res)        (block output, tc_resnet.py:40-41)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (int64_t)gridDim.x * 256) {
+        const int tt = (int)(i % a.tp) - kHalo;
+        const int c = (int)((i / a.tp) % a.c);
+        float v = 0.f;
+        if (tt >= 0 && tt < a.t) {
+            v = fmaf(a.y[i], a.scale[c], a.shift[c]);
+            if (a.res) v = fmaxf(v + a.res[i], 0.f);
+            else if (a.relu) v = fmaxf(v, 0.f);
+        }
+        a.out[i] = v;
+    }
+}
+
+int launch_bn_apply(const BnApplyArgs& a, hipStream_t s) {
+    int64_t blocks = ceil_div64(a.total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return check_launch("bn_apply_kernel");
+}
+
+// Backward finalize: dgamma, dbeta into the gradient arena + the per-channel coefficients of
+//   dy = k1 * (dz - k2 - (y - mean) * k3),  k1 = gamma*invstd, k2 = dbeta/n, k3 = invstd*dgamma/n
+__global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const BnBwdFinalizeArgs a) {
+    for (int c = threadIdx.x; c < a.c; c += 128) {
+        const float db = a.sums[c], dg = a.sums[a.c + c];
+        a.dbeta[c] = db;
+        a.dgamma[c] = dg;
+        a.k1[c] = a.gamma[c] * a.invstd[c];
+        a.k2[c] = (float)((double)db / a.count);
+        a.k3[c] = (float)((double)a.invstd[c] * (double)dg / a.count);
+    }
+}
+
+int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, s, a);
+    return check_launch("bn_bwd_finalize_kernel");
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (int64_t)gridDim.x * 256) {
+        const int tt = (int)(i % a.tp) - kHalo;
+        const int64_t row = i / a.tp;           // b * C + c
+        const int c = (int)(row % a.c);
+        float v = 0.f;
+        if (tt >= 0 && tt < a.t) {
+            float dz = a.bcast ? a.da[row] : a.da[i];
+            if (a.m1 && !(a.m1[i] > 0.f)) dz = 0.f;
+            if (a.m2 && !(a.m2[i] > 0.f)) dz = 0.f;
+            v = a.k1[c] * (dz - a.k2[c] - (a.y[i] - a.mean[c]) * a.k3[c]);
+        }
+        a.dy[i] = v;
+    }
+}
+
+int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s) {
+    int64_t blocks = ceil_div64(a.total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return check_launch("bn_bwd_apply_kernel");
+}
+
+}  // namespace tcr

@@ -1,0 +1,179 @@
+// Host-side construction of the front-end constant tables (float64 math, float32 storage).
+//
+// Restates the constants TF builds inside the graph for datasets/preprocessors.py:64-96,183-194:
+//   hann_window(periodic=True), the rfft twiddles, tf.contrib.signal.linear_to_mel_weight_matrix
+//   (HTK mel scale, DC bin zeroed, triangular, un-normalised) and the DCT-II of
+//   mfccs_from_log_mel_spectrograms (x 1/sqrt(2N)).
+// The mel matrix is stored in its sparse form: every spectrogram bin lies in exactly one
+// mel-edge segment j and contributes to at most two filters (up-slope of j, down-slope of j-1).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "frontend_plan.h"
+
+namespace tcr {
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+double hertz_to_mel(double f) { return 1127.0 * std::log1p(f / 700.0); }
+
+// numpy.linspace(start, stop, num)[i]
+double linspace_at(double start, double stop, int num, int i) {
+    if (i == num - 1) return stop;
+    double step = (stop - start) / (double)(num - 1);
+    return (double)i * step + start;
+}
+
+// Dense mel matrix exactly as TF builds it: [nbins][n_mel], row 0 (DC) zero.
+std::vector<double> dense_mel(const tcr_frontend_cfg& c, int nbins) {
+    const int nm = c.n_mel;
+    std::vector<double> m((size_t)nbins * nm, 0.0);
+    const double nyquist = c.sample_rate / 2.0;
+    std::vector<double> edges(nm + 2);
+    const double mlo = hertz_to_mel(c.lower_hz), mhi = hertz_to_mel(c.upper_hz);
+    for (int i = 0; i < nm + 2; ++i) edges[i] = linspace_at(mlo, mhi, nm + 2, i);
+    for (int k = 1; k < nbins; ++k) {
+        const double mel = hertz_to_mel(linspace_at(0.0, nyquist, nbins, k));
+        for (int j = 0; j < nm; ++j) {
+            const double lower = edges[j], center = edges[j + 1], upper = edges[j + 2];
+            const double ls = (mel - lower) / (center - lower);
+            const double us = (upper - mel) / (upper - center);
+            const double v = std::fmax(0.0, std::fmin(ls, us));
+            m[(size_t)k * nm + j] = v;
+        }
+    }
+    return m;
+}
+
+}  // namespace
+}  // namespace tcr
+
+using namespace tcr;
+
+extern "C" int tcr_frontend_resolve(tcr_frontend_cfg* cfg) {
+    TCR_REQUIRE(cfg != nullptr, "tcr_frontend_resolve: null cfg");
+    TCR_REQUIRE(cfg->sample_rate > 0 && cfg->n_samples > 0, "front-end: sample_rate/n_samples must be positive");
+    TCR_REQUIRE(cfg->win > 0 && cfg->hop > 0 && cfg->win <= cfg->n_samples, "front-end: bad window (%d) / stride (%d)", cfg->win, cfg->hop);
+    int nfft = 1;
+    while (nfft < cfg->win) nfft <<= 1;
+    TCR_REQUIRE(nfft == 512 || nfft == 1024,
+                "front-end: fft_length %d (window %d samples) unsupported; this build has the 512- and 1024-point kernels", nfft, cfg->win);
+    TCR_REQUIRE((cfg->win & 1) == 0, "front-end: window_size_samples must be even (got %d)", cfg->win);
+    TCR_REQUIRE(cfg->n_mel == 64, "front-end: num_mel_bins must be 64 (got %d)", cfg->n_mel);
+    TCR_REQUIRE(cfg->method == 0 || cfg->method == 1, "front-end: method must be 0 (mfcc) or 1 (log_mel_spectrogram)");
+    if (cfg->method == 1) cfg->n_coef = cfg->n_mel;
+    TCR_REQUIRE(cfg->n_coef >= 1 && cfg->n_coef <= cfg->n_mel, "front-end: num_mfccs must be in [1, %d] (got %d)", cfg->n_mel, cfg->n_coef);
+    TCR_REQUIRE(cfg->lower_hz >= 0.f && cfg->lower_hz < cfg->upper_hz && cfg->upper_hz <= cfg->sample_rate / 2.0f,
+                "front-end: mel edges [%g, %g] Hz invalid for sample rate %d", cfg->lower_hz, cfg->upper_hz, cfg->sample_rate);
+    cfg->nfft = nfft;
+    cfg->n_frames = 1 + (cfg->n_samples - cfg->win) / cfg->hop;
+    return TCR_OK;
+}
+
+extern "C" size_t tcr_frontend_plan_bytes(const tcr_frontend_cfg* cfg) {
+    if (!cfg || cfg->nfft <= 0) return 0;
+    return frontend_plan_layout(*cfg).words * 4;
+}
+
+extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_plan) {
+    TCR_REQUIRE(cfg && host_plan, "tcr_frontend_plan_init: null argument");
+    TCR_REQUIRE(cfg->nfft == 512 || cfg->nfft == 1024, "tcr_frontend_plan_init: call tcr_frontend_resolve first");
+    const FrontendPlanLayout L = frontend_plan_layout(*cfg);
+    float* w = static_cast<float*>(host_plan);
+    std::memset(w, 0, L.words * 4);
+
+    for (int i = 0; i < cfg->win; ++i) w[L.window + i] = (float)(0.5 - 0.5 * std::cos(2.0 * kPi * i / cfg->win));
+    for (int n1 = 0; n1 < 16; ++n1)
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const double a = -2.0 * kPi * (double)(n1 * k2) / 256.0;
+            w[L.tw256 + 2 * (n1 * 16 + k2)] = (float)std::cos(a);
+            w[L.tw256 + 2 * (n1 * 16 + k2) + 1] = (float)std::sin(a);
+        }
+    for (int k = 0; k < 256; ++k) {
+        const double a = -2.0 * kPi * (double)k / 512.0;
+        w[L.tw_combine + 2 * k] = (float)std::cos(a);
+        w[L.tw_combine + 2 * k + 1] = (float)std::sin(a);
+    }
+    for (int k = 0; k <= L.nc / 2; ++k) {
+        const double a = -2.0 * kPi * (double)k / (double)cfg->nfft;
+        w[L.tw_real + 2 * k] = (float)std::cos(a);
+        w[L.tw_real + 2 * k + 1] = (float)std::sin(a);
+    }
+
+    // Sparse mel: segment boundaries in bins + two slopes per bin, extracted from the dense matrix.
+    const int nm = cfg->n_mel;
+    const std::vector<double> M = dense_mel(*cfg, L.nbins);
+    const double nyquist = cfg->sample_rate / 2.0;
+    const double mlo = hertz_to_mel(cfg->lower_hz), mhi = hertz_to_mel(cfg->upper_hz);
+    int32_t* seg = reinterpret_cast<int32_t*>(w + L.seg_start);
+    // seg_of[k] = j when edges[j] <= mel(k) < edges[j+1]; -1 below the first edge, nm+1 at/after the
+    // last one (both weightless).  mel(k) is increasing, so segments are contiguous bin ranges and
+    // seg[j] = first bin whose segment index is >= j.
+    std::vector<int> seg_of(L.nbins, -1);
+    for (int k = 1; k < L.nbins; ++k) {
+        const double mel = hertz_to_mel(linspace_at(0.0, nyquist, L.nbins, k));
+        int j = -1;
+        for (int e = 0; e < nm + 2; ++e)
+            if (mel >= linspace_at(mlo, mhi, nm + 2, e)) j = e;
+        seg_of[k] = j;
+    }
+    for (int j = 0; j <= L.nseg; ++j) {
+        int first = L.nbins;
+        for (int k = L.nbins - 1; k >= 1; --k)
+            if (seg_of[k] >= j) first = k;
+        seg[j] = first;
+    }
+    for (int k = 1; k < L.nbins; ++k) {
+        const int j = seg_of[k];
+        float up = 0.f, down = 0.f;
+        if (j >= 0 && j < nm) up = (float)M[(size_t)k * nm + j];
+        if (j >= 1 && j <= nm) down = (float)M[(size_t)k * nm + j - 1];
+        w[L.wud + 2 * k] = up;
+        w[L.wud + 2 * k + 1] = down;
+        for (int m = 0; m < nm; ++m) {       // every other entry of the row must be exactly zero
+            if (m == j || m == j - 1) continue;
+            if (M[(size_t)k * nm + m] != 0.0) {
+                set_error("front-end: mel matrix row %d has an unexpected non-zero at filter %d (segment %d)", k, m, j);
+                return TCR_ERR_ARG;
+            }
+        }
+    }
+
+    // DCT-II rows, folded: dcth[c][n] = 2 cos(pi c (2n+1) / (2 N)) / sqrt(2 N), n < N/2
+    // (the n' = N-1-n half is (-1)^c times the same value).
+    const int half = nm / 2;
+    for (int c = 0; c < nm; ++c)
+        for (int n = 0; n < half; ++n)
+            w[L.dcth + (size_t)c * half + n] = (float)(2.0 * std::cos(kPi * c * (2.0 * n + 1.0) / (2.0 * nm)) / std::sqrt(2.0 * nm));
+    return TCR_OK;
+}
+
+extern "C" int tcr_frontend_plan_mel_matrix(const tcr_frontend_cfg* cfg, const void* host_plan, float* out) {
+    TCR_REQUIRE(cfg && host_plan && out, "tcr_frontend_plan_mel_matrix: null argument");
+    const FrontendPlanLayout L = frontend_plan_layout(*cfg);
+    const float* w = static_cast<const float*>(host_plan);
+    const int32_t* seg = reinterpret_cast<const int32_t*>(w + L.seg_start);
+    const int nm = cfg->n_mel;
+    std::memset(out, 0, sizeof(float) * (size_t)L.nbins * nm);
+    for (int j = 0; j < L.nseg; ++j)
+        for (int k = seg[j]; k < seg[j + 1]; ++k) {
+            if (j < nm) out[(size_t)k * nm + j] = w[L.wud + 2 * k];
+            if (j >= 1) out[(size_t)k * nm + j - 1] = w[L.wud + 2 * k + 1];
+        }
+    return TCR_OK;
+}
+
+extern "C" int tcr_frontend_plan_dct_matrix(const tcr_frontend_cfg* cfg, const void* host_plan, float* out) {
+    TCR_REQUIRE(cfg && host_plan && out, "tcr_frontend_plan_dct_matrix: null argument");
+    const FrontendPlanLayout L = frontend_plan_layout(*cfg);
+    const float* w = static_cast<const float*>(host_plan);
+    const int nm = cfg->n_mel, half = nm / 2;
+    for (int n = 0; n < nm; ++n)
+        for (int c = 0; c < cfg->n_coef; ++c) {
+            const float v = w[L.dcth + (size_t)c * half + (n < half ? n : nm - 1 - n)];
+            out[(size_t)n * cfg->n_coef + c] = (n < half || (c & 1) == 0) ? v : -v;
+        }
+    return TCR_OK;
+}

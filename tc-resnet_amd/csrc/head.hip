@@ -1,0 +1,208 @@
+// Classifier head: global average pool -> (dropout) -> fc / fc2 1x1 convs -> softmax / sigmoid,
+// the mean cross-entropy and its gradient.
+//
+// Replaces slim.avg_pool2d + slim.dropout + the two 1x1 slim.conv2d heads + sigmoid
+// (audio_nets/tc_resnet.py:43-52), slim.softmax (factory/audio_nets.py:154) and
+// tf.losses.softmax_cross_entropy (factory/audio_nets.py:168-173).
+//
+// The dense contraction runs on the matrix cores: D[class][utterance] = sum_c Wcat[c][class] *
+// pooled[c][utterance] with the exact-f32 16x16x4 MFMA; rows 0..nc-1 are the logits, rows nc, nc+1
+// the two "ranges" outputs of fc2.  A wave owns 16 utterances; the softmax over the class rows is a
+// register + 2-step cross-lane (xor 16, 32) reduction.
+#include "kernels.h"
+
+namespace tcr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT, bool TRAIN>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int u = (blockIdx.x * 4 + wave) * 16 + r;
+    const bool uv = u < a.batch;
+    const int n = uv ? u : a.batch - 1;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < a.c; c0 += 4) {
+        const int c = c0 + q;
+        const bool cv = c < a.c;
+        const int cc = cv ? c : a.c - 1;
+        // B operand: pooled (and dropped-out) feature of (utterance r, channel c)
+        const float* row = a.feat + ((size_t)n * a.c + cc) * a.tp + kHalo;
+        float sum = 0.f;
+        for (int t = 0; t < a.t; ++t) sum += row[t];
+        float pooled = sum / (float)a.t;                                    // tc_resnet.py:43
+        if (TRAIN) {
+            float ds = 1.0f / (float)a.t;
+            if (a.keep_prob < 1.0f) {                                       // tf.nn.dropout: div(x, keep_prob) * mask
+                const float rnd = uniform01(a.seed, (uint64_t)(a.sample_offset + n) * (uint64_t)a.c + (uint64_t)cc);
+                const bool keep = rnd < a.keep_prob;
+                pooled = keep ? pooled / a.keep_prob : 0.f;
+                ds = keep ? ds / a.keep_prob : 0.f;
+            }
+            if (uv && cv) {
+                a.dropped[(size_t)n * a.c + c] = pooled;
+                a.dscale[(size_t)n * a.c + c] = ds;
+            }
+        }
+        const float bf = cv ? pooled : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int o = m * 16 + r;                                       // A operand: Wcat[c][o]
+            float af = 0.f;
+            if (cv) {
+                if (o < a.nc) af = a.wfc[(size_t)c * a.nc + o];
+                else if (o < a.nc + 2) af = a.wfc2[(size_t)c * 2 + (o - a.nc)];
+            }
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[m], 0, 0, 0);
+        }
+    }
+
+    // this lane: utterance r, classes o = 16 m + 4 q + reg
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            if (m * 16 + q * 4 + reg < a.nc) mx = fmaxf(mx, acc[m][reg]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float e[MT][4];
+    float se = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const bool cls = m * 16 + q * 4 + reg < a.nc;
+            e[m][reg] = cls ? expf(acc[m][reg] - mx) : 0.f;
+            se += e[m][reg];
+        }
+    se += __shfl_xor(se, 16);
+    se += __shfl_xor(se, 32);
+    const float lse = logf(se);
+    float part = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int o = m * 16 + q * 4 + reg;
+            const float v = acc[m][reg];
+            if (o < a.nc) {
+                const float p = e[m][reg] / se;
+                if (uv) {
+                    a.logits[(size_t)n * a.nc + o] = v;
+                    a.probs[(size_t)n * a.nc + o] = p;
+                }
+                if (TRAIN) {
+                    float y = a.labels[(size_t)n * a.nc + o];
+                    if (a.label_smoothing > 0.f) y = y * (1.0f - a.label_smoothing) + a.label_smoothing / (float)a.nc;
+                    part -= y * (v - mx - lse);
+                    if (uv) a.dlogits[(size_t)n * a.nc + o] = (p - y) * a.inv_global_batch;
+                }
+            } else if (o < a.nc + 2) {
+                if (uv && a.ranges) a.ranges[(size_t)n * 2 + (o - a.nc)] = 1.0f / (1.0f + expf(-v));   // tc_resnet.py:52
+            }
+        }
+    if (TRAIN) {
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (uv && q == 0) a.loss_utt[n] = part;
+    }
+}
+
+int launch_head_fwd(const HeadArgs& a, bool train, hipStream_t s) {
+    const int mt = ceil_div(a.nc + 2, 16);
+    if (mt > 3) { set_error("head: num_classes %d exceeds the 46-class limit of this build", a.nc); return TCR_ERR_ARG; }
+    const dim3 grid(ceil_div(a.batch, 64));
+#define TCR_H(MT_)                                                                                  \
+    if (train) hipLaunchKernelGGL((head_fwd_kernel<MT_, true>), grid, dim3(256), 0, s, a);          \
+    else hipLaunchKernelGGL((head_fwd_kernel<MT_, false>), grid, dim3(256), 0, s, a)
+    if (mt == 1) { TCR_H(1); }
+    else if (mt == 2) { TCR_H(2); }
+    else { TCR_H(3); }
+#undef TCR_H
+    return check_launch("head_fwd_kernel");
+}
+
+// dpool[b][c] = (sum_o dlogits[b][o] * Wfc[c][o]) * dscale[b][c]   (fc dgrad + dropout + avg-pool backward)
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ wfc,
+                                                       const float* __restrict__ dscale, float* __restrict__ dpool,
+                                                       int batch, int c, int nc) {
+    const int64_t total = (int64_t)batch * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        const int64_t b = i / c;
+        float s = 0.f;
+        for (int o = 0; o < nc; ++o) s = fmaf(dlogits[b * nc + o], wfc[(size_t)ch * nc + o], s);
+        dpool[i] = s * dscale[i];
+    }
+}
+
+int launch_head_bwd(const float* dlogits, const float* wfc, const float* dscale, float* dpool, int batch, int c, int nc, hipStream_t s) {
+    int64_t blocks = ceil_div64((int64_t)batch * c, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dlogits, wfc, dscale, dpool, batch, c, nc);
+    return check_launch("head_bwd_kernel");
+}
+
+// partial[chunk][c][o] = sum_{b in chunk} dropped[b][c] * dlogits[b][o]
+__global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dropped, const float* __restrict__ dlogits,
+                                                       float* __restrict__ partial, int batch, int c, int nc, int per_block) {
+    const int b0 = blockIdx.x * per_block, b1 = min(b0 + per_block, batch);
+    for (int i = threadIdx.x; i < c * nc; i += 256) {
+        const int ch = i / nc, o = i % nc;
+        float s = 0.f;
+        for (int b = b0; b < b1; ++b) s = fmaf(dropped[(size_t)b * c + ch], dlogits[(size_t)b * nc + o], s);
+        partial[(size_t)blockIdx.x * c * nc + i] = s;
+    }
+}
+
+// out[i] = sum_k partial[k][i]  (double accumulation, fixed order)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nchunk, int n, float* __restrict__ out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += (double)partial[(size_t)k * n + i];
+        out[i] = (float)s;
+    }
+}
+
+int fc_wgrad_chunks(int batch) {
+    int n = ceil_div(batch, 64);
+    if (n > 64) n = 64;
+    return n < 1 ? 1 : n;
+}
+
+int launch_fc_wgrad(const float* dropped, const float* dlogits, float* partial, float* dw, int batch, int c, int nc, hipStream_t s) {
+    const int nchunk = fc_wgrad_chunks(batch);
+    const int per_block = ceil_div(batch, nchunk);
+    const int grid = ceil_div(batch, per_block);
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(grid), dim3(256), 0, s, dropped, dlogits, partial, batch, c, nc, per_block);
+    TCR_TRY(check_launch("fc_wgrad_kernel"));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(c * nc, 256)), dim3(256), 0, s, (const float*)partial, grid, c * nc, dw);
+    return check_launch("sum_partials_kernel");
+}
+
+// out[0] = sum_i in[i]   (single workgroup, double accumulation, fixed order)
+__global__ __launch_bounds__(256) void sum_vector_kernel(const float* __restrict__ in, int n, float* __restrict__ out) {
+    __shared__ double s_part[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)in[i];
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < 256; ++i) tot += s_part[i];
+        out[0] = (float)tot;
+    }
+}
+
+int launch_sum_vector(const float* in, int n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(256), 0, s, in, n, out);
+    return check_launch("sum_vector_kernel");
+}
+
+}  // namespace tcr

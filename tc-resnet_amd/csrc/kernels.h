@@ -1,0 +1,176 @@
+// Argument blocks and host-side launchers of every kernel family; shared between the kernel
+// translation units and the network engine (net.cpp).
+#pragma once
+#include "tcr_common.h"
+
+namespace tcr {
+
+// ---- conv.hip : VALU direct convolutions ----------------------------------------------------
+enum ConvEpilogue { EPI_RAW = 0, EPI_AFFINE = 1 };
+
+struct ConvArgs {
+    const float* x;         // [B][Cin][Tpi]
+    const float* w;         // [K][Cin][Cout]
+    float* y;               // [B][Cout][Tpo]
+    const float* scale;     // [Cout]  (EPI_AFFINE)
+    const float* shift;     // [Cout]
+    const float* res;       // [B][Cout][Tpo] residual added before the final ReLU, or nullptr
+    int npos;               // B * Tout
+    int cin, cout;
+    int tpi, tout, tpo;
+    int xoff;               // HALO - pad_lo
+    int relu;
+};
+
+struct DgradArgs {
+    const float* dy;        // [B][Cout][Tpo]
+    const float* wt;        // [K][Cout][Cin]
+    float* dx;              // [B][Cin][Tpi]
+    const float* add;       // optional [B][Cin][Tpi] tensor accumulated into dx, or nullptr
+    const float* add_mask;  // optional: add is gated by [add_mask > 0] (ReLU of the residual sum)
+    int ngrp;               // B * U, U = ceil(Tin / S)
+    int ugrp;               // U
+    int cin, cout;
+    int tin, tpi, tout, tpo;
+    int pad_lo;
+    int add_bcast;          // add is [B][Cin] broadcast over time
+};
+
+int pick_channel_tile(int c);
+int launch_conv_fwd(int k, int stride, const ConvArgs& a, int epi, hipStream_t s);
+int launch_conv_dgrad(int k, int stride, const DgradArgs& a, hipStream_t s);
+int launch_transpose_weights(const float* w, float* wt, int k, int cin, int cout, hipStream_t s);
+
+// ---- mfma.hip : matrix-core contractions ----------------------------------------------------
+enum { MF_RAW = 0, MF_AFFINE = 1 };
+
+struct Conv1x1Args {
+    const float* x;         // [B][Cin][Tpi]
+    const float* w;         // [Cin][Cout]
+    float* y;               // [B][Cout][Tpo]
+    const float* scale;
+    const float* shift;
+    int npos, cin, cout, tpi, tout, tpo, stride, relu;
+};
+
+int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s);
+size_t wgrad_partial_floats(int k, int cin, int cout, int npos);
+int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
+                      int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s);
+
+// ---- bn.hip ---------------------------------------------------------------------------------
+constexpr int kBnMaxLayers = 40;
+
+struct BnFoldArgs {
+    const float* params;
+    const float* stats;
+    float* out;                 // scale at out_off, shift at out_off + c_pad
+    int n;
+    float eps;
+    int c[kBnMaxLayers];
+    int c_pad[kBnMaxLayers];
+    int64_t gamma_off[kBnMaxLayers], beta_off[kBnMaxLayers], mean_off[kBnMaxLayers], var_off[kBnMaxLayers], out_off[kBnMaxLayers];
+};
+
+struct ChanReduceArgs {
+    const float* y;         // [B][C][Tp]
+    const float* da;        // MODE 1: gradient wrt the activation ([B][C][Tp], or [B][C] when bcast)
+    const float* m1;        // MODE 1: optional ReLU mask sources (activation > 0)
+    const float* m2;
+    const float* mean;      // MODE 1
+    const float* invstd;    // MODE 1
+    float* partial;         // [nchunk][2][C]
+    int npos, c, t, tp;
+    int pos_per_block;
+    int bcast;              // da is [B][C] broadcast over time
+};
+
+struct BnFinalizeArgs {
+    const float* sums;          // [2][C]: sum y, sum y^2
+    const float* gamma;
+    const float* beta;
+    float* moving_mean;
+    float* moving_var;
+    float* scale;               // out: gamma * invstd
+    float* shift;               // out: beta - mean * scale
+    float* mean;                // out (saved for backward)
+    float* invstd;              // out (saved for backward)
+    int c;
+    double count;
+    float decay, eps;
+};
+
+struct BnApplyArgs {
+    const float* y;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* out;
+    int64_t total;      // B * C * Tp
+    int c, t, tp, relu;
+};
+
+struct BnBwdFinalizeArgs {
+    const float* sums;      // [2][C]: sum dz, sum dz*xhat
+    const float* gamma;
+    const float* invstd;
+    float* dgamma;
+    float* dbeta;
+    float* k1;
+    float* k2;
+    float* k3;
+    int c;
+    double count;           // elements per channel over the GLOBAL batch
+};
+
+struct BnBwdApplyArgs {
+    const float* y;
+    const float* da;
+    const float* m1;
+    const float* m2;
+    const float* mean;
+    const float* k1;
+    const float* k2;
+    const float* k3;
+    float* dy;
+    int64_t total;
+    int c, t, tp, bcast;
+};
+
+int launch_bn_fold(const BnFoldArgs& a, hipStream_t s);
+int chan_reduce_chunks(int npos);
+int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t s);
+int launch_chan_sums(const float* partial, int nchunk, int c, float* sums, hipStream_t s);
+int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
+int launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
+int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
+int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s);
+
+// ---- head.hip -------------------------------------------------------------------------------
+struct HeadArgs {
+    const float* feat;          // [B][C][Tp]
+    const float* wfc;           // [C][NC]
+    const float* wfc2;          // [C][2]
+    const float* labels;        // [B][NC] one-hot (train)
+    float* logits;              // [B][NC]
+    float* probs;               // [B][NC]
+    float* ranges;              // [B][2] or nullptr
+    float* dropped;             // [B][C]   (train) input of fc after dropout
+    float* dscale;              // [B][C]   (train) d(dropped)/d(sum over time) = mask / keep_prob / T
+    float* dlogits;             // [B][NC]  (train) (p - y) / global_batch
+    float* loss_utt;            // [B]      (train) -sum_k y_k log p_k
+    int batch, c, nc, t, tp;
+    float keep_prob;
+    uint64_t seed;
+    int64_t sample_offset;
+    float inv_global_batch;
+    float label_smoothing;
+};
+
+int launch_head_fwd(const HeadArgs& a, bool train, hipStream_t s);
+int launch_head_bwd(const float* dlogits, const float* wfc, const float* dscale, float* dpool, int batch, int c, int nc, hipStream_t s);
+int fc_wgrad_chunks(int batch);
+int launch_fc_wgrad(const float* dropped, const float* dlogits, float* partial, float* dw, int batch, int c, int nc, hipStream_t s);
+int launch_sum_vector(const float* in, int n, float* out, hipStream_t s);
+
+}  // namespace tcr

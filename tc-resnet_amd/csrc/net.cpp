@@ -1,0 +1,619 @@
+// TC-ResNet engine: turns a tcr_tcresnet_cfg into a layer table (the topology of
+// audio_nets/tc_resnet.py:6-54), lays out the flat parameter / moving-stat arenas and the caller's
+// workspace, and sequences the gfx950 kernels for eval-mode forward, train-mode forward and
+// backward.  Host-only state; every device buffer belongs to the caller.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace tcr {
+
+struct ConvLayer {
+    std::string name;           // scope under the model scope, e.g. "block0/conv0_0"
+    int k = 1, stride = 1, cin = 0, cout = 0;
+    int tin = 0, tout = 0, pad_lo = 0, pad_hi = 0;
+    bool bn = true, relu = true;
+    int64_t w_off = -1, gamma_off = -1, beta_off = -1;      // trainable arena (floats)
+    int64_t mean_off = -1, var_off = -1;                    // moving-stat arena (floats)
+    int c_pad = 0;
+    int64_t ss_off = -1;        // scale/shift slot inside the workspace "ss" region (floats)
+    int in_act = -1;            // index of the activation feeding this conv (-1: the feature input)
+};
+
+struct Block {
+    int down = -1, a = -1, b = -1;
+};
+
+}  // namespace tcr
+
+using namespace tcr;
+
+struct tcr_net {
+    tcr_tcresnet_cfg cfg;
+    std::vector<ConvLayer> layers;      // conv0, per block [down], a, b; then fc, fc2
+    std::vector<Block> blocks;
+    int fc = -1, fc2 = -1;
+    std::vector<int> units;             // BN'd conv layers in forward execution order
+    int64_t param_floats = 0, decay_floats = 0, stat_floats = 0;
+    std::vector<tcr_tensor_info> tensors;
+    int feat_c = 0, feat_t = 0;
+};
+
+namespace tcr {
+
+static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// ---- workspace carving ------------------------------------------------------------------------
+struct Workspace {
+    // offsets in floats; -1 when absent
+    int64_t ss = 0;                         // folded / batch scale+shift per BN layer
+    std::vector<int64_t> act;               // activation (post BN/ReLU/residual) per conv layer
+    std::vector<int64_t> raw;               // raw conv output per BN layer (train)
+    std::vector<int64_t> dyb;               // grad wrt raw conv output (train)
+    std::vector<int64_t> gact;              // grad wrt activation per conv layer (train)
+    std::vector<int64_t> mean, invstd;      // saved batch statistics (train)
+    int64_t partial = -1, sums = -1, kcoef = -1;
+    int64_t dropped = -1, dscale = -1, dlogits = -1, loss_utt = -1, dpool = -1;
+    int64_t wgrad_scratch = -1, wt = -1, fc_partial = -1;
+    int64_t total = 0;
+};
+
+static Workspace carve(const tcr_net& net, int batch, bool train) {
+    Workspace w;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t at = o; o += align_up(n, 64); return at; };
+    const size_t nl = net.layers.size();
+    w.act.assign(nl, -1); w.raw.assign(nl, -1); w.dyb.assign(nl, -1); w.gact.assign(nl, -1);
+    w.mean.assign(nl, -1); w.invstd.assign(nl, -1);
+    int64_t ss = 0;
+    for (const ConvLayer& l : net.layers) if (l.bn) ss += 2 * l.c_pad;
+    w.ss = take(ss);
+    int cmax = 0;
+    int64_t wmax = 0, wgmax = 0;
+    for (size_t i = 0; i < nl; ++i) {
+        const ConvLayer& l = net.layers[i];
+        if (!l.bn) continue;
+        const int64_t n = (int64_t)batch * l.cout * tcr_padded_len(l.tout);
+        w.act[i] = take(n);
+        if (train) {
+            w.raw[i] = take(n);
+            w.dyb[i] = take(n);
+            w.gact[i] = take(n);
+            w.mean[i] = take(l.c_pad);
+            w.invstd[i] = take(l.c_pad);
+        }
+        cmax = l.cout > cmax ? l.cout : cmax;
+        const int64_t wsz = (int64_t)l.k * l.cin * l.cout;
+        wmax = wsz > wmax ? wsz : wmax;
+        const int64_t wg = (int64_t)wgrad_partial_floats(l.k, l.cin, l.cout, batch * l.tout);
+        wgmax = wg > wgmax ? wg : wgmax;
+    }
+    if (train) {
+        w.partial = take((int64_t)128 * 2 * cmax);
+        w.sums = take(2 * cmax);
+        w.kcoef = take(3 * (int64_t)align_up(cmax, 64));
+        const int c = net.feat_c, nc = net.cfg.num_classes;
+        w.dropped = take((int64_t)batch * c);
+        w.dscale = take((int64_t)batch * c);
+        w.dpool = take((int64_t)batch * c);
+        w.dlogits = take((int64_t)batch * nc);
+        w.loss_utt = take(batch);
+        w.wgrad_scratch = take(wgmax);
+        w.wt = take(wmax);
+        w.fc_partial = take((int64_t)fc_wgrad_chunks(batch) * c * nc);
+    }
+    w.total = o;
+    return w;
+}
+
+}  // namespace tcr
+
+// ---- construction -----------------------------------------------------------------------------
+extern "C" int tcr_tcresnet_create(const tcr_tcresnet_cfg* cfg, tcr_net** out) {
+    TCR_REQUIRE(cfg && out, "tcr_tcresnet_create: null argument");
+    TCR_REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= TCR_MAX_BLOCKS, "tcr_tcresnet_create: n_blocks %d out of range", cfg->n_blocks);
+    TCR_REQUIRE(cfg->in_channels > 0 && cfg->t_in > 0 && cfg->num_classes > 0, "tcr_tcresnet_create: bad input shape");
+    TCR_REQUIRE(cfg->num_classes + 2 <= 48, "tcr_tcresnet_create: num_classes %d exceeds the 46-class head of this build", cfg->num_classes);
+    for (int i = 0; i <= cfg->n_blocks; ++i)
+        TCR_REQUIRE(cfg->channels[i] > 0, "tcr_tcresnet_create: channels[%d] = %d", i, cfg->channels[i]);
+    TCR_REQUIRE(std::strlen(cfg->scope) > 0 && std::strlen(cfg->scope) < sizeof(cfg->scope), "tcr_tcresnet_create: empty scope");
+
+    tcr_net* net = new tcr_net();
+    net->cfg = *cfg;
+    auto add_conv = [&](const std::string& name, int k, int stride, int cin, int cout, int tin, bool bn, bool relu, int in_act) {
+        ConvLayer l;
+        l.name = name; l.k = k; l.stride = stride; l.cin = cin; l.cout = cout; l.tin = tin;
+        same_pad(tin, k, stride, &l.tout, &l.pad_lo, &l.pad_hi);
+        l.bn = bn; l.relu = relu; l.c_pad = (int)align_up(cout, 64); l.in_act = in_act;
+        net->layers.push_back(l);
+        return (int)net->layers.size() - 1;
+    };
+    // tc_resnet(): conv0 3x1 s1 (:21); per block: [down 1x1 s2] (:29-32), conv 9x1 s, conv 9x1 s1 no activation (:37-39)
+    int cur = add_conv("conv0", 3, 1, cfg->in_channels, cfg->channels[0], cfg->t_in, true, true, -1);
+    net->units.push_back(cur);
+    int c = cfg->channels[0], t = net->layers[cur].tout;
+    for (int i = 0; i < cfg->n_blocks; ++i) {
+        const int n = cfg->channels[i + 1];
+        Block b;
+        int stride = 1;
+        const std::string pre = "block" + std::to_string(i) + "/";
+        if (n != c) {
+            stride = 2;
+            b.down = add_conv(pre + "down", 1, 2, c, n, t, true, true, cur);
+            net->units.push_back(b.down);
+        }
+        b.a = add_conv(pre + "conv" + std::to_string(i) + "_0", 9, stride, c, n, t, true, true, cur);
+        net->units.push_back(b.a);
+        b.b = add_conv(pre + "conv" + std::to_string(i) + "_1", 9, 1, n, n, net->layers[b.a].tout, true, false, b.a);
+        net->units.push_back(b.b);
+        net->blocks.push_back(b);
+        cur = b.b;
+        c = n;
+        t = net->layers[b.b].tout;
+    }
+    net->feat_c = c;
+    net->feat_t = t;
+    net->fc = add_conv("fc", 1, 1, c, cfg->num_classes, 1, false, false, cur);     // :47
+    net->fc2 = add_conv("fc2", 1, 1, c, 2, 1, false, false, cur);                  // :50
+    for (const ConvLayer& l : net->layers) {
+        if (l.pad_lo > TCR_HALO || l.pad_hi > TCR_HALO) {
+            set_error("tcr_tcresnet_create: layer %s needs padding (%d,%d) beyond the %d-sample halo", l.name.c_str(), l.pad_lo, l.pad_hi, TCR_HALO);
+            delete net;
+            return TCR_ERR_ARG;
+        }
+    }
+    if ((int)net->units.size() > kBnMaxLayers) {
+        set_error("tcr_tcresnet_create: %d BN layers exceed the limit %d", (int)net->units.size(), kBnMaxLayers);
+        delete net;
+        return TCR_ERR_ARG;
+    }
+
+    // arenas: weights (L2-decayed) first, then gamma/beta; every tensor starts on a 64-float
+    // boundary and is followed by >= 64 floats of zero padding (channel-tile over-reads land there).
+    const std::string scope = cfg->scope;
+    auto info = [&](const std::string& name, int kind, int arena, int64_t off, int64_t size, std::vector<int> shape) {
+        tcr_tensor_info ti;
+        std::memset(&ti, 0, sizeof(ti));
+        std::snprintf(ti.name, sizeof(ti.name), "%s/%s", scope.c_str(), name.c_str());
+        ti.kind = kind; ti.arena = arena; ti.offset = off; ti.size = size; ti.rank = (int)shape.size();
+        for (size_t i = 0; i < shape.size() && i < 4; ++i) ti.shape[i] = shape[i];
+        net->tensors.push_back(ti);
+    };
+    int64_t o = 0;
+    for (ConvLayer& l : net->layers) {
+        l.w_off = o;
+        const int64_t n = (int64_t)l.k * l.cin * l.cout;
+        info(l.name + "/weights", TCR_WEIGHT, 0, o, n, {l.k, 1, l.cin, l.cout});
+        o = align_up(o + n + 64, 64);
+    }
+    net->decay_floats = o;
+    int64_t so = 0, ss = 0;
+    for (ConvLayer& l : net->layers) {
+        if (!l.bn) continue;
+        l.gamma_off = o;
+        info(l.name + "/BatchNorm/gamma", TCR_GAMMA, 0, o, l.cout, {l.cout});
+        o += l.c_pad;
+        l.beta_off = o;
+        info(l.name + "/BatchNorm/beta", TCR_BETA, 0, o, l.cout, {l.cout});
+        o += l.c_pad;
+        l.mean_off = so;
+        info(l.name + "/BatchNorm/moving_mean", TCR_MOVING_MEAN, 1, so, l.cout, {l.cout});
+        so += l.c_pad;
+        l.var_off = so;
+        info(l.name + "/BatchNorm/moving_variance", TCR_MOVING_VAR, 1, so, l.cout, {l.cout});
+        so += l.c_pad;
+        l.ss_off = ss;
+        ss += 2 * l.c_pad;
+    }
+    net->param_floats = o;
+    net->stat_floats = so;
+    *out = net;
+    return TCR_OK;
+}
+
+extern "C" void tcr_net_destroy(tcr_net* net) { delete net; }
+extern "C" int64_t tcr_net_param_floats(const tcr_net* net) { return net ? net->param_floats : 0; }
+extern "C" int64_t tcr_net_decay_floats(const tcr_net* net) { return net ? net->decay_floats : 0; }
+extern "C" int64_t tcr_net_stat_floats(const tcr_net* net) { return net ? net->stat_floats : 0; }
+extern "C" int tcr_net_num_tensors(const tcr_net* net) { return net ? (int)net->tensors.size() : 0; }
+extern "C" int tcr_net_out_frames(const tcr_net* net) { return net ? net->feat_t : 0; }
+extern "C" int tcr_net_feat_channels(const tcr_net* net) { return net ? net->feat_c : 0; }
+
+extern "C" int tcr_net_tensor_info(const tcr_net* net, int index, tcr_tensor_info* out) {
+    TCR_REQUIRE(net && out, "tcr_net_tensor_info: null argument");
+    TCR_REQUIRE(index >= 0 && index < (int)net->tensors.size(), "tcr_net_tensor_info: index %d out of range", index);
+    *out = net->tensors[index];
+    return TCR_OK;
+}
+
+extern "C" size_t tcr_net_workspace_bytes(const tcr_net* net, int batch, int train) {
+    if (!net || batch <= 0) return 0;
+    return (size_t)carve(*net, batch, train != 0).total * sizeof(float);
+}
+
+extern "C" int tcr_net_num_stages(const tcr_net* net, int backward) {
+    (void)backward;
+    return net ? (int)net->units.size() + 1 : 0;
+}
+
+// ---- eval-mode forward ------------------------------------------------------------------------
+namespace tcr {
+
+static const float* layer_input(const tcr_net& net, const Workspace& w, const float* base, const float* feat, const ConvLayer& l) {
+    return l.in_act < 0 ? feat : base + w.act[l.in_act];
+}
+
+static int conv_forward(const tcr_net& net, const ConvLayer& l, const float* x, const float* params, float* y,
+                        const float* scale, const float* shift, const float* res, bool relu, int epi, int batch, hipStream_t s) {
+    (void)net;
+    if (l.k == 1 && res == nullptr) {
+        Conv1x1Args a;
+        a.x = x; a.w = params + l.w_off; a.y = y; a.scale = scale; a.shift = shift;
+        a.npos = batch * l.tout; a.cin = l.cin; a.cout = l.cout;
+        a.tpi = tcr_padded_len(l.tin); a.tout = l.tout; a.tpo = tcr_padded_len(l.tout);
+        a.stride = l.stride; a.relu = relu;
+        return launch_conv1x1(a, epi == EPI_AFFINE ? MF_AFFINE : MF_RAW, s);
+    }
+    ConvArgs a;
+    a.x = x; a.w = params + l.w_off; a.y = y; a.scale = scale; a.shift = shift; a.res = res;
+    a.npos = batch * l.tout; a.cin = l.cin; a.cout = l.cout;
+    a.tpi = tcr_padded_len(l.tin); a.tout = l.tout; a.tpo = tcr_padded_len(l.tout);
+    a.xoff = TCR_HALO - l.pad_lo; a.relu = relu;
+    return launch_conv_fwd(l.k, l.stride, a, epi, s);
+}
+
+}  // namespace tcr
+
+extern "C" int tcr_net_forward_infer(const tcr_net* net, const float* params, const float* stats, const float* feat,
+                                     int batch, void* workspace, size_t workspace_bytes,
+                                     float* logits, float* probs, float* ranges, void* stream) {
+    TCR_REQUIRE(net && params && stats && feat && workspace && logits && probs, "tcr_net_forward_infer: null argument");
+    TCR_REQUIRE(batch > 0, "tcr_net_forward_infer: batch must be positive (got %d)", batch);
+    const Workspace w = carve(*net, batch, false);
+    if ((size_t)w.total * sizeof(float) > workspace_bytes) {
+        set_error("tcr_net_forward_infer: workspace %zu bytes < required %zu", workspace_bytes, (size_t)w.total * sizeof(float));
+        return TCR_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* base = static_cast<float*>(workspace);
+    float* ss = base + w.ss;
+
+    BnFoldArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.params = params; f.stats = stats; f.out = ss; f.eps = net->cfg.bn_eps;
+    for (int li : net->units) {
+        const ConvLayer& l = net->layers[li];
+        f.c[f.n] = l.cout; f.c_pad[f.n] = l.c_pad;
+        f.gamma_off[f.n] = l.gamma_off; f.beta_off[f.n] = l.beta_off;
+        f.mean_off[f.n] = l.mean_off; f.var_off[f.n] = l.var_off; f.out_off[f.n] = l.ss_off;
+        ++f.n;
+    }
+    TCR_TRY(launch_bn_fold(f, s));
+
+    auto run = [&](int li, const float* res) -> int {
+        const ConvLayer& l = net->layers[li];
+        const float* x = layer_input(*net, w, base, feat, l);
+        return conv_forward(*net, l, x, params, base + w.act[li], ss + l.ss_off, ss + l.ss_off + l.c_pad, res, l.relu, EPI_AFFINE, batch, s);
+    };
+    TCR_TRY(run(0, nullptr));
+    int cur = 0;
+    for (const Block& b : net->blocks) {
+        const float* shortcut = base + w.act[cur];
+        if (b.down >= 0) {
+            TCR_TRY(run(b.down, nullptr));
+            shortcut = base + w.act[b.down];
+        }
+        TCR_TRY(run(b.a, nullptr));
+        TCR_TRY(run(b.b, shortcut));
+        cur = b.b;
+    }
+    HeadArgs h;
+    std::memset(&h, 0, sizeof(h));
+    h.feat = base + w.act[cur];
+    h.wfc = params + net->layers[net->fc].w_off;
+    h.wfc2 = params + net->layers[net->fc2].w_off;
+    h.logits = logits; h.probs = probs; h.ranges = ranges;
+    h.batch = batch; h.c = net->feat_c; h.nc = net->cfg.num_classes; h.t = net->feat_t; h.tp = tcr_padded_len(net->feat_t);
+    h.keep_prob = 1.0f; h.inv_global_batch = 1.0f;
+    return launch_head_fwd(h, false, s);
+}
+
+// ---- train-mode forward -----------------------------------------------------------------------
+namespace tcr {
+
+struct TrainCtx {
+    const tcr_net* net;
+    Workspace w;
+    float* base;
+    const float* params;
+    const float* feat;
+    int batch;
+    double bn_batch;        // batch the BN statistics are taken over (global batch under sync BN)
+    hipStream_t s;
+};
+
+// conv + per-channel sums of the raw output (everything before the cross-replica hand-off)
+static int fwd_unit_pre(const TrainCtx& c, int li) {
+    const ConvLayer& l = c.net->layers[li];
+    const float* x = layer_input(*c.net, c.w, c.base, c.feat, l);
+    float* raw = c.base + c.w.raw[li];
+    TCR_TRY(conv_forward(*c.net, l, x, c.params, raw, nullptr, nullptr, nullptr, false, EPI_RAW, c.batch, c.s));
+    ChanReduceArgs r;
+    std::memset(&r, 0, sizeof(r));
+    r.y = raw; r.partial = c.base + c.w.partial;
+    r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout);
+    int nchunk = 0;
+    TCR_TRY(launch_chan_reduce(0, r, &nchunk, c.s));
+    return launch_chan_sums(c.base + c.w.partial, nchunk, l.cout, c.base + c.w.sums, c.s);
+}
+
+// statistics -> scale/shift, moving-stat update, normalise (+ReLU / +residual)
+static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* res) {
+    const ConvLayer& l = c.net->layers[li];
+    float* ss = c.base + c.w.ss + l.ss_off;
+    BnFinalizeArgs f;
+    f.sums = c.base + c.w.sums;
+    f.gamma = c.params + l.gamma_off; f.beta = c.params + l.beta_off;
+    f.moving_mean = stats + l.mean_off; f.moving_var = stats + l.var_off;
+    f.scale = ss; f.shift = ss + l.c_pad;
+    f.mean = c.base + c.w.mean[li]; f.invstd = c.base + c.w.invstd[li];
+    f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
+    f.decay = c.net->cfg.bn_decay; f.eps = c.net->cfg.bn_eps;
+    TCR_TRY(launch_bn_finalize(f, c.s));
+    BnApplyArgs a;
+    a.y = c.base + c.w.raw[li]; a.scale = ss; a.shift = ss + l.c_pad; a.res = res; a.out = c.base + c.w.act[li];
+    a.total = (int64_t)c.batch * l.cout * tcr_padded_len(l.tout);
+    a.c = l.cout; a.t = l.tout; a.tp = tcr_padded_len(l.tout); a.relu = l.relu;
+    return launch_bn_apply(a, c.s);
+}
+
+// residual source of a unit: conv_b of a block adds the block's shortcut
+static const float* unit_residual(const TrainCtx& c, int li) {
+    int cur = 0;
+    for (const Block& b : c.net->blocks) {
+        if (b.b == li) return c.base + c.w.act[b.down >= 0 ? b.down : cur];
+        cur = b.b;
+    }
+    return nullptr;
+}
+
+}  // namespace tcr
+
+static int forward_train_stages(const tcr_net* net, const float* params, float* stats, const float* feat,
+                                const float* labels, int batch, int global_batch, int sync_bn, float keep_prob,
+                                uint64_t seed, int64_t sample_offset, float label_smoothing,
+                                void* workspace, size_t workspace_bytes, float* logits, float* probs, float* loss_out,
+                                int stage_begin, int stage_end, void* stream) {
+    TCR_REQUIRE(net && params && stats && feat && labels && workspace && logits && probs && loss_out, "tcr_net_forward_train: null argument");
+    TCR_REQUIRE(batch > 0 && global_batch >= batch, "tcr_net_forward_train: batch %d / global_batch %d", batch, global_batch);
+    TCR_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "tcr_net_forward_train: keep_prob %g outside (0, 1]", keep_prob);
+    TrainCtx c;
+    c.net = net; c.w = carve(*net, batch, true);
+    if ((size_t)c.w.total * sizeof(float) > workspace_bytes) {
+        set_error("tcr_net_forward_train: workspace %zu bytes < required %zu", workspace_bytes, (size_t)c.w.total * sizeof(float));
+        return TCR_ERR_WORKSPACE;
+    }
+    c.base = static_cast<float*>(workspace); c.params = params; c.feat = feat; c.batch = batch;
+    c.bn_batch = sync_bn ? (double)global_batch : (double)batch;
+    c.s = static_cast<hipStream_t>(stream);
+    const int nu = (int)net->units.size();
+    TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_forward_train: bad stage range [%d, %d)", stage_begin, stage_end);
+    for (int st = stage_begin; st < stage_end; ++st) {
+        if (st > 0) {
+            const int li = net->units[st - 1];
+            TCR_TRY(fwd_unit_post(c, li, stats, unit_residual(c, li)));
+        }
+        if (st < nu) {
+            TCR_TRY(fwd_unit_pre(c, net->units[st]));
+        } else {
+            HeadArgs h;
+            std::memset(&h, 0, sizeof(h));
+            h.feat = c.base + c.w.act[net->units[nu - 1]];
+            h.wfc = params + net->layers[net->fc].w_off;
+            h.wfc2 = params + net->layers[net->fc2].w_off;
+            h.labels = labels; h.logits = logits; h.probs = probs; h.ranges = nullptr;
+            h.dropped = c.base + c.w.dropped; h.dscale = c.base + c.w.dscale;
+            h.dlogits = c.base + c.w.dlogits; h.loss_utt = c.base + c.w.loss_utt;
+            h.batch = batch; h.c = net->feat_c; h.nc = net->cfg.num_classes; h.t = net->feat_t; h.tp = tcr_padded_len(net->feat_t);
+            h.keep_prob = keep_prob; h.seed = seed; h.sample_offset = sample_offset;
+            h.inv_global_batch = 1.0f / (float)global_batch; h.label_smoothing = label_smoothing;
+            TCR_TRY(launch_head_fwd(h, true, c.s));
+            TCR_TRY(launch_sum_vector(c.base + c.w.loss_utt, batch, loss_out, c.s));
+        }
+    }
+    return TCR_OK;
+}
+
+extern "C" int tcr_net_forward_train(const tcr_net* net, const float* params, float* stats, const float* feat,
+                                     const float* labels, int batch, int global_batch, float keep_prob,
+                                     uint64_t seed, int64_t sample_offset, float label_smoothing,
+                                     void* workspace, size_t workspace_bytes,
+                                     float* logits, float* probs, float* loss_out, void* stream) {
+    const int nu = net ? (int)net->units.size() : 0;
+    return forward_train_stages(net, params, stats, feat, labels, batch, global_batch, 0, keep_prob, seed, sample_offset,
+                                label_smoothing, workspace, workspace_bytes, logits, probs, loss_out, 0, nu + 1, stream);
+}
+
+extern "C" int tcr_net_forward_train_stage(const tcr_net* net, const float* params, float* stats, const float* feat,
+                                           const float* labels, int batch, int global_batch, float keep_prob,
+                                           uint64_t seed, int64_t sample_offset, float label_smoothing,
+                                           void* workspace, size_t workspace_bytes,
+                                           float* logits, float* probs, float* loss_out, int stage, void* stream) {
+    return forward_train_stages(net, params, stats, feat, labels, batch, global_batch, 1, keep_prob, seed, sample_offset,
+                                label_smoothing, workspace, workspace_bytes, logits, probs, loss_out, stage, stage + 1, stream);
+}
+
+namespace tcr { static std::vector<int> backward_order(const tcr_net& net); }
+
+extern "C" int tcr_net_stage_sums(const tcr_net* net, int backward, int stage, void* workspace, int batch,
+                                  float** sums_dev, int64_t* n_floats) {
+    TCR_REQUIRE(net && workspace && sums_dev && n_floats, "tcr_net_stage_sums: null argument");
+    const int nu = (int)net->units.size();
+    TCR_REQUIRE(stage >= 0 && stage < nu, "tcr_net_stage_sums: stage %d has no BN hand-off", stage);
+    const Workspace w = carve(*net, batch, true);
+    const int li = backward ? backward_order(*net)[stage] : net->units[stage];
+    *sums_dev = static_cast<float*>(workspace) + w.sums;
+    *n_floats = 2 * (int64_t)net->layers[li].cout;
+    return TCR_OK;
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+namespace tcr {
+
+struct BwdUnit {
+    int li;                 // conv layer
+    const float* da;        // gradient wrt the unit's (post-activation) output
+    int da_bcast;           // da is [B][C] (pooled gradient broadcast over time)
+    const float* m1;        // ReLU masks applied to da
+    const float* m2;
+};
+
+static BwdUnit bwd_unit_of(const TrainCtx& c, int li, const float* dpool) {
+    const tcr_net& net = *c.net;
+    BwdUnit u;
+    u.li = li; u.da = nullptr; u.da_bcast = 0; u.m1 = nullptr; u.m2 = nullptr;
+    const int last = net.blocks.back().b;
+    // gradient wrt the OUTPUT activation of block-output layer `b`
+    auto grad_of_block_out = [&](int b, const float** g, int* bc) {
+        if (b == last) { *g = dpool; *bc = 1; }
+        else { *g = c.base + c.w.gact[b]; *bc = 0; }
+    };
+    if (li == 0) {          // conv0: da = gradient wrt act[conv0], own ReLU
+        u.da = c.base + c.w.gact[0]; u.m1 = c.base + c.w.act[0];
+        return u;
+    }
+    for (const Block& b : net.blocks) {
+        if (li == b.b) {            // dz = dOut * [out > 0]
+            grad_of_block_out(b.b, &u.da, &u.da_bcast);
+            u.m1 = c.base + c.w.act[b.b];
+        } else if (li == b.a) {     // da = dgrad of conv_b, own ReLU
+            u.da = c.base + c.w.gact[b.a]; u.m1 = c.base + c.w.act[b.a];
+        } else if (li == b.down) {  // shortcut: dOut * [out > 0] * [down > 0]
+            grad_of_block_out(b.b, &u.da, &u.da_bcast);
+            u.m1 = c.base + c.w.act[b.b]; u.m2 = c.base + c.w.act[b.down];
+        }
+    }
+    return u;
+}
+
+static int bwd_unit_pre(const TrainCtx& c, const BwdUnit& u) {
+    const ConvLayer& l = c.net->layers[u.li];
+    ChanReduceArgs r;
+    std::memset(&r, 0, sizeof(r));
+    r.y = c.base + c.w.raw[u.li]; r.da = u.da; r.m1 = u.m1; r.m2 = u.m2;
+    r.mean = c.base + c.w.mean[u.li]; r.invstd = c.base + c.w.invstd[u.li];
+    r.partial = c.base + c.w.partial;
+    r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout); r.bcast = u.da_bcast;
+    int nchunk = 0;
+    TCR_TRY(launch_chan_reduce(1, r, &nchunk, c.s));
+    return launch_chan_sums(c.base + c.w.partial, nchunk, l.cout, c.base + c.w.sums, c.s);
+}
+
+static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, const float* dpool) {
+    const tcr_net& net = *c.net;
+    const ConvLayer& l = net.layers[u.li];
+    const int tp = tcr_padded_len(l.tout), tpi = tcr_padded_len(l.tin);
+    float* kc = c.base + c.w.kcoef;
+    const int64_t kstride = align_up(l.cout, 64);
+    BnBwdFinalizeArgs f;
+    f.sums = c.base + c.w.sums; f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[u.li];
+    f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
+    f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
+    f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
+    TCR_TRY(launch_bn_bwd_finalize(f, c.s));
+    float* dy = c.base + c.w.dyb[u.li];
+    BnBwdApplyArgs a;
+    a.y = c.base + c.w.raw[u.li]; a.da = u.da; a.m1 = u.m1; a.m2 = u.m2; a.mean = c.base + c.w.mean[u.li];
+    a.k1 = f.k1; a.k2 = f.k2; a.k3 = f.k3; a.dy = dy;
+    a.total = (int64_t)c.batch * l.cout * tp; a.c = l.cout; a.t = l.tout; a.tp = tp; a.bcast = u.da_bcast;
+    TCR_TRY(launch_bn_bwd_apply(a, c.s));
+    // weight gradient
+    const float* x = layer_input(net, c.w, c.base, c.feat, l);
+    TCR_TRY(launch_conv_wgrad(l.k, l.stride, l.pad_lo, x, dy, grads + l.w_off, c.base + c.w.wgrad_scratch,
+                              c.batch, l.cin, l.cout, tpi, l.tout, tp, c.s));
+    if (l.in_act < 0) return TCR_OK;        // no gradient flows into the features
+    // data gradient into gact[in_act]
+    float* wt = c.base + c.w.wt;
+    TCR_TRY(launch_transpose_weights(c.params + l.w_off, wt, l.k, l.cin, l.cout, c.s));
+    DgradArgs d;
+    std::memset(&d, 0, sizeof(d));
+    d.dy = dy; d.wt = wt; d.dx = c.base + c.w.gact[l.in_act];
+    d.ugrp = ceil_div(l.tin, l.stride); d.ngrp = c.batch * d.ugrp;
+    d.cin = l.cin; d.cout = l.cout; d.tin = l.tin; d.tpi = tpi; d.tout = l.tout; d.tpo = tp; d.pad_lo = l.pad_lo;
+    // second contribution to the block input: the shortcut branch
+    for (size_t bi = 0; bi < net.blocks.size(); ++bi) {
+        const Block& b = net.blocks[bi];
+        if (u.li == b.down) {               // conv_a's dgrad ran first and already wrote gact[in]
+            d.add = d.dx;
+        } else if (u.li == b.a && b.down < 0) {     // identity shortcut: + dOut * [out > 0]
+            if (b.b == net.blocks.back().b) { d.add = dpool; d.add_bcast = 1; }
+            else d.add = c.base + c.w.gact[b.b];
+            d.add_mask = c.base + c.w.act[b.b];
+        }
+    }
+    return launch_conv_dgrad(l.k, l.stride, d, c.s);
+}
+
+// backward execution order of the BN units: reverse blocks; inside a block conv_b, conv_a, down
+static std::vector<int> backward_order(const tcr_net& net) {
+    std::vector<int> order;
+    for (int bi = (int)net.blocks.size() - 1; bi >= 0; --bi) {
+        const Block& b = net.blocks[bi];
+        order.push_back(b.b);
+        order.push_back(b.a);
+        if (b.down >= 0) order.push_back(b.down);
+    }
+    order.push_back(0);
+    return order;
+}
+
+}  // namespace tcr
+
+static int backward_stages(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch, int sync_bn,
+                           void* workspace, size_t workspace_bytes, float* grads, int stage_begin, int stage_end, void* stream) {
+    TCR_REQUIRE(net && params && feat && workspace && grads, "tcr_net_backward: null argument");
+    TCR_REQUIRE(batch > 0 && global_batch >= batch, "tcr_net_backward: batch %d / global_batch %d", batch, global_batch);
+    TrainCtx c;
+    c.net = net; c.w = carve(*net, batch, true);
+    if ((size_t)c.w.total * sizeof(float) > workspace_bytes) {
+        set_error("tcr_net_backward: workspace %zu bytes < required %zu", workspace_bytes, (size_t)c.w.total * sizeof(float));
+        return TCR_ERR_WORKSPACE;
+    }
+    c.base = static_cast<float*>(workspace); c.params = params; c.feat = feat; c.batch = batch;
+    c.bn_batch = sync_bn ? (double)global_batch : (double)batch;
+    c.s = static_cast<hipStream_t>(stream);
+    const std::vector<int> order = backward_order(*net);
+    const int nu = (int)order.size();
+    TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);
+    const float* dpool = c.base + c.w.dpool;
+    for (int st = stage_begin; st < stage_end; ++st) {
+        if (st == 0) {
+            // head: zero the arena (padding + fc2, which gets no loss gradient), fc wgrad, pooled gradient
+            if (hipMemsetAsync(grads, 0, (size_t)net->param_floats * sizeof(float), c.s) != hipSuccess) {
+                set_error("tcr_net_backward: hipMemsetAsync failed");
+                return TCR_ERR_HIP;
+            }
+            const int nc = net->cfg.num_classes;
+            TCR_TRY(launch_fc_wgrad(c.base + c.w.dropped, c.base + c.w.dlogits, c.base + c.w.fc_partial,
+                                    grads + net->layers[net->fc].w_off, batch, net->feat_c, nc, c.s));
+            TCR_TRY(launch_head_bwd(c.base + c.w.dlogits, params + net->layers[net->fc].w_off, c.base + c.w.dscale,
+                                    c.base + c.w.dpool, batch, net->feat_c, nc, c.s));
+        }
+        if (st > 0) TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, order[st - 1], dpool), grads, dpool));
+        if (st < nu) TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, order[st], dpool)));
+    }
+    return TCR_OK;
+}
+
+extern "C" int tcr_net_backward(const tcr_net* net, const float* params, const float* feat, int batch,
+                                void* workspace, size_t workspace_bytes, float* grads, void* stream) {
+    const int nu = net ? (int)net->units.size() : 0;
+    return backward_stages(net, params, feat, batch, batch, 0, workspace, workspace_bytes, grads, 0, nu + 1, stream);
+}
+
+extern "C" int tcr_net_backward_stage(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch,
+                                      void* workspace, size_t workspace_bytes, float* grads, int stage, void* stream) {
+    return backward_stages(net, params, feat, batch, global_batch, 1, workspace, workspace_bytes, grads, stage, stage + 1, stream);
+}

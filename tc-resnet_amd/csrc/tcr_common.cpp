@@ -1,0 +1,40 @@
+// Error plumbing and ABI bookkeeping shared by every translation unit.
+#include "tcr_common.h"
+
+#include <cstring>
+
+namespace tcr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return TCR_ERR_HIP;
+    }
+    return TCR_OK;
+}
+
+}  // namespace tcr
+
+extern "C" int tcr_abi_version(void) { return TCR_ABI_VERSION; }
+extern "C" const char* tcr_last_error(void) { return tcr::g_err; }
+
+extern "C" const char* tcr_kernel_name(int index) {
+    static const char* names[] = {
+        "frontend_kernel", "conv_fwd_kernel", "conv1x1_mfma_kernel", "head_fwd_kernel",
+        "bn_finalize_kernel", "bn_apply_kernel", "head_bwd_kernel", "bn_bwd_reduce_kernel",
+        "bn_bwd_apply_kernel", "conv_dgrad_kernel", "conv_wgrad_mfma_kernel", "wgrad_reduce_kernel",
+        "sgd_momentum_kernel", "adam_kernel", "l2_loss_kernel",
+    };
+    const int n = (int)(sizeof(names) / sizeof(names[0]));
+    return (index >= 0 && index < n) ? names[index] : nullptr;
+}

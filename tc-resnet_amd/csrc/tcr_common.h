@@ -1,0 +1,70 @@
+// Shared host/device helpers for the gfx950 TC-ResNet kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/tcresnet_hip.h"
+
+namespace tcr {
+
+constexpr int kHalo = TCR_HALO;
+constexpr int kWave = 64;
+
+// ---- error plumbing (thread-local message behind tcr_last_error) --------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);      // hipGetLastError -> TCR_OK / TCR_ERR_HIP
+
+#define TCR_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::tcr::set_error(__VA_ARGS__);     \
+            return TCR_ERR_ARG;                \
+        }                                      \
+    } while (0)
+
+#define TCR_TRY(expr)                          \
+    do {                                       \
+        int _s = (expr);                       \
+        if (_s != TCR_OK) return _s;           \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t round_up64(int64_t a, int64_t b) { return ceil_div64(a, b) * b; }
+
+// TF "SAME" padding rule (extra padding on the high side).
+inline void same_pad(int len, int k, int stride, int* out, int* lo, int* hi) {
+    *out = (len + stride - 1) / stride;
+    int total = (*out - 1) * stride + k - len;
+    if (total < 0) total = 0;
+    *lo = total / 2;
+    *hi = total - *lo;
+}
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// Stateless counter-based uniform in [0,1): two rounds of a 32-bit mixer over (seed, index).
+// Mirrored bit-for-bit in tests (numpy) so that dropout masks are reproducible on the host.
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t index) {
+    uint32_t lo = (uint32_t)index, hi = (uint32_t)(index >> 32);
+    uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    uint32_t h = mix32(lo ^ mix32(hi ^ mix32(s0 ^ mix32(s1 + 0x9e3779b9U))));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+}  // namespace tcr

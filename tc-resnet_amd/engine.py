@@ -1,0 +1,335 @@
+"""Host-side objects over the C ABI: the MFCC front-end and the TC-ResNet engine.
+
+PyTorch is used here for device memory, streams and (in `parallel.py`) torch.distributed only --
+every number on the path is produced by the HIP kernels behind `include/tcresnet_hip.h`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HALO, FrontendCfg, TCResNetCfg, TensorInfo, TcrError, padded_len
+
+
+def _resolve(lib: Optional[_lib.Library], device) -> Tuple[_lib.Library, torch.device]:
+    if lib is None:
+        lib = _lib.get()            # raises when the HIP extension is missing
+    if lib.kind == "hip":
+        if not torch.cuda.is_available():
+            raise TcrError("the gfx950 library needs a visible AMD GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+        dev = torch.device(device if device is not None else "cuda")
+        if dev.type != "cuda":
+            raise TcrError(f"device {dev} is not a GPU; the HIP path has no CPU fallback")
+    else:                            # emulator build: tests only
+        dev = torch.device("cpu")
+    return lib, dev
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class _Base:
+    def _stream(self):
+        if self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return None
+
+    def _check_tensor(self, t: torch.Tensor, what: str):
+        if t.device.type != self.device.type or t.dtype != torch.float32 or not t.is_contiguous():
+            raise TcrError(f"{what}: expected a contiguous float32 tensor on {self.device}, got {t.dtype} on {t.device}"
+                           f"{'' if t.is_contiguous() else ' (non-contiguous)'}")
+
+
+class Frontend(_Base):
+    """MFCC / log-mel front-end (datasets/preprocessors.py:54-96,183-194 of the reference)."""
+
+    METHODS = {"mfcc": 0, "log_mel_spectrogram": 1}
+
+    def __init__(self, sample_rate: int = 16000, clip_duration_ms: int = 1000, window_size_samples: int = 480,
+                 window_stride_samples: int = 160, num_mel_bins: int = 64, num_mfccs: int = 40,
+                 lower_edge_hertz: float = 80.0, upper_edge_hertz: float = 7600.0, method: str = "mfcc",
+                 lib: Optional[_lib.Library] = None, device=None):
+        self.lib, self.device = _resolve(lib, device)
+        if method not in self.METHODS:
+            raise NotImplementedError(method)
+        cfg = FrontendCfg(int(sample_rate), int(sample_rate * clip_duration_ms / 1000), int(window_size_samples),
+                          int(window_stride_samples), 0, 0, int(num_mel_bins), int(num_mfccs),
+                          float(lower_edge_hertz), float(upper_edge_hertz), self.METHODS[method])
+        self.lib.check(self.lib.tcr_frontend_resolve(C.byref(cfg)), "tcr_frontend_resolve")
+        self.cfg = cfg
+        nbytes = self.lib.tcr_frontend_plan_bytes(C.byref(cfg))
+        host = torch.zeros(nbytes // 4, dtype=torch.float32)
+        self.lib.check(self.lib.tcr_frontend_plan_init(C.byref(cfg), host.data_ptr()), "tcr_frontend_plan_init")
+        self._plan_host = host
+        self.plan = host.to(self.device)
+
+    # shapes ------------------------------------------------------------------------------------
+    @property
+    def n_frames(self) -> int:
+        return self.cfg.n_frames
+
+    @property
+    def n_coef(self) -> int:
+        return self.cfg.n_coef
+
+    @property
+    def n_samples(self) -> int:
+        return self.cfg.n_samples
+
+    def mel_matrix(self) -> np.ndarray:
+        out = np.zeros((self.cfg.nfft // 2 + 1, self.cfg.n_mel), np.float32)
+        self.lib.check(self.lib.tcr_frontend_plan_mel_matrix(C.byref(self.cfg), self._plan_host.data_ptr(), out.ctypes.data),
+                       "tcr_frontend_plan_mel_matrix")
+        return out
+
+    def dct_matrix(self) -> np.ndarray:
+        out = np.zeros((self.cfg.n_mel, self.cfg.n_coef), np.float32)
+        self.lib.check(self.lib.tcr_frontend_plan_dct_matrix(C.byref(self.cfg), self._plan_host.data_ptr(), out.ctypes.data),
+                       "tcr_frontend_plan_dct_matrix")
+        return out
+
+    # compute -----------------------------------------------------------------------------------
+    def __call__(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """wav [B, n_samples] or [B, n_samples, 1] -> planar features [B, n_coef, T + 2*HALO]."""
+        if wav.dim() == 3:
+            if wav.shape[-1] != 1:
+                raise TcrError("front-end accepts single-channel audio only")     # tf.squeeze(audio, -1)
+            wav = wav[..., 0]
+        if wav.dim() != 2 or wav.shape[1] != self.cfg.n_samples:
+            raise TcrError(f"front-end expects [B, {self.cfg.n_samples}] waveforms, got {tuple(wav.shape)}")
+        self._check_tensor(wav, "front-end input")
+        b = wav.shape[0]
+        if out is None:
+            out = torch.empty((b, self.cfg.n_coef, padded_len(self.cfg.n_frames)), dtype=torch.float32, device=self.device)
+        self.lib.check(self.lib.tcr_frontend_fwd(C.byref(self.cfg), self.plan.data_ptr(), wav.data_ptr(), b, out.data_ptr(),
+                                                 self._stream()), "tcr_frontend_fwd")
+        return out
+
+    def reference_view(self, feat: torch.Tensor) -> torch.Tensor:
+        """Planar [B, F, Tp] -> the reference's [B, T, F, 1] (a view, no copy)."""
+        return feat[:, :, HALO:HALO + self.cfg.n_frames].permute(0, 2, 1).unsqueeze(-1)
+
+
+def features_to_planar(x: torch.Tensor, lib: Optional[_lib.Library] = None) -> torch.Tensor:
+    """Reference-layout features [B, T, F] or [B, T, F, 1] -> planar halo layout [B, F, T + 2*HALO]."""
+    if x.dim() == 4:
+        x = x[..., 0]
+    x = x.contiguous()
+    lib2, dev = _resolve(lib, x.device)
+    b, t, f = x.shape
+    out = torch.empty((b, f, padded_len(t)), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+    lib2.check(lib2.tcr_features_to_planar(x.data_ptr(), b, t, f, out.data_ptr(), stream), "tcr_features_to_planar")
+    return out
+
+
+class TCResNet(_Base):
+    """TC-ResNet parameters + kernels (audio_nets/tc_resnet.py:6-70 of the reference)."""
+
+    KIND = {0: "weight", 1: "gamma", 2: "beta", 3: "moving_mean", 4: "moving_variance"}
+
+    def __init__(self, scope: str, channels: Sequence[int], in_channels: int, t_in: int, num_classes: int,
+                 bn_decay: float = 0.997, bn_eps: float = 0.001, lib: Optional[_lib.Library] = None, device=None):
+        self.lib, self.device = _resolve(lib, device)
+        cfg = TCResNetCfg()
+        cfg.scope = scope.encode()
+        cfg.in_channels, cfg.t_in, cfg.num_classes = int(in_channels), int(t_in), int(num_classes)
+        cfg.n_blocks = len(channels) - 1
+        if cfg.n_blocks > _lib.MAX_BLOCKS:
+            raise TcrError(f"at most {_lib.MAX_BLOCKS} blocks")
+        for i, c in enumerate(channels):
+            cfg.channels[i] = int(c)
+        cfg.bn_decay, cfg.bn_eps = float(bn_decay), float(bn_eps)
+        handle = C.c_void_p()
+        self.lib.check(self.lib.tcr_tcresnet_create(C.byref(cfg), C.byref(handle)), "tcr_tcresnet_create")
+        self.cfg, self._h = cfg, handle
+        self.scope, self.channels = scope, list(channels)
+        self.num_classes, self.in_channels, self.t_in = int(num_classes), int(in_channels), int(t_in)
+        self.n_param = self.lib.tcr_net_param_floats(handle)
+        self.n_decay = self.lib.tcr_net_decay_floats(handle)
+        self.n_stat = self.lib.tcr_net_stat_floats(handle)
+        self.tensors: Dict[str, TensorInfo] = {}
+        for i in range(self.lib.tcr_net_num_tensors(handle)):
+            ti = TensorInfo()
+            self.lib.check(self.lib.tcr_net_tensor_info(handle, i, C.byref(ti)), "tcr_net_tensor_info")
+            self.tensors[ti.name.decode()] = ti
+        self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.slots: Dict[str, torch.Tensor] = {}      # optimiser slots (arena-shaped)
+        self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
+        self.reset_bn()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.tcr_net_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def _view(self, name: str) -> torch.Tensor:
+        ti = self.tensors[name]
+        arena = self.params if ti.arena == 0 else self.stats
+        return arena[ti.offset:ti.offset + ti.size].view(*[ti.shape[i] for i in range(ti.rank)])
+
+    def grad_view(self, name: str) -> torch.Tensor:
+        ti = self.tensors[name]
+        assert ti.arena == 0
+        return self.grads[ti.offset:ti.offset + ti.size].view(*[ti.shape[i] for i in range(ti.rank)])
+
+    def trainable_names(self) -> List[str]:
+        return [n for n, ti in self.tensors.items() if ti.arena == 0]
+
+    def total_params(self) -> int:
+        return sum(int(ti.size) for ti in self.tensors.values() if ti.arena == 0)
+
+    def reset_bn(self):
+        for n, ti in self.tensors.items():
+            if ti.kind in (1, 4):       # gamma, moving_variance -> 1
+                self._view(n).fill_(1.0)
+            elif ti.kind in (2, 3):
+                self._view(n).zero_()
+
+    def init_xavier(self, seed: int = 0):
+        """slim.initializers.xavier_initializer() (uniform) for every conv/fc weight (tc_resnet.py:112)."""
+        gen = torch.Generator().manual_seed(int(seed))
+        for n, ti in self.tensors.items():
+            if ti.kind != 0:
+                continue
+            k, _, cin, cout = (ti.shape[i] for i in range(4))
+            lim = math.sqrt(6.0 / (k * cin + k * cout))
+            w = (torch.rand((k, 1, cin, cout), generator=gen, dtype=torch.float32) * 2.0 - 1.0) * lim
+            self._view(n).copy_(w.to(self.device))
+        self.reset_bn()
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        """TF variable name -> array in the reference checkpoint shape."""
+        return {n: self._view(n).detach().cpu().numpy().copy() for n in self.tensors}
+
+    def load_state_dict(self, sd: Dict[str, np.ndarray], strict: bool = True):
+        for n, ti in self.tensors.items():
+            if n not in sd:
+                if strict:
+                    raise KeyError(n)
+                continue
+            v = torch.as_tensor(np.asarray(sd[n], dtype=np.float32))
+            shape = tuple(ti.shape[i] for i in range(ti.rank))
+            if ti.rank == 4 and v.dim() == 3:       # [k, Cin, Cout] accepted for [k, 1, Cin, Cout]
+                v = v.unsqueeze(1)
+            if tuple(v.shape) != shape:
+                raise TcrError(f"{n}: shape {tuple(v.shape)} != {shape}")
+            self._view(n).copy_(v.to(self.device))
+
+    # ---- workspaces ---------------------------------------------------------------------------
+    def workspace(self, batch: int, train: bool) -> torch.Tensor:
+        key = (int(batch), int(train))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = self.lib.tcr_net_workspace_bytes(self._h, batch, int(train))
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def _check_feat(self, feat: torch.Tensor):
+        self._check_tensor(feat, "features")
+        want = (self.in_channels, padded_len(self.t_in))
+        if feat.dim() != 3 or tuple(feat.shape[1:]) != want:
+            raise TcrError(f"features must be planar [B, {want[0]}, {want[1]}], got {tuple(feat.shape)}")
+
+    # ---- compute ------------------------------------------------------------------------------
+    def forward_infer(self, feat: torch.Tensor, want_ranges: bool = False):
+        self._check_feat(feat)
+        b = feat.shape[0]
+        ws = self.workspace(b, False)
+        logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
+        probs = torch.empty_like(logits)
+        ranges = torch.empty((b, 2), dtype=torch.float32, device=self.device) if want_ranges else None
+        self.lib.check(self.lib.tcr_net_forward_infer(self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(), b,
+                                                      ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(),
+                                                      _ptr(ranges), self._stream()), "tcr_net_forward_infer")
+        return (logits, probs, ranges) if want_ranges else (logits, probs)
+
+    def forward_train(self, feat: torch.Tensor, labels: torch.Tensor, keep_prob: float = 1.0, seed: int = 0,
+                      sample_offset: int = 0, global_batch: Optional[int] = None, label_smoothing: float = 0.0,
+                      sync_hook=None):
+        """Train-mode forward.  Returns (logits, probs, loss_sum) where loss_sum is a device scalar holding
+        the SUM over this replica's utterances of the per-utterance cross-entropy.
+        sync_hook(sums: Tensor) -- optional in-place cross-replica reduction of BN sums (sync BN)."""
+        self._check_feat(feat)
+        self._check_tensor(labels, "labels")
+        b = feat.shape[0]
+        gb = int(global_batch or b)
+        ws = self.workspace(b, True)
+        logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
+        probs = torch.empty_like(logits)
+        loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        common = (self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(), labels.data_ptr(), b, gb,
+                  float(keep_prob), int(seed), int(sample_offset), float(label_smoothing), ws.data_ptr(), ws.numel() * 4,
+                  logits.data_ptr(), probs.data_ptr(), loss.data_ptr())
+        if sync_hook is None:
+            self.lib.check(self.lib.tcr_net_forward_train(*common, self._stream()), "tcr_net_forward_train")
+        else:
+            ns = self.lib.tcr_net_num_stages(self._h, 0)
+            for st in range(ns):
+                self.lib.check(self.lib.tcr_net_forward_train_stage(*common, st, self._stream()), "tcr_net_forward_train_stage")
+                if st < ns - 1:
+                    sync_hook(self._stage_sums(0, st, ws, b))
+        self._last = (feat, b, gb, sync_hook)
+        return logits, probs, loss[0]
+
+    def _stage_sums(self, backward: int, stage: int, ws: torch.Tensor, batch: int) -> torch.Tensor:
+        ptr, n = C.c_void_p(), C.c_int64()
+        self.lib.check(self.lib.tcr_net_stage_sums(self._h, backward, stage, ws.data_ptr(), batch, C.byref(ptr), C.byref(n)),
+                       "tcr_net_stage_sums")
+        off = (ptr.value - ws.data_ptr()) // 4
+        return ws[off:off + n.value]
+
+    def backward(self) -> torch.Tensor:
+        """Gradient of the mean cross-entropy wrt every trainable, into self.grads (L2 excluded)."""
+        feat, b, gb, sync_hook = self._last
+        ws = self.workspace(b, True)
+        if sync_hook is None:
+            self.lib.check(self.lib.tcr_net_backward(self._h, self.params.data_ptr(), feat.data_ptr(), b, ws.data_ptr(),
+                                                     ws.numel() * 4, self.grads.data_ptr(), self._stream()), "tcr_net_backward")
+        else:
+            ns = self.lib.tcr_net_num_stages(self._h, 1)
+            for st in range(ns):
+                self.lib.check(self.lib.tcr_net_backward_stage(self._h, self.params.data_ptr(), feat.data_ptr(), b, gb,
+                                                               ws.data_ptr(), ws.numel() * 4, self.grads.data_ptr(), st,
+                                                               self._stream()), "tcr_net_backward_stage")
+                if st < ns - 1:
+                    sync_hook(self._stage_sums(1, st, ws, b))
+        return self.grads
+
+    def _slot(self, name: str) -> torch.Tensor:
+        if name not in self.slots:
+            self.slots[name] = torch.zeros_like(self.params)
+        return self.slots[name]
+
+    def sgd_momentum_step(self, lr: float, momentum: float = 0.9, weight_decay: float = 0.0, grad_scale: float = 1.0):
+        m = self._slot("Momentum")
+        self.lib.check(self.lib.tcr_sgd_momentum_step(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), self.n_param,
+                                                      self.n_decay, float(lr), float(momentum), float(weight_decay),
+                                                      float(grad_scale), self._stream()), "tcr_sgd_momentum_step")
+
+    def adam_step(self, lr: float, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                  weight_decay: float = 0.0, grad_scale: float = 1.0):
+        m, v = self._slot("Adam"), self._slot("Adam_1")
+        self.lib.check(self.lib.tcr_adam_step(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                              self.n_param, self.n_decay, float(lr), float(beta1), float(beta2), float(eps),
+                                              int(step), float(weight_decay), float(grad_scale), self._stream()), "tcr_adam_step")
+
+    def l2_loss(self, weight_decay: float) -> torch.Tensor:
+        out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.lib.check(self.lib.tcr_l2_loss(self.params.data_ptr(), self.n_decay, float(weight_decay), out.data_ptr(),
+                                            self._stream()), "tcr_l2_loss")
+        return out[0]

@@ -1,0 +1,136 @@
+"""Shared parity checks: the same assertions run against the emulator build (CPU, `-m "not gpu"`) and the
+gfx950 library on a real MI355X (`-m gpu`).  The oracle is only ever the checker."""
+import os
+
+import numpy as np
+import torch
+
+import tcresnet_amd as T
+from oracle import numpy_ref as R
+from oracle.make_golden import dropout_mask
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LOGIT_TOL = 1e-4          # north_star: logits within 1e-4 (fp32) of the reference CPU path
+MFCC_TOL = 1e-4           # 1e-4 abs on MFCC (values reach ~ +-150)
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def device_of(lib):
+    return torch.device("cuda" if lib.kind == "hip" else "cpu")
+
+
+def to_dev(lib, a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(device_of(lib))
+
+
+def frontend_cfg(win, hop, num_mfccs=40):
+    import dataclasses
+    return dataclasses.replace(R.FRONTEND_3010, window_size_ms=win / 16.0, window_stride_ms=hop / 16.0, num_mfccs=num_mfccs)
+
+
+def make_frontend(lib, win, hop, num_mfccs=40, method="mfcc"):
+    return T.Frontend(window_size_samples=int(win), window_stride_samples=int(hop), num_mfccs=num_mfccs, method=method,
+                      lib=lib, device=device_of(lib))
+
+
+def fixture_params(fx, name, width):
+    """(arch, params, stats) of a net fixture (regenerated from the seeds when not stored in full)."""
+    arch = R.make_tcresnet(name, float(width))
+    if bool(fx["full"]):
+        p = {k[len("param:"):]: v for k, v in fx.items() if k.startswith("param:")}
+        s = {k[len("stat:"):]: v for k, v in fx.items() if k.startswith("stat:")}
+    else:
+        p, s = R.init_params(arch, int(fx["init_seed"]))
+        R.randomize_bn(arch, p, s, int(fx["bn_seed"]))
+    return arch, p, s
+
+
+def make_net(lib, name, width, t_in, p, s, in_channels=40, num_classes=12):
+    net = T.TCResNet(name, R.tcresnet_channels(name, float(width)), in_channels, t_in, num_classes, lib=lib, device=device_of(lib))
+    sd = dict(p)
+    sd.update(s)
+    net.load_state_dict(sd)
+    return net
+
+
+def check_frontend(lib, tag):
+    fx = load(f"frontend_{tag}.npz")
+    fe = make_frontend(lib, fx["win"], fx["hop"])
+    feat = fe(to_dev(lib, fx["wav"]))
+    got = fe.reference_view(feat)[..., 0].cpu().numpy()
+    assert got.shape == fx["mfcc"].shape
+    err = np.abs(got - fx["mfcc"]).max()
+    assert err < MFCC_TOL, f"MFCC {tag}: max abs err {err}"
+    # halo must be exactly zero (it implements SAME padding for conv0)
+    f = feat.cpu().numpy()
+    assert np.all(f[:, :, :T._lib.HALO] == 0) and np.all(f[:, :, T._lib.HALO + fe.n_frames:] == 0)
+    # digital silence (row 2): every log-mel = ln(1e-6) -> c0 = -156.3, the rest 0 (SURVEY "hard parts")
+    assert abs(got[2, 0, 0] - (-156.3047)) < 1e-2 and np.abs(got[2, :, 1:]).max() < 1e-3
+    return err
+
+
+def check_eval(lib, fname, name, width):
+    fx = load(fname)
+    arch, p, s = fixture_params(fx, name, width)
+    fe = make_frontend(lib, fx["win"], fx["hop"])
+    feat = fe(to_dev(lib, fx["wav"]))
+    net = make_net(lib, name, width, fe.n_frames, p, s)
+    logits, probs, ranges = net.forward_infer(feat, want_ranges=True)
+    logits, probs, ranges = logits.cpu().numpy(), probs.cpu().numpy(), ranges.cpu().numpy()
+    err = np.abs(logits - fx["eval_logits"]).max()
+    assert err < LOGIT_TOL, f"{fname}: eval logits max abs err {err}"
+    assert np.array_equal(logits.argmax(1), fx["eval_logits"].argmax(1)), "argmax class ids differ"
+    assert np.abs(probs - fx["eval_probs"]).max() < 1e-5
+    assert np.abs(ranges - fx["eval_ranges"]).max() < 1e-5
+    assert np.allclose(probs.sum(1), 1.0, atol=1e-5)
+    return err
+
+
+def check_train(lib, fname, name, width, steps=3, grad_rtol=2e-4):
+    """fwd(train) + bwd + momentum for `steps` steps against the fixture (keep_prob 0.5, wd 1e-3, lr 0.1)."""
+    fx = load(fname)
+    arch, p, s = fixture_params(fx, name, width)
+    fe = make_frontend(lib, fx["win"], fx["hop"])
+    feat = fe(to_dev(lib, fx["wav"]))
+    labels = to_dev(lib, fx["labels"])
+    net = make_net(lib, name, width, fe.n_frames, p, s)
+    keep, wd, lr, mu = float(fx["train_keep_prob"]), float(fx["train_weight_decay"]), float(fx["train_lr"]), float(fx["train_momentum"])
+    seed, off = int(fx["train_seed"]), int(fx["train_sample_offset"])
+    b = fx["wav"].shape[0]
+    worst = 0.0
+    for step in range(steps):
+        logits, probs, loss_sum = net.forward_train(feat, labels, keep_prob=keep, seed=seed + step, sample_offset=off)
+        net.backward()
+        if step == 0:
+            assert np.abs(logits.cpu().numpy() - fx["train_logits"]).max() < LOGIT_TOL
+            assert abs(float(loss_sum) / b - float(fx["train_model_loss"])) < 1e-4
+            assert abs(float(net.l2_loss(wd)) - float(fx["train_l2_loss"])) < 1e-5
+            for k in [k for k in fx if k.startswith("grad:")]:
+                n = k[len("grad:"):]
+                ref = fx[k]
+                got = net.grad_view(n).cpu().numpy().reshape(ref.shape).astype(np.float64)
+                if R.is_l2_param(n):
+                    got = got + wd * net._view(n).cpu().numpy().reshape(ref.shape)       # the fixture includes wd * w
+                scale = max(np.abs(ref).max(), 1e-3)
+                e = np.abs(got - ref).max() / scale
+                worst = max(worst, e)
+                assert e < grad_rtol, f"{n}: grad rel err {e}"
+        net.sgd_momentum_step(lr, mu, wd)
+        if step == 0:
+            for k in [k for k in fx if k.startswith("stat1:")]:
+                ref = fx[k]
+                assert np.abs(net._view(k[len("stat1:"):]).cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), k
+            for k in [k for k in fx if k.startswith("param1:")]:
+                ref = fx[k]
+                assert np.abs(net._view(k[len("param1:"):]).cpu().numpy().reshape(ref.shape) - ref).max() < 2e-5, k
+    if steps == 3:
+        for k in [k for k in fx if k.startswith("param3:")]:
+            ref = fx[k]
+            assert np.abs(net._view(k[len("param3:"):]).cpu().numpy().reshape(ref.shape) - ref).max() < 2e-4, k
+        for k in [k for k in fx if k.startswith("stat3:")]:
+            ref = fx[k]
+            assert np.abs(net._view(k[len("stat3:"):]).cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k
+    return worst

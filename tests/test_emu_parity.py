@@ -1,0 +1,92 @@
+"""CPU: the kernel SOURCES (tc-resnet_amd/csrc) run under the host-side wave-64 emulator (tests/emu) and are
+checked against the golden vectors -- host logic + kernel logic without a GPU.  The gfx950 build of the same
+sources is checked by tests/test_gpu_parity.py (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+import tcresnet_amd as T
+from oracle import numpy_ref as R
+from tests import common as Cm
+
+
+@pytest.mark.parametrize("tag", ["3010", "4020"])
+def test_frontend(emu_lib, tag):
+    Cm.check_frontend(emu_lib, tag)
+
+
+def test_frontend_variants(emu_lib):
+    fx = Cm.load("frontend_4020.npz")
+    wav = torch.from_numpy(fx["wav"])
+    # num_mfccs = 10 (the DS-CNN scripts) is a prefix of the 40-coefficient result
+    f10 = Cm.make_frontend(emu_lib, 640, 320, num_mfccs=10)
+    got = f10.reference_view(f10(wav))[..., 0].numpy()
+    assert np.abs(got - fx["mfcc"][..., :10]).max() < Cm.MFCC_TOL
+    # log_mel_spectrogram preprocessor: magnitude spectrum, no DCT (datasets/preprocessors.py:161-169)
+    flm = Cm.make_frontend(emu_lib, 640, 320, method="log_mel_spectrogram")
+    got = flm.reference_view(flm(wav))[..., 0].numpy()
+    assert got.shape[-1] == 64 and np.abs(got[:2] - fx["log_mel_magnitude"][:2]).max() < 1e-4
+    # [B, n, 1] input, ragged batch (not a multiple of the 64-frame workgroup tile), B = 1
+    one = f10(wav[:1].unsqueeze(-1))
+    assert np.array_equal(one.numpy(), f10(wav)[:1].numpy())
+    with pytest.raises(T.TcrError):
+        f10(wav[:, :100])
+    with pytest.raises(NotImplementedError):
+        Cm.make_frontend(emu_lib, 640, 320, method="spectrogram")
+
+
+def test_no_preprocessing_relayout(emu_lib):
+    x = torch.randn(3, 49, 40)
+    planar = T.features_to_planar(x, lib=emu_lib)
+    assert planar.shape == (3, 40, 57)
+    assert torch.equal(planar[:, :, 4:53].permute(0, 2, 1), x) and planar[:, :, :4].abs().max() == 0 and planar[:, :, 53:].abs().max() == 0
+
+
+@pytest.mark.parametrize("fname,name,width", [("tcresnet8_1.0_4020.npz", "TCResNet8", 1.0), ("tcresnet8_1.0_3010.npz", "TCResNet8", 1.0),
+                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5)])
+def test_eval_forward(emu_lib, fname, name, width):
+    Cm.check_eval(emu_lib, fname, name, width)
+
+
+def test_train_three_steps(emu_lib):
+    Cm.check_train(emu_lib, "tcresnet8_1.0_4020.npz", "TCResNet8", 1.0, steps=3)
+
+
+def test_train_asymmetric_padding(emu_lib):
+    Cm.check_train(emu_lib, "tcresnet8_1.0_3010.npz", "TCResNet8", 1.0, steps=1)     # T=98: SAME pads (3,4)
+
+
+def test_train_identity_shortcuts_and_wide_channels(emu_lib):
+    Cm.check_train(emu_lib, "tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, steps=1)
+
+
+def test_batch_independence_in_eval(emu_lib):
+    """Eval-mode utterances are independent: a batch of 70 (ragged vs the 64-position tiles) reproduces
+    the single-utterance results bit for bit."""
+    arch = R.make_tcresnet("TCResNet8", 1.0)
+    p, s = R.init_params(arch, 3)
+    R.randomize_bn(arch, p, s)
+    wav = torch.from_numpy(R.synth_waveforms(70, seed=7))
+    fe = Cm.make_frontend(emu_lib, 640, 320)
+    net = Cm.make_net(emu_lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+    big, _ = net.forward_infer(fe(wav))
+    for i in (0, 63, 64, 69):
+        one, _ = net.forward_infer(fe(wav[i:i + 1]))
+        assert torch.equal(one[0], big[i])
+
+
+def test_engine_argument_errors(emu_lib):
+    net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, 49, 12, lib=emu_lib)
+    with pytest.raises(T.TcrError):
+        net.forward_infer(torch.zeros(2, 40, 49))            # not the padded planar layout
+    with pytest.raises(T.TcrError):
+        net.forward_infer(torch.zeros(2, 40, 57, dtype=torch.float64))
+    with pytest.raises(T.TcrError):
+        net.load_state_dict({n: np.zeros(3) for n in net.tensors})
+    with pytest.raises(KeyError):
+        net.load_state_dict({})
+    net.init_xavier(0)
+    sd = net.state_dict()
+    assert sd["TCResNet8/conv0/weights"].shape == (3, 1, 40, 16) and abs(sd["TCResNet8/conv0/weights"]).max() <= np.sqrt(6.0 / (120 + 48)) + 1e-6
+    assert np.all(sd["TCResNet8/conv0/BatchNorm/gamma"] == 1) and np.all(sd["TCResNet8/conv0/BatchNorm/moving_variance"] == 1)
+    assert net.total_params() == 65264

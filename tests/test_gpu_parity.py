@@ -1,0 +1,107 @@
+"""GPU (-m gpu): the gfx950 library, called through the C ABI, against the golden vectors / the oracle, plus
+size-independent properties at BASELINE.json's full batch (4096)."""
+import numpy as np
+import pytest
+import torch
+
+import tcresnet_amd as T
+from oracle import numpy_ref as R
+from tests import common as Cm
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_library_is_the_one_loaded(hip_lib):
+    assert hip_lib.kind == "hip" and hip_lib.path.endswith("tc-resnet_amd/lib/libtcresnet_hip.so")
+    maps = open("/proc/self/maps").read()
+    assert "libtcresnet_hip.so" in maps
+
+
+@pytest.mark.parametrize("tag", ["3010", "4020"])
+def test_frontend(hip_lib, tag):
+    Cm.check_frontend(hip_lib, tag)
+
+
+def test_frontend_variants(hip_lib):
+    fx = Cm.load("frontend_4020.npz")
+    wav = Cm.to_dev(hip_lib, fx["wav"])
+    f10 = Cm.make_frontend(hip_lib, 640, 320, num_mfccs=10)
+    got = f10.reference_view(f10(wav))[..., 0].cpu().numpy()
+    assert np.abs(got - fx["mfcc"][..., :10]).max() < Cm.MFCC_TOL
+    flm = Cm.make_frontend(hip_lib, 640, 320, method="log_mel_spectrogram")
+    got = flm.reference_view(flm(wav))[..., 0].cpu().numpy()
+    assert np.abs(got[:2] - fx["log_mel_magnitude"][:2]).max() < 1e-4
+    x = torch.randn(3, 49, 40, device="cuda")
+    planar = T.features_to_planar(x)
+    assert torch.equal(planar[:, :, 4:53].permute(0, 2, 1), x) and planar[:, :, :4].abs().max() == 0
+
+
+@pytest.mark.parametrize("fname,name,width", [("tcresnet8_1.0_4020.npz", "TCResNet8", 1.0), ("tcresnet8_1.0_3010.npz", "TCResNet8", 1.0),
+                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5)])
+def test_eval_forward(hip_lib, fname, name, width):
+    Cm.check_eval(hip_lib, fname, name, width)
+
+
+@pytest.mark.parametrize("fname,name,width,steps", [("tcresnet8_1.0_4020.npz", "TCResNet8", 1.0, 3), ("tcresnet8_1.0_3010.npz", "TCResNet8", 1.0, 1),
+                                                    ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, 1)])
+def test_train(hip_lib, fname, name, width, steps):
+    Cm.check_train(hip_lib, fname, name, width, steps=steps)
+
+
+def _full_batch(hip_lib, tag, b=4096):
+    win, hop = (640, 320) if tag == "4020" else (480, 160)
+    arch = R.make_tcresnet("TCResNet8", 1.0)
+    p, s = R.init_params(arch, 11)
+    R.randomize_bn(arch, p, s)
+    base = R.synth_waveforms(64, seed=5)
+    wav = torch.from_numpy(np.tile(base, (b // 64, 1))).cuda()
+    fe = Cm.make_frontend(hip_lib, win, hop)
+    net = Cm.make_net(hip_lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+    return arch, p, s, base, wav, fe, net
+
+
+@pytest.mark.parametrize("tag", ["4020", "3010"])
+def test_full_batch_eval_properties(hip_lib, tag):
+    """B = 4096 (BASELINE.json configs[1]): utterance independence (64 distinct utterances tiled 64x must give
+    64 bit-identical copies), parity of the distinct rows with the oracle, softmax rows sum to 1."""
+    arch, p, s, base, wav, fe, net = _full_batch(hip_lib, tag)
+    logits, probs = net.forward_infer(fe(wav))
+    l = logits.view(64, 64, 12)
+    assert torch.equal(l, l[:1].expand_as(l)), "utterances in a batch are not independent"
+    cfg = Cm.frontend_cfg(fe.cfg.win, fe.cfg.hop)
+    ref = R.forward(arch, p, s, R.mfcc(base, cfg), False)
+    assert np.abs(l[0].cpu().numpy() - ref["logits"]).max() < Cm.LOGIT_TOL
+    assert np.array_equal(l[0].cpu().numpy().argmax(1), ref["logits"].argmax(1))
+    assert torch.allclose(probs.sum(1), torch.ones(4096, device="cuda"), atol=1e-5)
+    # permutation equivariance, bit exact
+    perm = torch.randperm(4096, device="cuda")
+    l2, _ = net.forward_infer(fe(wav[perm].contiguous()))
+    assert torch.equal(l2, logits[perm])
+
+
+def test_full_batch_train_properties(hip_lib):
+    """B = 4096 training step: bitwise run-to-run determinism (no float atomics on the path) and agreement of
+    the batch statistics / gradients with the oracle evaluated on the 64 distinct utterances (tiling a batch
+    leaves mean/variance and the mean-loss gradient unchanged)."""
+    arch, p, s, base, wav, fe, net = _full_batch(hip_lib, "4020")
+    lab = torch.from_numpy(np.tile(R.synth_labels(64), (64, 1))).cuda()
+    feat = fe(wav)
+    outs = []
+    for _ in range(2):
+        sd = dict(p); sd.update(s); net.load_state_dict(sd)
+        logits, probs, loss = net.forward_train(feat, lab, keep_prob=1.0)
+        g = net.backward().clone()
+        outs.append((logits.clone(), loss.clone(), g, net.stats.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "training step is not bitwise deterministic"
+    x = R.mfcc(base, R.FRONTEND_4020)
+    ref = R.forward(arch, p, s, x, True)
+    assert np.abs(outs[0][0][:64].cpu().numpy() - ref["logits"]).max() < 2e-4
+    tot, model, _ = R.loss(ref["logits"], R.synth_labels(64).astype(np.float64), p, 0.0)
+    assert abs(float(outs[0][1]) / 4096 - model) < 1e-4
+    rg = R.backward(arch, p, ref, R.synth_labels(64).astype(np.float64), 0.0)
+    for k, v in rg.items():
+        got = net.grad_view(k).cpu().numpy().reshape(v.shape)
+        assert np.abs(got - v).max() < 5e-4 * max(np.abs(v).max(), 1e-3), k
+    # moving variance uses the Bessel factor n/(n-1) of the ACTUAL count (4096*T), not of the 64-utterance oracle
+    k = "TCResNet8/conv0/BatchNorm/moving_mean"
+    assert np.abs(net._view(k).cpu().numpy() - ref["new_stats"][k]).max() < 1e-5

@@ -1,0 +1,89 @@
+"""CPU: the oracle against the committed golden vectors, and against its independent second implementation."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import numpy_ref as R
+from oracle import torch_ref as TR
+from oracle.make_golden import dropout_mask
+from tests import common as Cm
+
+
+@pytest.mark.parametrize("tag", ["3010", "4020"])
+def test_frontend_matches_golden(tag):
+    fx = Cm.load(f"frontend_{tag}.npz")
+    cfg = Cm.frontend_cfg(int(fx["win"]), int(fx["hop"]))
+    assert np.abs(R.mfcc(fx["wav"], cfg) - fx["mfcc"]).max() < 1e-10
+    assert np.abs(R.log_mel_spectrogram(fx["wav"], cfg, False) - fx["log_mel_magnitude"]).max() < 1e-10
+    assert fx["mfcc"].shape[1] == {"3010": 98, "4020": 49}[tag]
+
+
+def test_frontend_constants():
+    # 471 / 942 non-zeros, rows 3..243 / 6..486, no empty filter
+    for nbins, nnz, lo, hi in ((257, 471, 3, 243), (513, 942, 6, 486)):
+        m = R.linear_to_mel_weight_matrix(64, nbins, 16000, 80.0, 7600.0)
+        assert (m > 0).sum() == nnz
+        rows = np.nonzero(m.sum(1))[0]
+        assert rows[0] == lo and rows[-1] == hi and (m.sum(0) > 0).all()
+    # digital silence: c0 = (2/sqrt(128)) * 64 * ln(1e-6)
+    c = R.mfcc(np.zeros((1, 16000), np.float32), R.FRONTEND_3010)
+    assert abs(c[0, 0, 0] + 156.3047) < 1e-3 and np.abs(c[0, :, 1:]).max() < 1e-9
+    # DCT: rfft form == cosine-sum form (scipy as the third opinion)
+    import scipy.fft
+    x = np.random.RandomState(0).randn(5, 64)
+    assert np.abs(x @ R.dct2_matrix(64, 40) - scipy.fft.dct(x, type=2, axis=-1)[:, :40] / np.sqrt(128.0)).max() < 1e-12
+
+
+def test_same_padding_rule():
+    assert R.same_pad(98, 9, 2) == (49, 3, 4)       # the one asymmetric case on the path
+    assert R.same_pad(49, 9, 2) == (25, 4, 4)
+    assert R.same_pad(98, 3, 1) == (98, 1, 1)
+    assert R.same_pad(49, 1, 2) == (25, 0, 0)
+
+
+def test_param_counts():
+    for name, w, n in (("TCResNet8", 1.0, 65264), ("TCResNet8", 1.5, 144408), ("TCResNet14", 1.0, 135952), ("TCResNet14", 1.5, 303144)):
+        p, _ = R.init_params(R.make_tcresnet(name, w))
+        assert sum(v.size for v in p.values()) == n
+
+
+@pytest.mark.parametrize("fname,name,width", [("tcresnet8_1.0_4020.npz", "TCResNet8", 1.0), ("tcresnet8_1.0_3010.npz", "TCResNet8", 1.0),
+                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5)])
+def test_net_matches_golden_and_torch(fname, name, width):
+    fx = Cm.load(fname)
+    arch, p, s = Cm.fixture_params(fx, name, width)
+    cfg = Cm.frontend_cfg(int(fx["win"]), int(fx["hop"]))
+    x = R.mfcc(fx["wav"], cfg)
+    ev = R.forward(arch, p, s, x, False)
+    assert np.abs(ev["logits"] - fx["eval_logits"]).max() < 1e-10
+    keep, wd = float(fx["train_keep_prob"]), float(fx["train_weight_decay"])
+    mask = dropout_mask(int(fx["train_seed"]), int(fx["train_sample_offset"]), x.shape[0], arch.fc.cin, keep)
+    fwd = R.forward(arch, p, s, x, True, keep, mask)
+    g = R.backward(arch, p, fwd, fx["labels"], wd)
+    for k in [k for k in fx if k.startswith("grad:")]:
+        assert np.abs(g[k[5:]] - fx[k]).max() < 1e-10
+    # independent implementation: autograd through torch ops
+    tg, ttot, tmodel, tns = TR.grads(arch, p, s, x, fx["labels"], wd, keep, mask)
+    assert max(np.abs(g[k] - tg[k]).max() for k in g) < 1e-9
+    assert abs(tmodel - float(fx["train_model_loss"])) < 1e-10
+    assert max(np.abs(fwd["new_stats"][k] - tns[k]).max() for k in tns) < 1e-12
+
+
+def test_float32_oracle_error_budget():
+    """The f32 restatement stays within the 1e-4 logit budget of the f64 one (sets the tolerance's meaning)."""
+    arch = R.make_tcresnet("TCResNet8", 1.0)
+    p, s = R.init_params(arch, 0)
+    R.randomize_bn(arch, p, s)
+    wav = R.synth_waveforms(8)
+    l64 = R.forward(arch, p, s, R.mfcc(wav, R.FRONTEND_4020), False)["logits"]
+    t = TR.forward(arch, {k: torch.tensor(v, dtype=torch.float32) for k, v in p.items()},
+                   {k: torch.tensor(v, dtype=torch.float32) for k, v in s.items()}, TR.mfcc(torch.tensor(wav), R.FRONTEND_4020), False)
+    assert np.abs(t["logits"].numpy() - l64).max() < 1e-4
+
+
+def test_lr_schedule_and_dropout_mirror():
+    assert [R.piecewise_constant_lr(s, [10000, 20000], [0.1, 0.01, 0.001]) for s in (0, 10000, 10001, 20000, 20001)] == [0.1, 0.1, 0.01, 0.01, 0.001]
+    m = dropout_mask(7, 0, 64, 48, 0.5)
+    assert 0.4 < m.mean() < 0.6 and set(np.unique(m)) == {0.0, 1.0}
+    # shard invariance: rows of a shard equal the rows of the global mask
+    assert np.array_equal(dropout_mask(7, 16, 8, 48, 0.5), m[16:24])
