@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- utterances/s of the TC-ResNet keyword-spotting hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one eval-mode pass of the hot path over one batch of synthetic 1 s @ 16 kHz waveforms
+(waveform -> MFCC -> TCResNet8-1.0 -> softmax), BASELINE.json configs[1]: batch 4096 per GPU, 40/20 ms
+front-end (49x40 MFCC, the shape BASELINE.json names).  Inputs are resident in HBM before the timed region.
+N > 1 shards utterances across ranks with no collective (weak scaling).  The same JSON line also carries the
+training step (configs[2]: train-mode BN + backward + momentum, with the RCCL gradient all-reduce when N > 1),
+the 30/10 ms front-end variant, the roofline of the dominant kernel and the CPU baseline.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 4096
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP32_PEAK_TFLOPS = 157.3         # f32 vector == f32-input MFMA peak
+# algorithmic work per utterance (BASELINE.md section 2 / SURVEY App. B)
+WORK = {
+    "4020": {"win": 640, "hop": 320, "frames": 49, "mfcc_flops": 1707503.0, "net_flops": 1585344.0},
+    "3010": {"win": 480, "hop": 160, "frames": 98, "mfcc_flops": 1851906.0, "net_flops": 3045312.0},
+}
+
+
+def synth_batch(batch: int, device, seed: int, start: int = 0) -> torch.Tensor:
+    """uniform(-0.5, 0.5) noise + per-utterance sine 440*(1 + i mod 8) Hz at 0.25, built on device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    noise = (torch.rand((batch, 16000), generator=g, device=device, dtype=torch.float32) - 0.5)
+    t = torch.arange(16000, device=device, dtype=torch.float32) / 16000.0
+    f = 440.0 * (1 + (torch.arange(batch, device=device) + start) % 8).to(torch.float32)
+    return (noise + 0.25 * torch.sin(2.0 * torch.pi * f[:, None] * t[None, :])).contiguous()
+
+
+def timed(fn, steps: int, warmup: int, dist_on: bool):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU per step (BASELINE config: 4096)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the train / 3010 legs (profiling runs)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import tcresnet_amd as T
+    from tcresnet_amd.parallel import DataParallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+
+    B = args.batch
+
+    def build(tag):
+        w = WORK[tag]
+        fe = T.Frontend(window_size_samples=w["win"], window_stride_samples=w["hop"], device=dev)
+        net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, fe.n_frames, 12, device=dev)
+        net.init_xavier(0)
+        return fe, net
+
+    wav = synth_batch(B, dev, 1234 + rank, start=rank * B)
+    labels = torch.zeros((B, 12), device=dev)
+    labels[torch.arange(B), (torch.arange(B) + rank * B) % 12] = 1.0
+
+    # ---------------- headline: eval forward, 49x40 front-end ----------------
+    fe, net = build("4020")
+    feat = torch.empty((B, 40, fe.n_frames + 8), device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * (args.steps + args.warmup))]
+    counter = [0]
+
+    def fwd_step():
+        i = counter[0]
+        counter[0] += 1
+        ev[3 * i].record()
+        fe(wav, out=feat)
+        ev[3 * i + 1].record()
+        net.forward_infer(feat)
+        ev[3 * i + 2].record()
+
+    dt = timed(fwd_step, args.steps, args.warmup, dist_on)
+    value = world * B * args.steps / dt
+    fe_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(args.warmup, args.warmup + args.steps)) / args.steps
+    net_ms = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.warmup, args.warmup + args.steps)) / args.steps
+
+    w = WORK["4020"]
+    # dominant kernel = the fused front-end (one launch per step): waveform read once, [40][49] tile written once
+    fe_bytes = B * (16000 * 4 + 40 * w["frames"] * 4)
+    fe_flops = B * w["mfcc_flops"]
+    fe_gbs = fe_bytes / (fe_ms * 1e-3) / 1e9
+    fe_tf = fe_flops / (fe_ms * 1e-3) / 1e12
+    hbm_frac, fp_frac = fe_gbs / HBM_PEAK_GBS, fe_tf / FP32_PEAK_TFLOPS
+    if fp_frac >= hbm_frac:
+        roof = {"bound": "mfma", "achieved": round(fe_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fp_frac, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
+    roof.update({"traffic": None, "kernel": "frontend_kernel<512>", "kernel_ms": round(fe_ms, 4),
+                 "note": "f32 VALU pipe; its 157.3 TFLOP/s peak equals the exact-f32 MFMA peak. Event-bracketed launch on the stream",
+                 "hbm_gbs": round(fe_gbs, 1), "hbm_frac": round(hbm_frac, 4), "fp32_tflops": round(fe_tf, 3), "fp32_frac": round(fp_frac, 4),
+                 "algorithmic_bytes_per_launch": fe_bytes, "algorithmic_flops_per_launch": fe_flops})
+    whole_tf = value / world * (w["mfcc_flops"] + w["net_flops"]) / 1e12
+    out = {
+        "metric": "utterances/sec (1 s@16 kHz) TCResNet8-1.0 forward", "value": round(value, 1), "unit": "utterances/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "TCResNet8-1.0 eval forward, waveform->softmax, batch 4096/GPU, 49x40 MFCC (40/20 ms, FFT 1024), 12 classes",
+                   "global_batch": world * B, "parallelism": f"dp{world} (utterance shards, no collective)"},
+        "roofline": roof,
+        "phases_ms": {"frontend": round(fe_ms, 4), "net": round(net_ms, 4)},
+        "whole_path_fp32_frac": round(whole_tf / FP32_PEAK_TFLOPS, 4),
+        "whole_path_hbm_frac": round(value / world * 64048 / 1e9 / HBM_PEAK_GBS, 4),
+    }
+
+    if not args.no_extras:
+        # ---------------- training step (configs[2]) ----------------
+        dp = DataParallel(net)
+        step_no = [0]
+
+        def train_step():
+            step_no[0] += 1
+            f = fe(wav, out=feat)
+            dp.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
+            dp.backward()
+            net.sgd_momentum_step(0.1, 0.9, 0.001)
+
+        tsteps = max(5, args.steps // 2)
+        tdt = timed(train_step, tsteps, max(2, args.warmup // 2), dist_on)
+        out["train"] = {"value": round(world * B * tsteps / tdt, 1), "unit": "utterances/s", "ms_per_step": round(tdt / tsteps * 1e3, 4),
+                        "steps": tsteps, "workload": "TCResNet8-1.0 train step: MFCC + train-mode BN fwd + bwd + momentum (wd 1e-3, keep_prob 0.5), "
+                                                     "batch 4096/GPU" + (", RCCL all-reduce of the flat gradient arena" if dist_on else "")}
+        # ---------------- 30/10 ms front-end (98x40, the reference's training scripts) ----------------
+        fe2, net2 = build("3010")
+        feat2 = torch.empty((B, 40, fe2.n_frames + 8), device=dev)
+
+        def fwd2():
+            fe2(wav, out=feat2)
+            net2.forward_infer(feat2)
+
+        dt2 = timed(fwd2, args.steps, args.warmup, dist_on)
+        out["forward_3010"] = {"value": round(world * B * args.steps / dt2, 1), "unit": "utterances/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                               "workload": "same, 98x40 MFCC (30/10 ms, FFT 512)"}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.destroy_process_group()
+
+
+def cpu_baseline():
+    """The oracle's PyTorch-CPU float32 restatement of the same path, timed on the host cores (bounded sample)."""
+    from oracle import numpy_ref as R
+    from oracle import torch_ref as TR
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    arch = R.make_tcresnet("TCResNet8", 1.0)
+    p, s = R.init_params(arch, 0)
+    cb = TR.CpuBaseline(arch, R.FRONTEND_4020, p, s, threads)
+    b = 256
+    wav = torch.from_numpy(R.synth_waveforms(b))
+    cb.infer(wav)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 10.0:
+        cb.infer(wav)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * b / dt, 1), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x batch {b} eval forwards (waveform->softmax, 49x40 MFCC) in {dt:.1f} s; PyTorch-CPU f32 restatement "
+                      f"of the TF1 graph (oracle/torch_ref.py), os.cpu_count()={os.cpu_count()}"}
+
+
+if __name__ == "__main__":
+    main()
