@@ -1,0 +1,215 @@
+"""Model classes: the drop-in boundary of the reference (factory/audio_nets.py:19-187,341-409).
+
+Same class names, constructor `(args, dataset=None)`, `add_arguments`, `build(wavs, labels, is_training)` and the
+attributes the trainer/evaluator read afterwards (`audio`, `audio_original`, `inputs`, `logits`, `outputs`,
+`labels`, `endpoints`, `total_loss`, `model_loss`, `endpoints_loss`, `total_params`,
+`input_preprocessors_for_tflite`, `is_training`).  The reference builds a TF graph that a session runs later;
+here `build()` executes the HIP kernels at once, and `train_step()` is what the trainer's `session.run(train_op)`
+becomes (fwd with batch statistics + bwd + optimiser + moving-average update in one call).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, Tuple
+
+import torch
+
+from .. import runtime
+from ..audio_nets import tc_resnet
+from ..datasets import preprocessor_factory
+from ..parallel import DataParallel
+from .base import TFModel
+
+_available_nets = [
+    "KWSModel", "Res8Model", "Res8NarrowModel", "Res15Model", "Res15NarrowModel", "DSCNNSModel", "DSCNNMModel",
+    "DSCNNLModel", "TCResNet8Model", "TCResNet14Model", "ResNet2D8Model", "ResNet2D8PoolModel",
+]
+
+
+class AudioNetModel(TFModel):
+    def __init__(self, args, dataset=None):
+        self.log = logging.getLogger("AudioNetModel")
+        self.dataset = dataset
+        self.args = args
+        self.engine = None
+        self._dp = None
+        self._step = 0
+
+    # ---- reference surface ---------------------------------------------------------------------
+    def build(self, wavs, labels, is_training):
+        self._audio_original = wavs
+        self.is_training = is_training
+        self.labels = labels
+        self.preprocess_input()
+        self.inputs, self.logits, self._outputs, self.endpoints = self.build_output(self.audio, self.is_training, self.args.output_name)
+        self._total_loss, self._model_loss, self.endpoints_loss = self.build_loss(self.logits, self.outputs, self.labels)
+        self.total_params = self.engine.total_params()
+        self.log.info("total trainable parameters: %d", self.total_params)
+
+    def preprocess_input(self, for_deploy=False):
+        window_size_samples = int(self.args.sample_rate * self.args.window_size_ms / 1000)
+        window_stride_samples = int(self.args.sample_rate * self.args.window_stride_ms / 1000)
+        if not hasattr(self, "_preprocessor"):
+            self._preprocessor = preprocessor_factory.factory(
+                preprocess_method=self.args.preprocess_method, scope="input/audio/preprocessing",
+                preprocessed_node_name="input/audio/preprocessed")
+        self._audio = self._preprocessor.preprocess(
+            self._audio_original, window_size_samples=window_size_samples, window_stride_samples=window_stride_samples,
+            for_deploy=for_deploy, **vars(self.args))
+        self.args.height, self.args.width, self.args.channels = [int(x) for x in self._audio.shape[1:4]]
+        self.input_preprocessors_for_tflite = [self._preprocessor]
+
+    def build_deployable_model(self, include_preprocess=True):
+        raise NotImplementedError("frozen-graph / TFLite export is outside the MI355X hot path (SURVEY 8(f) #3)")
+
+    @property
+    def model_loss(self):
+        return self._model_loss
+
+    @property
+    def total_loss(self):
+        return self._total_loss
+
+    @property
+    def audio_original(self):
+        return self._audio_original
+
+    @property
+    def audio(self):
+        return self._audio
+
+    @property
+    def outputs(self):
+        return self._outputs
+
+    def build_output(self, inputs, is_training, output_name):
+        logits, endpoints = self.build_inference(inputs, is_training=is_training)
+        return inputs, logits, self._probs, endpoints
+
+    def build_inference(self, inputs, is_training=True):
+        raise NotImplementedError
+
+    def build_loss(self, logits, scores, labels) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
+        """model_loss = mean softmax cross-entropy; total = model + weight_decay * sum l2_loss(non-BN trainables)
+        (reference :161-183).  In eval builds the cross-entropy is evaluated from the softmax outputs."""
+        if self._loss_sum is not None:
+            model_loss = self._mean_loss
+        else:
+            y = labels
+            ls = float(getattr(self.args, "label_smoothing", 0.0))
+            if ls > 0:
+                y = y * (1.0 - ls) + ls / y.shape[-1]
+            model_loss = -(y * torch.log_softmax(logits, dim=-1)).sum(dim=-1).mean()
+        total = model_loss + self.engine.l2_loss(self.args.weight_decay)
+        return total, model_loss, {}
+
+    @staticmethod
+    def add_arguments(parser):
+        parser.add_argument("--label_smoothing", default=0.0, type=float)
+
+    # ---- what session.run(train_op) becomes ------------------------------------------------------
+    def data_parallel(self, sync_bn: bool = False) -> DataParallel:
+        if self._dp is None or self._dp.sync_bn != sync_bn:
+            self._dp = DataParallel(self.engine, sync_bn=sync_bn)
+        return self._dp
+
+    def train_step(self, wavs, labels, learning_rate, optimizer="mom", momentum=0.9, sync_bn=False,
+                   adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8):
+        """One optimisation step on a (local shard of a) batch; returns (total_loss, model_loss) as device scalars."""
+        self._audio_original, self.labels, self.is_training = wavs, labels, True
+        self.preprocess_input()
+        self._step += 1
+        dp = self.data_parallel(sync_bn)
+        b = wavs.shape[0]
+        self.logits, self._outputs, loss_sum = dp.forward_train(
+            self._preprocessor.planar, labels, keep_prob=self._keep_prob(), seed=self._step,
+            label_smoothing=float(getattr(self.args, "label_smoothing", 0.0)))
+        dp.backward()
+        l2 = self.engine.l2_loss(self.args.weight_decay)
+        wd = float(self.args.weight_decay)
+        if optimizer == "mom":
+            self.engine.sgd_momentum_step(learning_rate, momentum, wd)
+        elif optimizer == "gd":
+            self.engine.sgd_momentum_step(learning_rate, 0.0, wd)
+        elif optimizer == "adam":
+            self.engine.adam_step(learning_rate, self._step, adam_beta1, adam_beta2, adam_epsilon, wd)
+        else:
+            raise NotImplementedError(f"optimizer {optimizer}")
+        self._model_loss = dp.mean_loss(loss_sum, b)
+        self._total_loss = self._model_loss + l2
+        return self._total_loss, self._model_loss
+
+    def _keep_prob(self) -> float:
+        return 1.0
+
+
+class _TCResNetModel(AudioNetModel):
+    scope = None
+    base_channels = None
+
+    @staticmethod
+    def add_arguments(parser):
+        parser.add_argument("--weight_decay", default=0.0001, type=float)
+        parser.add_argument("--dropout_keep_prob", default=0.5, type=float)
+        parser.add_argument("--width_multiplier", default=1.0, type=float)
+
+    def _keep_prob(self) -> float:
+        return float(self.args.dropout_keep_prob)
+
+    def build_inference(self, inputs, is_training):
+        scope = tc_resnet.TCResNet_arg_scope(is_training=is_training, weight_decay=self.args.weight_decay,
+                                             keep_prob=self.args.dropout_keep_prob)
+        channels = tc_resnet.tcresnet_channels(self.base_channels, self.args.width_multiplier)
+        self.engine = tc_resnet.get_engine(self.scope, channels, int(inputs.shape[2]), int(inputs.shape[1]),
+                                           self.args.num_classes, scope["bn_decay"], scope["bn_eps"])
+        planar = self._preprocessor.planar
+        self._loss_sum = None
+        if is_training:
+            # the reference's training graph: batch-statistics BN, dropout, CE (moving averages are only
+            # assigned by the train op, so this read-only build restores them afterwards)
+            saved = self.engine.stats.clone()
+            logits, probs, loss_sum = self.engine.forward_train(planar, self.labels, keep_prob=self._keep_prob(), seed=0,
+                                                                label_smoothing=float(getattr(self.args, "label_smoothing", 0.0)))
+            self.engine.stats.copy_(saved)
+            self._loss_sum, self._mean_loss = loss_sum, loss_sum / float(planar.shape[0])
+            self._probs = probs
+            return logits, {"engine": self.engine}
+        with tc_resnet.arg_scope(scope):
+            builder = tc_resnet.TCResNet8 if self.scope == "TCResNet8" else tc_resnet.TCResNet14
+            logits, endpoints = builder(inputs, self.args.num_classes, width_multiplier=self.args.width_multiplier, planar=planar)
+        self._probs = endpoints["softmax"]
+        return logits, endpoints
+
+
+class TCResNet8Model(_TCResNetModel):
+    scope = "TCResNet8"
+    base_channels = [16, 24, 32, 48]
+
+
+class TCResNet14Model(_TCResNetModel):
+    scope = "TCResNet14"
+    base_channels = [16, 24, 24, 32, 32, 48, 48]
+
+
+def _not_built(name, ref):
+    class _Stub(AudioNetModel):
+        @staticmethod
+        def add_arguments(parser):
+            parser.add_argument("--weight_decay", default=0.0, type=float)
+
+        def build_inference(self, inputs, is_training=True):
+            raise NotImplementedError(f"{name} ({ref}) is outside the TC-ResNet hot path built so far (SURVEY 8(f))")
+    _Stub.__name__ = name
+    return _Stub
+
+
+KWSModel = _not_built("KWSModel", "audio_nets/kws.py")
+Res8Model = _not_built("Res8Model", "audio_nets/res.py")
+Res8NarrowModel = _not_built("Res8NarrowModel", "audio_nets/res.py")
+Res15Model = _not_built("Res15Model", "audio_nets/res.py")
+Res15NarrowModel = _not_built("Res15NarrowModel", "audio_nets/res.py")
+DSCNNSModel = _not_built("DSCNNSModel", "audio_nets/ds_cnn.py")
+DSCNNMModel = _not_built("DSCNNMModel", "audio_nets/ds_cnn.py")
+DSCNNLModel = _not_built("DSCNNLModel", "audio_nets/ds_cnn.py")
+ResNet2D8Model = _not_built("ResNet2D8Model", "audio_nets/tc_resnet.py:73-84")
+ResNet2D8PoolModel = _not_built("ResNet2D8PoolModel", "audio_nets/tc_resnet.py:88-99")

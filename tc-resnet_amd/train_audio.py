@@ -1,0 +1,76 @@
+"""`python -m tcresnet_amd.train_audio <global flags> <ModelName> <model flags>` -- same command-line shape as
+the reference's train_audio.py (:19-77).  Data: --dataset_path synthetic (the tf.data input pipeline is outside
+the hot path).  Multi-GPU: launch with torch.distributed.run, one process per GPU."""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+from .datasets.synthetic import SyntheticAudioDataWrapper
+from .factory import audio_nets
+from .factory.base import TFModel
+from .helper.trainer import SingleLabelAudioTrainer
+
+
+def add_data_arguments(parser):
+    g = parser.add_argument_group("(Data) Arguments")       # datasets/data_wrapper_base.py:250-288, audio_data_wrapper.py:61-110
+    g.add_argument("--dataset_path", default="synthetic", type=str)
+    g.add_argument("--dataset_split_name", default=["train"], type=str, nargs="*")
+    g.add_argument("--batch_size", default=32, type=int)
+    g.add_argument("--augmentation_method", default="no_augmentation_audio", type=str)
+    g.add_argument("--num_threads", default=8, type=int)
+    g.add_argument("--sample_rate", default=16000, type=int)
+    g.add_argument("--clip_duration_ms", default=1000, type=int)
+    g.add_argument("--window_size_ms", default=30.0, type=float)
+    g.add_argument("--window_stride_ms", default=10.0, type=float)
+    g.add_argument("--lower_edge_hertz", default=80.0, type=float)
+    g.add_argument("--upper_edge_hertz", default=7600.0, type=float)
+    g.add_argument("--num_mel_bins", default=64, type=int)
+    g.add_argument("--num_mfccs", default=40, type=int)
+    g.add_argument("--num_silent", default=-1, type=int)
+    g.add_argument("--background_max_volume", default=0.1, type=float)
+    g.add_argument("--background_frequency", default=0.8, type=float)
+    g.add_argument("--shuffle", dest="shuffle", action="store_true")
+    g.add_argument("--no-shuffle", dest="shuffle", action="store_false")
+    g.set_defaults(shuffle=True)
+    g.add_argument("--buffer_size", default=1000, type=int)
+    g.add_argument("--prefetch_factor", default=100, type=int)
+
+
+def parse_arguments(arguments: List[str] = None):
+    parser = argparse.ArgumentParser(description=__doc__)
+    subparsers = parser.add_subparsers(title="Model", description="")
+    TFModel.add_arguments(parser)
+    audio_nets.AudioNetModel.add_arguments(parser)
+    for class_name in audio_nets._available_nets:
+        sub = subparsers.add_parser(class_name)
+        sub.add_argument("--model", default=class_name, type=str, help="DO NOT FIX ME")
+        getattr(audio_nets, class_name).add_arguments(sub)
+    add_data_arguments(parser)
+    SingleLabelAudioTrainer.add_arguments(parser)
+    return parser.parse_args(arguments)
+
+
+def train(args):
+    logging.basicConfig(level=logging.INFO)
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    if args.dataset_path != "synthetic":
+        raise NotImplementedError("only --dataset_path synthetic: WAV decode/augmentation is outside the hot path (SURVEY 8(f) #1)")
+    dataset = SyntheticAudioDataWrapper(args, None, args.dataset_split_name[0], True)
+    wavs, labels = dataset.get_input_and_output_op()
+    model = getattr(audio_nets, args.model)(args, dataset)
+    model.build(wavs=wavs, labels=labels, is_training=True)
+    trainer = SingleLabelAudioTrainer(model, None, args, dataset, args.dataset_split_name[0])
+    trainer.train()
+    return trainer
+
+
+if __name__ == "__main__":
+    train(parse_arguments())
