@@ -181,8 +181,8 @@ int launch_bn_apply(const BnApplyArgs& a, hipStream_t s) {
 __global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const BnBwdFinalizeArgs a) {
     for (int c = threadIdx.x; c < a.c; c += 128) {
         const float db = a.sums[c], dg = a.sums[a.c + c];
-        a.dbeta[c] = db;
-        a.dgamma[c] = dg;
+        a.dbeta[c] = db * a.grad_scale;
+        a.dgamma[c] = dg * a.grad_scale;
         a.k1[c] = a.gamma[c] * a.invstd[c];
         a.k2[c] = (float)((double)db / a.count);
         a.k3[c] = (float)((double)a.invstd[c] * (double)dg / a.count);

@@ -120,7 +120,9 @@ struct BnBwdFinalizeArgs {
     float* k2;
     float* k3;
     int c;
-    double count;           // elements per channel over the GLOBAL batch
+    double count;           // elements per channel over the batch the statistics span
+    float grad_scale;       // sync BN: sums are global on every replica, and the arena all-reduce will add the
+                            // replicas' copies up again -> store dgamma/dbeta divided by the replica count
 };
 
 struct BnBwdApplyArgs {

@@ -522,6 +522,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
     f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
     f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
+    f.grad_scale = (float)((double)c.batch / c.bn_batch);
     TCR_TRY(launch_bn_bwd_finalize(f, c.s));
     float* dy = c.base + c.w.dyb[u.li];
     BnBwdApplyArgs a;
