@@ -198,6 +198,13 @@ int tcr_l2_loss(const float* params, int64_t n_decay, float weight_decay, float*
  * rocprofv3 kernel-trace rows. */
 const char* tcr_kernel_name(int index);
 
+/* Process-wide kernel-selection knobs for A/B measurements (defaults = 0 = the tuned choice). */
+enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the shape fits, 1: scalar-fed VALU conv, 2: as 0 */
+       TCR_TUNE_FRONTEND = 1,    /* 0: tuned default; 1..4: variant (v-1): bit0 wave-local phase ordering, bit1 sample prefetch */
+       TCR_TUNE_CONV_B = 2,      /* MFMA conv activations: 0 straight from global/L1 (default), 1 via an LDS image */
+       TCR_TUNE_COUNT = 3 };
+int tcr_tune(int knob, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,7 @@ _PROTOTYPES = {
     "tcr_abi_version": (C.c_int, []),
     "tcr_last_error": (C.c_char_p, []),
     "tcr_kernel_name": (C.c_char_p, [C.c_int]),
+    "tcr_tune": (C.c_int, [C.c_int, C.c_int]),
     "tcr_frontend_resolve": (C.c_int, [C.POINTER(FrontendCfg)]),
     "tcr_frontend_plan_bytes": (C.c_size_t, [C.POINTER(FrontendCfg)]),
     "tcr_frontend_plan_init": (C.c_int, [C.POINTER(FrontendCfg), _P]),

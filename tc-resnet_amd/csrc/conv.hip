@@ -14,26 +14,36 @@
 
 namespace tcr {
 
-template <int K, int S, int CT, int P, int EPI>
+// KS > 1 splits the Cin reduction over KS waves of the workgroup (same positions, disjoint ci ranges) and
+// combines them through LDS: late layers have few positions (B*T_out shrinks 49 -> 7 while Cin*K grows), and
+// a wave's stream of scalar weight loads is latency-bound, so more, shorter waves are what fills the SIMDs.
+template <int K, int S, int CT, int P, int EPI, int KS>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
+    __shared__ float s_red[(KS > 1) ? (KS - 1) * (4 / KS) * P * CT * 64 : 1];
     const int co0 = blockIdx.y * CT;
     const int lane = threadIdx.x & 63;
-    const int p0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) * P + lane;
+    const int wave = threadIdx.x >> 6;
+    const int grp = wave / KS;              // position group inside the workgroup
+    const int part = wave % KS;             // slice of the Cin reduction
+    const int p0 = ((blockIdx.x * (4 / KS) + grp) * 64) * P + lane;
 
     float acc[P][CT];
     const float* xb[P];
+    const int ci_per = (a.cin + KS - 1) / KS;
+    const int ci_begin = part * ci_per;
+    const int ci_end = min(a.cin, ci_begin + ci_per);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int p = min(p0 + 64 * i, a.npos - 1);
         const int n = p / a.tout;
         const int t = p - n * a.tout;
-        xb[i] = a.x + (size_t)n * a.cin * a.tpi + t * S + a.xoff;
+        xb[i] = a.x + ((size_t)n * a.cin + ci_begin) * a.tpi + t * S + a.xoff;
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[i][c] = 0.f;
     }
-    const float* __restrict__ wr = a.w + co0;
+    const float* __restrict__ wr = a.w + (size_t)ci_begin * a.cout + co0;
     const size_t wtap = (size_t)a.cin * a.cout;
-    for (int ci = 0; ci < a.cin; ++ci) {
+    for (int ci = ci_begin; ci < ci_end; ++ci) {
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             float xv[P];
@@ -49,6 +59,24 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
         wr += a.cout;
 #pragma unroll
         for (int i = 0; i < P; ++i) xb[i] += a.tpi;
+    }
+
+    if (KS > 1) {
+        float* red = s_red + (size_t)grp * (KS - 1) * P * CT * 64;
+        if (part > 0) {
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) red[((part - 1) * P * CT + i * CT + c) * 64 + lane] = acc[i][c];
+        }
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[i][c] += red[(q * P * CT + i * CT + c) * 64 + lane];
     }
 
 #pragma unroll
@@ -151,21 +179,38 @@ __global__ __launch_bounds__(256) void transpose_weights_kernel(const float* __r
     }
 }
 
-template <int K, int S, int CT, int P>
+// waves launched for a given tiling; the host picks the reduction split that brings this to ~6+ waves/SIMD
+static int pick_ksplit(int npos, int cout, int ct, int p, int cin) {
+    const long base = (long)ceil_div(npos, 64 * p) * ceil_div(cout, ct);
+    int ks = 1;
+    while (ks < 4 && base * ks < 6144 && cin / (ks * 2) >= 4) ks *= 2;
+    return ks;
+}
+
+template <int K, int S, int CT, int P, int KS>
 static int launch_fwd_epi(const ConvArgs& a, int epi, hipStream_t s) {
-    const dim3 grid(ceil_div(a.npos, 256 * P), ceil_div(a.cout, CT));
-    if (epi == EPI_RAW) hipLaunchKernelGGL((conv_fwd_kernel<K, S, CT, P, EPI_RAW>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_fwd_kernel<K, S, CT, P, EPI_AFFINE>), grid, dim3(256), 0, s, a);
+    const dim3 grid(ceil_div(a.npos, 64 * P * (4 / KS)), ceil_div(a.cout, CT));
+    if (epi == EPI_RAW) hipLaunchKernelGGL((conv_fwd_kernel<K, S, CT, P, EPI_RAW, KS>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<K, S, CT, P, EPI_AFFINE, KS>), grid, dim3(256), 0, s, a);
     return check_launch("conv_fwd_kernel");
+}
+
+template <int K, int S, int CT, int P>
+static int launch_fwd_ksplit(const ConvArgs& a, int epi, hipStream_t s) {
+    switch (pick_ksplit(a.npos, a.cout, CT, P, a.cin)) {
+        case 1: return launch_fwd_epi<K, S, CT, P, 1>(a, epi, s);
+        case 2: return launch_fwd_epi<K, S, CT, P, 2>(a, epi, s);
+        default: return launch_fwd_epi<K, S, CT, P, 4>(a, epi, s);
+    }
 }
 
 template <int K, int S>
 static int launch_fwd_ks(const ConvArgs& a, int ct, int epi, hipStream_t s) {
     switch (ct) {
-        case 8: return launch_fwd_epi<K, S, 8, 4>(a, epi, s);
-        case 12: return launch_fwd_epi<K, S, 12, 4>(a, epi, s);
-        case 16: return launch_fwd_epi<K, S, 16, 2>(a, epi, s);
-        default: return launch_fwd_epi<K, S, 24, 2>(a, epi, s);
+        case 8: return launch_fwd_ksplit<K, S, 8, 4>(a, epi, s);
+        case 12: return launch_fwd_ksplit<K, S, 12, 4>(a, epi, s);
+        case 16: return launch_fwd_ksplit<K, S, 16, 2>(a, epi, s);
+        default: return launch_fwd_ksplit<K, S, 24, 2>(a, epi, s);
     }
 }
 

@@ -98,8 +98,13 @@ __device__ __forceinline__ void real_pair_power(float2 zk, float2 zn, float2 w, 
     p_hi = fmaf(yr, yr, yi * yi);       // |X[N-k]|^2
 }
 
-template <int NC>
+// VAR bit 0: the phases of a round are ordered by wave-local points (a frame's lanes never straddle a
+//            wavefront) instead of s_barrier;  bit 1: the next round's samples are prefetched into registers
+//            while the current round computes (the kernel is latency-bound at its 2 waves/SIMD).
+template <int NC, int VAR>
 __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) {
+    constexpr bool WSYNC = (VAR & 1) != 0;
+    constexpr bool PREFETCH = (VAR & 2) != 0;
     constexpr int LPF = NC / 16;            // lanes per frame
     constexpr int FPR = 256 / LPF;          // frames per round
     constexpr int ROUNDS = 64 / FPR;
@@ -138,14 +143,14 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
         twc[i] = (SUB == 2) ? a.tw_combine[k] : make_float2(1.f, 0.f);
     }
 
-    for (int r = 0; r < ROUNDS; ++r) {
-        // ---------------- load + window + first radix-16 pass ----------------
-        int g = blockIdx.x * 64 + r * FPR + f;
+#define TCR_SYNC() do { if (WSYNC) wave_sync(); else __syncthreads(); } while (0)
+    float2 xa[16];
+    auto load_frame = [&](int rr, float2 (&dst)[16]) {
+        int g = blockIdx.x * 64 + rr * FPR + f;
         g = min(g, a.total_frames - 1);
         const int n = g / a.n_frames;
         const int t = g - n * a.n_frames;
         const float* src = a.wav + (size_t)n * a.n_samples + (size_t)t * a.hop;
-        float2 v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int idx = 2 * (SUB * (l + 16 * q) + u);
@@ -154,20 +159,28 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
                 if (a.aligned) x = *reinterpret_cast<const float2*>(src + idx);
                 else x = make_float2(src[idx], src[idx + 1]);
             }
-            v[q] = make_float2(x.x * wnd[q].x, x.y * wnd[q].y);
+            dst[q] = x;
         }
+    };
+    for (int r = 0; r < ROUNDS; ++r) {
+        // ---------------- load (+ prefetch of the next round) + window + first radix-16 pass ----------------
+        float2 v[16];
+        if (!PREFETCH || r == 0) load_frame(r, xa);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = make_float2(xa[q].x * wnd[q].x, xa[q].y * wnd[q].y);
+        if (PREFETCH && r + 1 < ROUNDS) load_frame(r + 1, xa);
         dft16(v);
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) s_x[unit * UNIT + k2 * XLD + l] = cmul(v[k2], tw[k2]);
-        __syncthreads();
+        TCR_SYNC();
         // ---------------- transpose + second radix-16 pass ----------------
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = s_x[unit * UNIT + l * XLD + n1];
         dft16(v);
-        __syncthreads();
+        TCR_SYNC();
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) s_x[unit * UNIT + 16 * k1 + l] = v[k1];     // bin 16 k1 + l
-        __syncthreads();
+        TCR_SYNC();
         // ---------------- real-FFT post-processing -> power spectrum ----------------
         {
             const float2* E = s_x + (f * SUB) * UNIT;
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
                 P[NC / 2] = plo;
             }
         }
-        __syncthreads();
+        TCR_SYNC();
         // ---------------- sparse mel: per-segment up/down sums ----------------
         {
             const float* P = s_p + f * PLD;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
                 }
             }
         }
-        __syncthreads();
+        TCR_SYNC();
         // ---------------- log(mel + 1e-6) -> [mel][frame] ----------------
         {
             const float* UD = s_ud + f * 2 * (NSEG + 1);
@@ -237,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
     }
     __syncthreads();
 
+#undef TCR_SYNC
     // ---------------- DCT-II (lane == frame, wave-uniform coefficients) + store ----------------
     const int fr = tid & 63;
     const int w = tid >> 6;
@@ -335,8 +349,16 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     a.aligned = ((cfg->n_samples | cfg->hop) & 1) == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0;
     const int grid = ceil_div(a.total_frames, 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (cfg->nfft == 512) hipLaunchKernelGGL((frontend_kernel<256>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((frontend_kernel<512>), dim3(grid), dim3(256), 0, s, a);
+    const int var = tune_get(TCR_TUNE_FRONTEND) == 0 ? 3 : (tune_get(TCR_TUNE_FRONTEND) - 1) & 3;   // default: both on
+#define TCR_FE(NC_)                                                                                     \
+    switch (var) {                                                                                      \
+        case 0: hipLaunchKernelGGL((frontend_kernel<NC_, 0>), dim3(grid), dim3(256), 0, s, a); break;   \
+        case 1: hipLaunchKernelGGL((frontend_kernel<NC_, 1>), dim3(grid), dim3(256), 0, s, a); break;   \
+        case 2: hipLaunchKernelGGL((frontend_kernel<NC_, 2>), dim3(grid), dim3(256), 0, s, a); break;   \
+        default: hipLaunchKernelGGL((frontend_kernel<NC_, 3>), dim3(grid), dim3(256), 0, s, a); break;  \
+    }
+    if (cfg->nfft == 512) { TCR_FE(256); } else { TCR_FE(512); }
+#undef TCR_FE
     return check_launch("frontend_kernel");
 }
 

@@ -54,6 +54,10 @@ struct Conv1x1Args {
 };
 
 int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s);
+// implicit-GEMM k x 1 conv on the matrix cores; returns 1 (nothing launched) when the shape does not fit
+int launch_conv_mfma(int k, int stride, const ConvArgs& a, int epi, hipStream_t s);
+int launch_conv_mfma_with_down(const ConvArgs& a, const float* w_down, float* y_down, const float* scale_down,
+                               const float* shift_down, int pad_lo, int epi, hipStream_t s);
 size_t wgrad_partial_floats(int k, int cin, int cout, int npos);
 int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
                       int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s);

@@ -88,6 +88,237 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k x 1 convolution as an implicit GEMM on the matrix cores:
+//   D[row = co][col = position] = sum_{j, ci} W[j][ci][co] * x[b][ci][t*S + j - pad_lo]
+// A = W (16 output channels x 4 input channels of one tap per instruction, straight from L1/L2 -- the
+// weight tensor is shared by every workgroup), B = activations read from an LDS image of the
+// workgroup's utterances.  Because activations are planar per utterance, the rows a workgroup needs
+// ([n0..n1][Cin][Tp]) are ONE contiguous block of global memory: the LDS image is a straight float4
+// memcpy (fully coalesced) and taps / strides / SAME padding become plain LDS offsets into the halo'd rows.
+// The f32 MFMA is bitwise an fmaf chain, so this changes scheduling, not numerics.
+// Why not the scalar-fed VALU kernel of conv.hip everywhere: once the weight tensor outgrows the 16 KB
+// scalar cache (every block conv; 20-83 KB) its waves stall on scalar-cache misses (measured 5-8 % of the
+// FP32 peak, 75 % of wave time in s_waitcnt; profiles/r01_baseline_pmc.csv).
+// ---------------------------------------------------------------------------------------------
+// DOWN: additionally produce the block's 1x1 stride-2 "down" shortcut (tc_resnet.py:30-32) from the SAME
+// LDS image -- it is the centre-tap column of the stride-2 9x1 conv with its own weights.
+struct ConvDownArgs {
+    const float* w;         // [Cin][Cout]
+    float* y;               // [B][Cout][Tpo]
+    const float* scale;
+    const float* shift;
+    int tap;                // pad_lo of the main conv: x[t*S + tap - pad_lo] == x[t*S]
+    int relu;
+};
+
+template <int MT, int EPI>
+__device__ __forceinline__ void conv_mfma_store(const f32x4 (&acc)[MT][2], float* y, const float* scale, const float* shift,
+                                                const float* res, int relu, int cot0, int cout, int tout, int tpo,
+                                                int p_base, int wg_p1, int r, int q) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int p = p_base + nt * 16 + r;
+        if (p >= wg_p1) continue;
+        const int n = p / tout, t = p - n * tout;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = (cot0 + m) * 16 + q * 4 + reg;
+                if (co >= cout) continue;
+                float v = acc[m][nt][reg];
+                const size_t o = ((size_t)n * cout + co) * tpo + kHalo + t;
+                if (EPI == EPI_AFFINE) {
+                    v = fmaf(v, scale[co], shift[co]);
+                    if (res) v = fmaxf(v + res[o], 0.f);            // net += layer_in; relu  (tc_resnet.py:40-41)
+                    else if (relu) v = fmaxf(v, 0.f);
+                }
+                float* dst = y + o;
+                dst[0] = v;
+                if (t == 0) { dst[-4] = 0.f; dst[-3] = 0.f; dst[-2] = 0.f; dst[-1] = 0.f; }
+                if (t == tout - 1) { dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f; dst[4] = 0.f; }
+            }
+    }
+}
+
+// LDSB = true: activations via the LDS image; false: B fragments straight from global/L1 (each fragment load is
+// 4 input-channel rows x 16 consecutive positions = four 64-byte segments), prefetched together with the
+// weights -- no staging pass, no barrier, no LDS-limited occupancy, no over-fetch of whole utterances.
+template <int K, int S, int MT, int EPI, bool DOWN, bool LDSB>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a, const ConvDownArgs d, const int ppw) {
+    constexpr int CH = 4;                                   // K-steps (of 4 input channels) per weight prefetch chunk
+    float* xt = reinterpret_cast<float*>(dyn_lds());
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wg_p0 = blockIdx.x * ppw;
+    const int wg_p1 = min(wg_p0 + ppw, a.npos);
+    const int n0 = wg_p0 / a.tout, n1 = (wg_p1 - 1) / a.tout;
+    const int row = a.cin * a.tpi;                          // floats per utterance (multiple of 4)
+    if (LDSB) {
+        const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)n0 * row);
+        float4* dst = reinterpret_cast<float4*>(xt);
+        const int nvec = (n1 - n0 + 1) * (row / 4);
+        for (int i = tid; i < nvec; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+    const int p_base = wg_p0 + wave * 32;                   // 2 column tiles of 16 positions per wave
+    if (p_base >= wg_p1) return;
+
+    const float* xb = LDSB ? xt : a.x + (size_t)n0 * row;   // same indexing for the LDS image and for global
+    int xo[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int p = min(p_base + nt * 16 + r, wg_p1 - 1);
+        const int n = p / a.tout, t = p - n * a.tout;
+        xo[nt] = (n - n0) * row + t * S + a.xoff + q * a.tpi;
+    }
+    const int cot0 = blockIdx.y * MT;
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int wofs[MT];                                           // q * Cout + co of this lane's A-fragment column
+    bool wv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co = (cot0 + m) * 16 + r;
+        wv[m] = co < a.cout;
+        wofs[m] = q * a.cout + (wv[m] ? co : 0);
+    }
+    const int C4 = a.cin >> 2;
+    const int tap_stride = a.cin * a.cout;
+    const int step_stride = 4 * a.cout;
+
+    // Weights stream from L1/L2 with a one-chunk (4 K-steps = 4*MT loads) lookahead so that their latency
+    // hides behind the previous chunk's 8*MT MFMAs; activations come from the LDS image.
+    auto load_chunk = [&](const float* w, int j, int c0, float (&af)[CH][MT + 2]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c4 = c0 + i;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                af[i][m] = (c4 < C4 && wv[m]) ? w[(size_t)j * tap_stride + (size_t)c4 * step_stride + wofs[m]] : 0.f;
+            if (!LDSB) {
+                af[i][MT] = (c4 < C4) ? xb[xo[0] + 4 * c4 * a.tpi + j] : 0.f;
+                af[i][MT + 1] = (c4 < C4) ? xb[xo[1] + 4 * c4 * a.tpi + j] : 0.f;
+            }
+        }
+    };
+    auto mma_chunk = [&](int j, int c0, const float (&af)[CH][MT + 2], f32x4 (&ac)[MT][2]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c4 = c0 + i;
+            if (c4 < C4) {
+                const float b0 = LDSB ? xb[xo[0] + 4 * c4 * a.tpi + j] : af[i][MT];
+                const float b1 = LDSB ? xb[xo[1] + 4 * c4 * a.tpi + j] : af[i][MT + 1];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    ac[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][m], b0, ac[m][0], 0, 0, 0);
+                    ac[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][m], b1, ac[m][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    const int cpj = (C4 + CH - 1) / CH;
+    const int nchunks = K * cpj;
+    float afA[CH][MT + 2], afB[CH][MT + 2];
+    int j = 0, c0 = 0;
+    load_chunk(a.w, 0, 0, afA);
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        int j1 = j, c1 = c0 + CH;
+        if (c1 >= C4) { c1 = 0; ++j1; }
+        if (ch + 1 < nchunks) load_chunk(a.w, j1, c1, afB);
+        mma_chunk(j, c0, afA, acc);
+        int j2 = j1, c2 = c1 + CH;
+        if (c2 >= C4) { c2 = 0; ++j2; }
+        if (ch + 2 < nchunks) load_chunk(a.w, j2, c2, afA);
+        if (ch + 1 < nchunks) mma_chunk(j1, c1, afB, acc);
+        j = j2;
+        c0 = c2;
+    }
+    conv_mfma_store<MT, EPI>(acc, a.y, a.scale, a.shift, a.res, a.relu, cot0, a.cout, a.tout, a.tpo, p_base, wg_p1, r, q);
+
+    if (DOWN) {
+        f32x4 acc2[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc2[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int cc = 0; cc < C4; cc += CH) {
+            load_chunk(d.w, 0, cc, afA);
+            if (!LDSB) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {      // B of the centre tap (load_chunk fetched tap 0)
+                    afA[i][MT] = (cc + i < C4) ? xb[xo[0] + 4 * (cc + i) * a.tpi + d.tap] : 0.f;
+                    afA[i][MT + 1] = (cc + i < C4) ? xb[xo[1] + 4 * (cc + i) * a.tpi + d.tap] : 0.f;
+                }
+            }
+            mma_chunk(d.tap, cc, afA, acc2);
+        }
+        conv_mfma_store<MT, EPI>(acc2, d.y, d.scale, d.shift, nullptr, d.relu, cot0, a.cout, a.tout, a.tpo, p_base, wg_p1, r, q);
+    }
+}
+
+// Returns TCR_OK after launching, or 1 when the shape does not fit this kernel (caller falls back).
+template <int K, int S>
+static int launch_conv_mfma_ks(const ConvArgs& a, const ConvDownArgs* down, int epi, hipStream_t s) {
+    if (a.cin % 4 != 0) return 1;
+    const int row = a.cin * a.tpi;
+    // positions per workgroup (32 per wave): shrink until the grid has >= ~768 workgroups and the LDS image
+    // of the utterances a workgroup touches fits 64 KB
+    int ppw = 128;
+    while (ppw > 32 && ceil_div(a.npos, ppw) < 768) ppw /= 2;
+    size_t lds = 0;
+    for (; ppw >= 32; ppw /= 2) {
+        const int span = (ppw + a.tout - 2) / a.tout + 1;       // utterances a workgroup can touch
+        lds = (size_t)span * row * sizeof(float);
+        if (lds <= 64 * 1024) break;
+    }
+    const bool ldsb = tune_get(TCR_TUNE_CONV_B) == 1;
+    if (ldsb && ppw < 32) return 1;
+    if (!ldsb) { ppw = 128; lds = 0; while (ppw > 32 && ceil_div(a.npos, ppw) < 1024) ppw /= 2; }
+    const int tiles = ceil_div(a.cout, 16);
+    const int mt = tiles <= 3 ? tiles : (tiles == 4 ? 2 : (tiles == 5 ? 5 : 3));
+    const dim3 grid(ceil_div(a.npos, ppw), ceil_div(tiles, mt));
+    const dim3 block(ppw * 2);
+    ConvDownArgs d;
+    if (down) d = *down; else { d.w = nullptr; d.y = nullptr; d.scale = d.shift = nullptr; d.tap = 0; d.relu = 0; }
+#define TCR_CM3(MT_, EPI_, LB_)                                                                                         \
+    if (down) hipLaunchKernelGGL((conv_mfma_kernel<K, S, MT_, EPI_, true, LB_>), grid, block, lds, s, a, d, ppw);       \
+    else hipLaunchKernelGGL((conv_mfma_kernel<K, S, MT_, EPI_, false, LB_>), grid, block, lds, s, a, d, ppw)
+#define TCR_CM2(MT_, EPI_) if (ldsb) { TCR_CM3(MT_, EPI_, true); } else { TCR_CM3(MT_, EPI_, false); }
+#define TCR_CM(MT_) if (epi == EPI_RAW) { TCR_CM2(MT_, EPI_RAW); } else { TCR_CM2(MT_, EPI_AFFINE); }
+    switch (mt) {
+        case 1: TCR_CM(1); break;
+        case 2: TCR_CM(2); break;
+        case 3: TCR_CM(3); break;
+        default: TCR_CM(5); break;
+    }
+#undef TCR_CM
+#undef TCR_CM2
+#undef TCR_CM3
+    return check_launch("conv_mfma_kernel");
+}
+
+int launch_conv_mfma(int k, int stride, const ConvArgs& a, int epi, hipStream_t s) {
+    if (k == 3 && stride == 1) return launch_conv_mfma_ks<3, 1>(a, nullptr, epi, s);
+    if (k == 9 && stride == 1) return launch_conv_mfma_ks<9, 1>(a, nullptr, epi, s);
+    if (k == 9 && stride == 2) return launch_conv_mfma_ks<9, 2>(a, nullptr, epi, s);
+    return 1;
+}
+
+// 9x1 stride-2 conv + the block's 1x1 stride-2 "down" conv in one launch (shared LDS image).
+int launch_conv_mfma_with_down(const ConvArgs& a, const float* w_down, float* y_down, const float* scale_down,
+                               const float* shift_down, int pad_lo, int epi, hipStream_t s) {
+    ConvDownArgs d;
+    d.w = w_down; d.y = y_down; d.scale = scale_down; d.shift = shift_down; d.tap = pad_lo; d.relu = 1;
+    return launch_conv_mfma_ks<9, 2>(a, &d, epi, s);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[j][ci][co] = sum_{b,t} x[b][ci][t*S + j - pad_lo] * dy[b][co][t].
 // Per wave: one 16-channel ci tile, all K taps, NCO co tiles; the reduction index (positions) is the
 // MFMA k dimension, 4 positions per instruction.  Workgroups split the position range (split-K);

@@ -261,7 +261,25 @@ static int conv_forward(const tcr_net& net, const ConvLayer& l, const float* x, 
     a.npos = batch * l.tout; a.cin = l.cin; a.cout = l.cout;
     a.tpi = tcr_padded_len(l.tin); a.tout = l.tout; a.tpo = tcr_padded_len(l.tout);
     a.xoff = TCR_HALO - l.pad_lo; a.relu = relu;
+    if (tune_get(TCR_TUNE_CONV_PATH) != 1) {
+        const int rc = launch_conv_mfma(l.k, l.stride, a, epi, s);
+        if (rc != 1) return rc;             // launched (or failed); 1 == shape not covered -> VALU kernel
+    }
     return launch_conv_fwd(l.k, l.stride, a, epi, s);
+}
+
+// conv_a (9x1, stride 2) and the block's 1x1 stride-2 `down` shortcut read the same input rows: one launch,
+// one LDS image.  Returns 1 when the fused kernel does not apply (caller launches them separately).
+static int conv_forward_with_down(const ConvLayer& la, const ConvLayer& ld, const float* x, const float* params,
+                                  float* ya, const float* sca, const float* sha, float* yd, const float* scd, const float* shd,
+                                  int epi, int batch, hipStream_t s) {
+    if (tune_get(TCR_TUNE_CONV_PATH) == 1 || la.k != 9 || la.stride != 2 || ld.k != 1 || ld.stride != 2) return 1;
+    ConvArgs a;
+    a.x = x; a.w = params + la.w_off; a.y = ya; a.scale = sca; a.shift = sha; a.res = nullptr;
+    a.npos = batch * la.tout; a.cin = la.cin; a.cout = la.cout;
+    a.tpi = tcr_padded_len(la.tin); a.tout = la.tout; a.tpo = tcr_padded_len(la.tout);
+    a.xoff = TCR_HALO - la.pad_lo; a.relu = la.relu;
+    return launch_conv_mfma_with_down(a, params + ld.w_off, yd, scd, shd, la.pad_lo, epi, s);
 }
 
 }  // namespace tcr
@@ -301,11 +319,18 @@ extern "C" int tcr_net_forward_infer(const tcr_net* net, const float* params, co
     int cur = 0;
     for (const Block& b : net->blocks) {
         const float* shortcut = base + w.act[cur];
+        bool a_done = false;
         if (b.down >= 0) {
-            TCR_TRY(run(b.down, nullptr));
+            const ConvLayer& la = net->layers[b.a];
+            const ConvLayer& ld = net->layers[b.down];
+            const int rc = conv_forward_with_down(la, ld, base + w.act[cur], params, base + w.act[b.a], ss + la.ss_off,
+                                                  ss + la.ss_off + la.c_pad, base + w.act[b.down], ss + ld.ss_off,
+                                                  ss + ld.ss_off + ld.c_pad, EPI_AFFINE, batch, s);
+            if (rc == 1) TCR_TRY(run(b.down, nullptr));
+            else { TCR_TRY(rc); a_done = true; }
             shortcut = base + w.act[b.down];
         }
-        TCR_TRY(run(b.a, nullptr));
+        if (!a_done) TCR_TRY(run(b.a, nullptr));
         TCR_TRY(run(b.b, shortcut));
         cur = b.b;
     }
@@ -335,11 +360,38 @@ struct TrainCtx {
 };
 
 // conv + per-channel sums of the raw output (everything before the cross-replica hand-off)
+static bool fused_with_down(const tcr_net& net, int li, int* down_of_a, int* a_of_down) {
+    for (const Block& b : net.blocks) {
+        if (b.down < 0) continue;
+        const ConvLayer& la = net.layers[b.a];
+        const ConvLayer& ld = net.layers[b.down];
+        const bool ok = tune_get(TCR_TUNE_CONV_PATH) != 1 && la.k == 9 && la.stride == 2 && ld.k == 1 && ld.stride == 2 && la.cin % 4 == 0;
+        if (!ok) continue;
+        if (li == b.a) { if (down_of_a) *down_of_a = b.down; return true; }
+        if (li == b.down) { if (a_of_down) *a_of_down = b.a; return true; }
+    }
+    return false;
+}
+
 static int fwd_unit_pre(const TrainCtx& c, int li) {
     const ConvLayer& l = c.net->layers[li];
     const float* x = layer_input(*c.net, c.w, c.base, c.feat, l);
     float* raw = c.base + c.w.raw[li];
-    TCR_TRY(conv_forward(*c.net, l, x, c.params, raw, nullptr, nullptr, nullptr, false, EPI_RAW, c.batch, c.s));
+    int partner = -1;
+    bool conv_done = false;
+    if (fused_with_down(*c.net, li, &partner, nullptr) && partner >= 0) {
+        conv_done = true;                   // conv_a: its raw output was produced together with the down conv
+    } else if (fused_with_down(*c.net, li, nullptr, &partner) && partner >= 0) {
+        const ConvLayer& la = c.net->layers[partner];
+        const int rc = conv_forward_with_down(la, l, x, c.params, c.base + c.w.raw[partner], nullptr, nullptr, raw, nullptr, nullptr,
+                                              EPI_RAW, c.batch, c.s);
+        if (rc != 1) { TCR_TRY(rc); conv_done = true; }
+        else {
+            // (shape not covered after all) fall through to separate launches for both layers
+            TCR_TRY(conv_forward(*c.net, la, x, c.params, c.base + c.w.raw[partner], nullptr, nullptr, nullptr, false, EPI_RAW, c.batch, c.s));
+        }
+    }
+    if (!conv_done) TCR_TRY(conv_forward(*c.net, l, x, c.params, raw, nullptr, nullptr, nullptr, false, EPI_RAW, c.batch, c.s));
     ChanReduceArgs r;
     std::memset(&r, 0, sizeof(r));
     r.y = raw; r.partial = c.base + c.w.partial;

@@ -23,14 +23,27 @@ int check_launch(const char* what) {
     return TCR_OK;
 }
 
+static int g_tune[TCR_TUNE_COUNT] = {0};
+
+int tune_get(int knob) { return (knob >= 0 && knob < TCR_TUNE_COUNT) ? g_tune[knob] : 0; }
+
 }  // namespace tcr
+
+extern "C" int tcr_tune(int knob, int value) {
+    if (knob < 0 || knob >= TCR_TUNE_COUNT) {
+        tcr::set_error("tcr_tune: unknown knob %d", knob);
+        return TCR_ERR_ARG;
+    }
+    tcr::g_tune[knob] = value;
+    return TCR_OK;
+}
 
 extern "C" int tcr_abi_version(void) { return TCR_ABI_VERSION; }
 extern "C" const char* tcr_last_error(void) { return tcr::g_err; }
 
 extern "C" const char* tcr_kernel_name(int index) {
     static const char* names[] = {
-        "frontend_kernel", "conv_fwd_kernel", "conv1x1_mfma_kernel", "head_fwd_kernel",
+        "frontend_kernel", "conv_fwd_kernel", "conv_mfma_kernel", "conv1x1_mfma_kernel", "head_fwd_kernel",
         "bn_finalize_kernel", "bn_apply_kernel", "head_bwd_kernel", "bn_bwd_reduce_kernel",
         "bn_bwd_apply_kernel", "conv_dgrad_kernel", "conv_wgrad_mfma_kernel", "wgrad_reduce_kernel",
         "sgd_momentum_kernel", "adam_kernel", "l2_loss_kernel",

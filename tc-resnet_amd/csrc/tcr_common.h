@@ -17,6 +17,7 @@ constexpr int kWave = 64;
 // ---- error plumbing (thread-local message behind tcr_last_error) --------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);      // hipGetLastError -> TCR_OK / TCR_ERR_HIP
+int tune_get(int knob);                  // process-wide tuning knobs (tcr_tune)
 
 #define TCR_REQUIRE(cond, ...)                 \
     do {                                       \
@@ -46,6 +47,39 @@ inline void same_pad(int len, int k, int stride, int* out, int* lo, int* hi) {
 }
 
 // ---- device helpers -------------------------------------------------------------------------
+// Ordering point between LDS phases that stay INSIDE one wavefront: a wave's DS operations execute in
+// order, so no s_barrier is needed -- only the compiler must not move LDS accesses across the point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Base of the dynamic LDS region (launch-time size, third hipLaunchKernelGGL argument).
+#if defined(TCR_HOST_EMULATION)
+inline char* dyn_lds() {
+    alignas(16) static char buf[160 * 1024];
+    return buf;
+}
+#else
+__device__ __forceinline__ char* dyn_lds() {
+    extern __shared__ __attribute__((aligned(16))) char tcr_dyn_lds[];
+    return tcr_dyn_lds;
+}
+#endif
+
+// A zero the optimiser cannot see through.  Adding it to a table pointer keeps loop-invariant table
+// loads INSIDE the loop (they hit L1/K$) instead of being hoisted into dozens of long-lived VGPRs.
+__device__ __forceinline__ int opaque_zero() {
+#if defined(TCR_HOST_EMULATION)
+    return 0;
+#else
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
