@@ -184,6 +184,23 @@ def main():
         out["forward_3010"] = {"value": round(world * B * args.steps / dt2, 1), "unit": "utterances/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
                                "workload": "same, 98x40 MFCC (30/10 ms, FFT 512)"}
 
+        # ---------------- DS-CNN-L forward (configs[4]): 49x10 MFCC, batch 4096 ----------------
+        fe3 = T.Frontend(window_size_samples=640, window_stride_samples=320, num_mfccs=10, device=dev)
+        ds = T.DSCNN("L", fe3.n_frames, 10, 12, device=dev)
+        ds.init_xavier(0)
+        feat3 = torch.empty((B, 10, fe3.n_frames + 8), device=dev)
+
+        def fwd3():
+            fe3(wav, out=feat3)
+            ds.forward_infer(feat3)
+
+        dsteps = max(5, args.steps // 3)
+        dt3 = timed(fwd3, dsteps, max(2, args.warmup // 3), dist_on)
+        ds_flops = 2.0 * 28327812.0          # 28.33 M MAC / utterance
+        out["dscnn_l_forward"] = {"value": round(world * B * dsteps / dt3, 1), "unit": "utterances/s", "ms_per_step": round(dt3 / dsteps * 1e3, 4),
+                                  "net_tflops": round(world * B * dsteps / dt3 * ds_flops / 1e12 / world, 2),
+                                  "workload": "DSCNNLModel eval forward, waveform->softmax, 49x10 MFCC, batch 4096/GPU"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

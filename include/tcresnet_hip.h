@@ -178,6 +178,36 @@ int tcr_net_backward_stage(const tcr_net* net, const float* params, const float*
                            void* workspace, size_t workspace_bytes, float* grads, int stage, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Network: DS-CNN S / M / L (audio_nets/ds_cnn.py:19-118), the depthwise-separable baseline     */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct tcr_dscnn_cfg {
+    int32_t h_in;                   /* frames (49 for 40/20 ms) */
+    int32_t w_in;                   /* MFCC coefficients (--num_mfccs 10) */
+    int32_t num_classes;
+    int32_t depth;                  /* 64 / 172 / 276 (ds_cnn.py:20,29,37) */
+    int32_t n_separable;            /* 4 / 4 / 5 separable blocks */
+    int32_t conv1_kh, conv1_kw;     /* 10 x 4 */
+    int32_t conv1_sh, conv1_sw;     /* (2,2) S; (2,1) M, L */
+    int32_t ds1_sh, ds1_sw;         /* stride of conv_ds_1: (1,1) S; (2,2) M, L */
+    float bn_decay;                 /* 0.96 (ds_cnn.py:107) */
+    float bn_eps;                   /* 0.001 */
+} tcr_dscnn_cfg;
+
+typedef struct tcr_dscnn tcr_dscnn;
+
+int tcr_dscnn_create(const tcr_dscnn_cfg* cfg, tcr_dscnn** out);
+void tcr_dscnn_destroy(tcr_dscnn* net);
+int64_t tcr_dscnn_param_floats(const tcr_dscnn* net);   /* weights, biases, BN beta (no gamma: scale=False) */
+int64_t tcr_dscnn_stat_floats(const tcr_dscnn* net);
+int tcr_dscnn_num_tensors(const tcr_dscnn* net);
+int tcr_dscnn_tensor_info(const tcr_dscnn* net, int index, tcr_tensor_info* out);   /* names: "DSCNN/conv_ds_1/pointwise_conv/weights", ... */
+size_t tcr_dscnn_workspace_bytes(const tcr_dscnn* net, int batch);
+/* Eval-mode forward: feat = front-end output [batch][w_in][tcr_padded_len(h_in)] (num_mfccs = w_in);
+ * logits / probs [batch][num_classes].  DSCNN() + slim.softmax (ds_cnn.py:89-101, factory/audio_nets.py:147-156). */
+int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params, const float* stats, const float* feat,
+                            int batch, void* workspace, size_t workspace_bytes, float* logits, float* probs, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Optimiser (helper/trainer.py:171-197) and L2 (factory/audio_nets.py:175-182)                */
 /* ------------------------------------------------------------------------------------------ */
 /* tf.train.MomentumOptimizer, use_nesterov=False:  g' = g*grad_scale + wd*w (first n_decay floats)

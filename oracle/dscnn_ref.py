@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE ONLY -- NumPy restatement of DS-CNN (audio_nets/ds_cnn.py:19-118 of the reference).
+
+PARITY UNPINNED (see oracle/__init__.py).  Layout follows TF NHWC: activations [N, H, W, C] with H = time
+(49 frames), W = MFCC coefficient (10), C = 1 at the input (factory/audio_nets.py feeds [B, T, F, 1]).
+
+DSCNN_arg_scope (:104-118): conv2d / separable_conv2d have activation_fn=None, Xavier weights, ZERO-initialised
+biases (present); slim.batch_norm with decay 0.96, epsilon 1e-3 (slim default), center=True, scale=False (slim
+default -> no gamma), activation_fn=relu applied inside the BN layer.  SAME padding everywhere (slim default).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .numpy_ref import BN_EPS, same_pad, softmax
+
+BN_DECAY = 0.96
+
+
+@dataclass
+class DsBlock:
+    type: str            # "conv" | "separable"
+    depth: int
+    kernel: Tuple[int, int]
+    stride: Tuple[int, int]
+    scope: str
+
+
+def net_def(size: str) -> List[DsBlock]:
+    """S_NET_DEF / M_NET_DEF / L_NET_DEF (audio_nets/ds_cnn.py:19-43)."""
+    depth = {"S": 64, "M": 172, "L": 276}[size]
+    first = (2, 2) if size == "S" else (2, 1)
+    ds1 = (1, 1) if size == "S" else (2, 2)
+    n_ds = 4 if size in ("S", "M") else 5
+    out = [DsBlock("conv", depth, (10, 4), first, "conv_1")]
+    for i in range(1, n_ds + 1):
+        out.append(DsBlock("separable", depth, (3, 3), ds1 if i == 1 else (1, 1), f"conv_ds_{i}"))
+    return out
+
+
+def init_params(blocks: List[DsBlock], num_classes: int = 12, in_channels: int = 1, seed: int = 0, dtype=np.float64,
+                randomize: bool = True):
+    """TF variable names: DSCNN/conv_1/{weights,biases}, DSCNN/conv_1/batch_norm/{beta,moving_*},
+    DSCNN/conv_ds_k/depthwise_conv/{depthwise_weights,biases}, .../dw_batch_norm/*, .../pointwise_conv/{weights,biases},
+    .../pw_batch_norm/*, DSCNN/fc1/{weights,biases}.  `randomize` fills biases/beta/moving stats with non-trivial
+    values (the reference initialises them to 0 / 0 / 0,1) so that parity exercises every term."""
+    rng = np.random.RandomState(seed)
+    p: Dict[str, np.ndarray] = {}
+    s: Dict[str, np.ndarray] = {}
+
+    def xavier(shape, fan_in, fan_out):
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, size=shape).astype(dtype)
+
+    def bn(prefix, c):
+        p[prefix + "/beta"] = (rng.uniform(-0.5, 0.5, c) if randomize else np.zeros(c)).astype(dtype)
+        s[prefix + "/moving_mean"] = (rng.uniform(-0.5, 0.5, c) if randomize else np.zeros(c)).astype(dtype)
+        s[prefix + "/moving_variance"] = (rng.uniform(0.5, 2.0, c) if randomize else np.ones(c)).astype(dtype)
+
+    def bias(c):
+        return (rng.uniform(-0.2, 0.2, c) if randomize else np.zeros(c)).astype(dtype)
+
+    c = in_channels
+    for b in blocks:
+        kh, kw = b.kernel
+        if b.type == "conv":
+            p[f"DSCNN/{b.scope}/weights"] = xavier((kh, kw, c, b.depth), kh * kw * c, kh * kw * b.depth)
+            p[f"DSCNN/{b.scope}/biases"] = bias(b.depth)
+            bn(f"DSCNN/{b.scope}/batch_norm", b.depth)
+        else:
+            # slim.separable_conv2d(num_outputs=None, depth_multiplier=1): depthwise only; xavier fans as for a conv
+            p[f"DSCNN/{b.scope}/depthwise_conv/depthwise_weights"] = xavier((kh, kw, c, 1), kh * kw * c, kh * kw * 1)
+            p[f"DSCNN/{b.scope}/depthwise_conv/biases"] = bias(c)
+            bn(f"DSCNN/{b.scope}/dw_batch_norm", c)
+            p[f"DSCNN/{b.scope}/pointwise_conv/weights"] = xavier((1, 1, c, b.depth), c, b.depth)
+            p[f"DSCNN/{b.scope}/pointwise_conv/biases"] = bias(b.depth)
+            bn(f"DSCNN/{b.scope}/pw_batch_norm", b.depth)
+        c = b.depth
+    p["DSCNN/fc1/weights"] = xavier((c, num_classes), c, num_classes)
+    p["DSCNN/fc1/biases"] = bias(num_classes)
+    return p, s
+
+
+def _pad2d(x, kh, kw, sh, sw):
+    n, h, w, c = x.shape
+    oh, pt, pb = same_pad(h, kh, sh)
+    ow, pl, pr = same_pad(w, kw, sw)
+    return np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0))), oh, ow
+
+
+def conv2d(x, w, stride):
+    """tf.nn.conv2d NHWC / HWIO, SAME."""
+    kh, kw, ci, co = w.shape
+    sh, sw = stride
+    xp, oh, ow = _pad2d(x, kh, kw, sh, sw)
+    hi = np.arange(oh)[:, None] * sh + np.arange(kh)[None, :]
+    wi = np.arange(ow)[:, None] * sw + np.arange(kw)[None, :]
+    cols = xp[:, hi[:, None, :, None], wi[None, :, None, :], :]          # [N, oh, ow, kh, kw, C]
+    return np.einsum("nhwijc,ijco->nhwo", cols, w, optimize=True)
+
+
+def depthwise_conv2d(x, w, stride):
+    """tf.nn.depthwise_conv2d, depth_multiplier 1: w [kh, kw, C, 1]."""
+    kh, kw, c, _ = w.shape
+    sh, sw = stride
+    xp, oh, ow = _pad2d(x, kh, kw, sh, sw)
+    hi = np.arange(oh)[:, None] * sh + np.arange(kh)[None, :]
+    wi = np.arange(ow)[:, None] * sw + np.arange(kw)[None, :]
+    cols = xp[:, hi[:, None, :, None], wi[None, :, None, :], :]
+    return np.einsum("nhwijc,ijc->nhwc", cols, w[..., 0], optimize=True)
+
+
+def _bn_relu(y, p, s, prefix, is_training, new_stats):
+    beta = p[prefix + "/beta"]
+    if is_training:
+        mean = y.mean(axis=(0, 1, 2))
+        var = ((y - mean) ** 2).mean(axis=(0, 1, 2))
+        n = y.shape[0] * y.shape[1] * y.shape[2]
+        mm, mv = s[prefix + "/moving_mean"], s[prefix + "/moving_variance"]
+        new_stats[prefix + "/moving_mean"] = mm - (1.0 - BN_DECAY) * (mm - mean)
+        new_stats[prefix + "/moving_variance"] = mv - (1.0 - BN_DECAY) * (mv - var * n / max(n - 1, 1))
+    else:
+        mean, var = s[prefix + "/moving_mean"], s[prefix + "/moving_variance"]
+    return np.maximum((y - mean) / np.sqrt(var + BN_EPS) + beta, 0.0)       # scale=False: no gamma; relu inside BN
+
+
+def forward(blocks: List[DsBlock], p, s, x, is_training: bool = False):
+    """DSCNN() (audio_nets/ds_cnn.py:89-101).  x: [N, H, W] or [N, H, W, 1].  Returns dict(logits, probs, new_stats)."""
+    if x.ndim == 3:
+        x = x[..., None]
+    new_stats = dict(s)
+    net = x
+    for b in blocks:
+        if b.type == "conv":                                                     # parse_block :66-74
+            net = conv2d(net, p[f"DSCNN/{b.scope}/weights"], b.stride) + p[f"DSCNN/{b.scope}/biases"]
+            net = _bn_relu(net, p, s, f"DSCNN/{b.scope}/batch_norm", is_training, new_stats)
+        else:                                                                    # _depthwise_separable_conv :46-62
+            pre = f"DSCNN/{b.scope}"
+            net = depthwise_conv2d(net, p[pre + "/depthwise_conv/depthwise_weights"], b.stride) + p[pre + "/depthwise_conv/biases"]
+            net = _bn_relu(net, p, s, pre + "/dw_batch_norm", is_training, new_stats)
+            net = conv2d(net, p[pre + "/pointwise_conv/weights"], (1, 1)) + p[pre + "/pointwise_conv/biases"]
+            net = _bn_relu(net, p, s, pre + "/pw_batch_norm", is_training, new_stats)
+    pooled = net.mean(axis=(1, 2))                                               # avg_pool over the full map (:96)
+    logits = pooled @ p["DSCNN/fc1/weights"] + p["DSCNN/fc1/biases"]             # slim.fully_connected (:99)
+    return {"logits": logits, "probs": softmax(logits), "new_stats": new_stats, "feat": net}

@@ -119,8 +119,26 @@ def make_net(name: str, width: float, tag: str, batch: int = 4, seed: int = 0, f
     np.savez_compressed(os.path.join(OUT, f"{name.lower()}_{width}_{tag}.npz"), **out)
 
 
+def make_dscnn():
+    """DS-CNN S/M/L eval logits; weights are regenerated from the seed (dscnn_ref.init_params(net_def(size), seed=0))."""
+    import dataclasses
+    from . import dscnn_ref as D
+    cfg = dataclasses.replace(R.FRONTEND_4020, num_mfccs=10)
+    wav = R.synth_waveforms(3, seed=2468)
+    x = R.mfcc(wav, cfg)
+    out = {"wav": wav, "mfcc": x, "win": cfg.win, "hop": cfg.hop, "init_seed": 0}
+    for size in ("S", "M", "L"):
+        p, s = D.init_params(D.net_def(size), seed=0)
+        r = D.forward(D.net_def(size), p, s, x, False)
+        out[f"logits_{size}"] = r["logits"]
+        out[f"probs_{size}"] = r["probs"]
+        out[f"n_params_{size}"] = sum(v.size for v in p.values())
+    np.savez_compressed(os.path.join(OUT, "dscnn_4020.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    make_dscnn()
     make_frontend()
     make_net("TCResNet8", 1.0, "4020")
     make_net("TCResNet8", 1.0, "3010", batch=3)

@@ -33,6 +33,13 @@ class TCResNetCfg(C.Structure):
                 ("bn_eps", C.c_float)]
 
 
+class DSCNNCfg(C.Structure):
+    _fields_ = [("h_in", C.c_int32), ("w_in", C.c_int32), ("num_classes", C.c_int32), ("depth", C.c_int32),
+                ("n_separable", C.c_int32), ("conv1_kh", C.c_int32), ("conv1_kw", C.c_int32), ("conv1_sh", C.c_int32),
+                ("conv1_sw", C.c_int32), ("ds1_sh", C.c_int32), ("ds1_sw", C.c_int32), ("bn_decay", C.c_float),
+                ("bn_eps", C.c_float)]
+
+
 class TensorInfo(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("kind", C.c_int32), ("arena", C.c_int32), ("offset", C.c_int64),
                 ("size", C.c_int64), ("shape", C.c_int32 * 4), ("rank", C.c_int32)]
@@ -72,6 +79,14 @@ _PROTOTYPES = {
     "tcr_net_forward_train_stage": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int64,
                                               C.c_float, _P, C.c_size_t, _P, _P, _P, C.c_int, _P]),
     "tcr_net_backward_stage": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_int, _P]),
+    "tcr_dscnn_create": (C.c_int, [C.POINTER(DSCNNCfg), C.POINTER(_P)]),
+    "tcr_dscnn_destroy": (None, [_P]),
+    "tcr_dscnn_param_floats": (C.c_int64, [_P]),
+    "tcr_dscnn_stat_floats": (C.c_int64, [_P]),
+    "tcr_dscnn_num_tensors": (C.c_int, [_P]),
+    "tcr_dscnn_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(TensorInfo)]),
+    "tcr_dscnn_workspace_bytes": (C.c_size_t, [_P, C.c_int]),
+    "tcr_dscnn_forward_infer": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P, _P, _P]),
     "tcr_sgd_momentum_step": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "tcr_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int64, C.c_float, C.c_float, _P]),

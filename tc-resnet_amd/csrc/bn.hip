@@ -17,11 +17,12 @@ namespace tcr {
 __global__ __launch_bounds__(128) void bn_fold_kernel(const BnFoldArgs a) {
     const int l = blockIdx.x;
     for (int c = threadIdx.x; c < a.c[l]; c += 128) {
-        const float g = a.params[a.gamma_off[l] + c], b = a.params[a.beta_off[l] + c];
+        const float g = a.gamma_off[l] >= 0 ? a.params[a.gamma_off[l] + c] : 1.0f, b = a.params[a.beta_off[l] + c];
         const float mm = a.stats[a.mean_off[l] + c], mv = a.stats[a.var_off[l] + c];
+        const float cb = a.bias_off[l] >= 0 ? a.params[a.bias_off[l] + c] : 0.0f;
         const float sc = g / sqrtf(mv + a.eps);
         a.out[a.out_off[l] + c] = sc;
-        a.out[a.out_off[l] + a.c_pad[l] + c] = fmaf(-mm, sc, b);
+        a.out[a.out_off[l] + a.c_pad[l] + c] = fmaf(cb - mm, sc, b);
     }
 }
 

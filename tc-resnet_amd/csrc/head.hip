@@ -56,12 +56,21 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
             float af = 0.f;
             if (cv) {
                 if (o < a.nc) af = a.wfc[(size_t)c * a.nc + o];
-                else if (o < a.nc + 2) af = a.wfc2[(size_t)c * 2 + (o - a.nc)];
+                else if (o < a.nc + 2 && a.wfc2) af = a.wfc2[(size_t)c * 2 + (o - a.nc)];
             }
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[m], 0, 0, 0);
         }
     }
 
+    if (a.bias) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int o = m * 16 + q * 4 + reg;
+                if (o < a.nc) acc[m][reg] += a.bias[o];
+            }
+    }
     // this lane: utterance r, classes o = 16 m + 4 q + reg
     float mx = -3.0e38f;
 #pragma unroll

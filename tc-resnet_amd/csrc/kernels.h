@@ -74,6 +74,7 @@ struct BnFoldArgs {
     int c[kBnMaxLayers];
     int c_pad[kBnMaxLayers];
     int64_t gamma_off[kBnMaxLayers], beta_off[kBnMaxLayers], mean_off[kBnMaxLayers], var_off[kBnMaxLayers], out_off[kBnMaxLayers];
+    int64_t bias_off[kBnMaxLayers];     // conv bias folded into the shift (DS-CNN), or -1; gamma_off -1 = no scale
 };
 
 struct ChanReduceArgs {
@@ -165,6 +166,7 @@ struct HeadArgs {
     float* dscale;              // [B][C]   (train) d(dropped)/d(sum over time) = mask / keep_prob / T
     float* dlogits;             // [B][NC]  (train) (p - y) / global_batch
     float* loss_utt;            // [B]      (train) -sum_k y_k log p_k
+    const float* bias;          // [NC] added to the logits (slim.fully_connected of DS-CNN), or nullptr
     int batch, c, nc, t, tp;
     float keep_prob;
     uint64_t seed;

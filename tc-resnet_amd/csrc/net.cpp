@@ -305,7 +305,7 @@ extern "C" int tcr_net_forward_infer(const tcr_net* net, const float* params, co
         const ConvLayer& l = net->layers[li];
         f.c[f.n] = l.cout; f.c_pad[f.n] = l.c_pad;
         f.gamma_off[f.n] = l.gamma_off; f.beta_off[f.n] = l.beta_off;
-        f.mean_off[f.n] = l.mean_off; f.var_off[f.n] = l.var_off; f.out_off[f.n] = l.ss_off;
+        f.mean_off[f.n] = l.mean_off; f.var_off[f.n] = l.var_off; f.out_off[f.n] = l.ss_off; f.bias_off[f.n] = -1;
         ++f.n;
     }
     TCR_TRY(launch_bn_fold(f, s));

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import HALO, FrontendCfg, TCResNetCfg, TensorInfo, TcrError, padded_len
+from ._lib import HALO, DSCNNCfg, FrontendCfg, TCResNetCfg, TensorInfo, TcrError, padded_len
 
 
 def _resolve(lib: Optional[_lib.Library], device) -> Tuple[_lib.Library, torch.device]:
@@ -327,6 +327,93 @@ class TCResNet(_Base):
         self.lib.check(self.lib.tcr_adam_step(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), v.data_ptr(),
                                               self.n_param, self.n_decay, float(lr), float(beta1), float(beta2), float(eps),
                                               int(step), float(weight_decay), float(grad_scale), self._stream()), "tcr_adam_step")
+
+    def l2_loss(self, weight_decay: float) -> torch.Tensor:
+        out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.lib.check(self.lib.tcr_l2_loss(self.params.data_ptr(), self.n_decay, float(weight_decay), out.data_ptr(),
+                                            self._stream()), "tcr_l2_loss")
+        return out[0]
+
+
+class DSCNN(_Base):
+    """DS-CNN S / M / L, eval-mode forward (audio_nets/ds_cnn.py:19-118 of the reference)."""
+
+    NET_DEFS = {            # depth, separable blocks, conv_1 stride, conv_ds_1 stride  (ds_cnn.py:19-43)
+        "S": (64, 4, (2, 2), (1, 1)),
+        "M": (172, 4, (2, 1), (2, 2)),
+        "L": (276, 5, (2, 1), (2, 2)),
+    }
+
+    def __init__(self, size: str, h_in: int, w_in: int, num_classes: int, bn_decay: float = 0.96, bn_eps: float = 0.001,
+                 lib: Optional[_lib.Library] = None, device=None):
+        self.lib, self.device = _resolve(lib, device)
+        depth, nsep, s1, sds = self.NET_DEFS[size]
+        cfg = DSCNNCfg(int(h_in), int(w_in), int(num_classes), depth, nsep, 10, 4, s1[0], s1[1], sds[0], sds[1],
+                       float(bn_decay), float(bn_eps))
+        handle = C.c_void_p()
+        self.lib.check(self.lib.tcr_dscnn_create(C.byref(cfg), C.byref(handle)), "tcr_dscnn_create")
+        self.cfg, self._h, self.size = cfg, handle, size
+        self.num_classes, self.h_in, self.w_in = int(num_classes), int(h_in), int(w_in)
+        self.n_param = self.lib.tcr_dscnn_param_floats(handle)
+        self.n_decay = self.n_param     # the reference's name filter excludes only "BatchNorm"; these scopes are "batch_norm"
+        self.n_stat = self.lib.tcr_dscnn_stat_floats(handle)
+        self.tensors: Dict[str, TensorInfo] = {}
+        for i in range(self.lib.tcr_dscnn_num_tensors(handle)):
+            ti = TensorInfo()
+            self.lib.check(self.lib.tcr_dscnn_tensor_info(handle, i, C.byref(ti)), "tcr_dscnn_tensor_info")
+            self.tensors[ti.name.decode()] = ti
+        self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
+        self._ws: Dict[int, torch.Tensor] = {}
+        for n, ti in self.tensors.items():
+            if ti.kind == 4:
+                self._view(n).fill_(1.0)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.tcr_dscnn_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    _view = TCResNet._view
+    state_dict = TCResNet.state_dict
+    load_state_dict = TCResNet.load_state_dict
+
+    def total_params(self) -> int:
+        return sum(int(ti.size) for ti in self.tensors.values() if ti.arena == 0)
+
+    def init_xavier(self, seed: int = 0):
+        gen = torch.Generator().manual_seed(int(seed))
+        for n, ti in self.tensors.items():
+            if ti.kind != 0:
+                continue
+            shape = tuple(ti.shape[i] for i in range(ti.rank))
+            if ti.rank == 4:
+                kh, kw, cin, cout = shape
+                fan_in, fan_out = kh * kw * cin, kh * kw * cout
+            else:
+                fan_in, fan_out = shape
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            self._view(n).copy_(((torch.rand(shape, generator=gen) * 2.0 - 1.0) * lim).to(self.device))
+
+    def forward_infer(self, feat: torch.Tensor):
+        self._check_tensor(feat, "features")
+        want = (self.w_in, padded_len(self.h_in))
+        if feat.dim() != 3 or tuple(feat.shape[1:]) != want:
+            raise TcrError(f"features must be planar [B, {want[0]}, {want[1]}], got {tuple(feat.shape)}")
+        b = feat.shape[0]
+        ws = self._ws.get(b)
+        if ws is None:
+            ws = torch.empty(self.lib.tcr_dscnn_workspace_bytes(self._h, b) // 4, dtype=torch.float32, device=self.device)
+            self._ws[b] = ws
+        logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
+        probs = torch.empty_like(logits)
+        self.lib.check(self.lib.tcr_dscnn_forward_infer(self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(), b,
+                                                        ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(),
+                                                        self._stream()), "tcr_dscnn_forward_infer")
+        return logits, probs
 
     def l2_loss(self, weight_decay: float) -> torch.Tensor:
         out = torch.zeros(1, dtype=torch.float32, device=self.device)

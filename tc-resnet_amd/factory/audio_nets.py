@@ -191,6 +191,45 @@ class TCResNet14Model(_TCResNetModel):
     base_channels = [16, 24, 24, 32, 32, 48, 48]
 
 
+class _DSCNNModel(AudioNetModel):
+    """DS-CNN S / M / L (factory/audio_nets.py:299-359 of the reference): eval-mode build on the HIP kernels.
+    The training kernels of this family (BN without scale, biases, Adam) are not built yet."""
+    size = None
+
+    @staticmethod
+    def add_arguments(parser):
+        parser.add_argument("--weight_decay", default=0.0, type=float)
+
+    def build_inference(self, inputs, is_training):
+        from ..engine import DSCNN
+        if is_training:
+            raise NotImplementedError("DS-CNN training (train-mode BN / backward / Adam) is not built yet; eval-mode forward is")
+        key = ("DSCNN", self.size, int(inputs.shape[1]), int(inputs.shape[2]), self.args.num_classes, id(runtime.default_lib()))
+        eng = tc_resnet._engines.get(key)
+        if eng is None:
+            eng = DSCNN(self.size, int(inputs.shape[1]), int(inputs.shape[2]), self.args.num_classes,
+                        lib=runtime.default_lib(), device=runtime.default_device())
+            eng.init_xavier(0)
+            tc_resnet._engines[key] = eng
+        self.engine = eng
+        self._loss_sum = None
+        logits, probs = eng.forward_infer(self._preprocessor.planar)
+        self._probs = probs
+        return logits, {"engine": eng}
+
+
+class DSCNNSModel(_DSCNNModel):
+    size = "S"
+
+
+class DSCNNMModel(_DSCNNModel):
+    size = "M"
+
+
+class DSCNNLModel(_DSCNNModel):
+    size = "L"
+
+
 def _not_built(name, ref):
     class _Stub(AudioNetModel):
         @staticmethod
@@ -208,8 +247,5 @@ Res8Model = _not_built("Res8Model", "audio_nets/res.py")
 Res8NarrowModel = _not_built("Res8NarrowModel", "audio_nets/res.py")
 Res15Model = _not_built("Res15Model", "audio_nets/res.py")
 Res15NarrowModel = _not_built("Res15NarrowModel", "audio_nets/res.py")
-DSCNNSModel = _not_built("DSCNNSModel", "audio_nets/ds_cnn.py")
-DSCNNMModel = _not_built("DSCNNMModel", "audio_nets/ds_cnn.py")
-DSCNNLModel = _not_built("DSCNNLModel", "audio_nets/ds_cnn.py")
 ResNet2D8Model = _not_built("ResNet2D8Model", "audio_nets/tc_resnet.py:73-84")
 ResNet2D8PoolModel = _not_built("ResNet2D8PoolModel", "audio_nets/tc_resnet.py:88-99")

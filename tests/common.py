@@ -134,3 +134,22 @@ def check_train(lib, fname, name, width, steps=3, grad_rtol=2e-4):
             ref = fx[k]
             assert np.abs(net._view(k[len("stat3:"):]).cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k
     return worst
+
+
+def check_dscnn(lib, size):
+    from oracle import dscnn_ref as D
+    fx = load("dscnn_4020.npz")
+    p, s = D.init_params(D.net_def(size), seed=int(fx["init_seed"]))
+    fe = make_frontend(lib, fx["win"], fx["hop"], num_mfccs=10)
+    feat = fe(to_dev(lib, fx["wav"]))
+    net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
+    assert net.total_params() == int(fx[f"n_params_{size}"])
+    sd = dict(p)
+    sd.update(s)
+    net.load_state_dict(sd)
+    logits, probs = net.forward_infer(feat)
+    err = np.abs(logits.cpu().numpy() - fx[f"logits_{size}"]).max()
+    assert err < LOGIT_TOL, f"DSCNN-{size}: logits max abs err {err}"
+    assert np.array_equal(logits.cpu().numpy().argmax(1), fx[f"logits_{size}"].argmax(1))
+    assert np.abs(probs.cpu().numpy() - fx[f"probs_{size}"]).max() < 1e-5
+    return err

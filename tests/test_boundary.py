@@ -84,7 +84,11 @@ def test_model_build_matches_oracle(emu_runtime):
     assert abs(float(model.model_loss) - mdl) < 1e-4 and abs(float(model.total_loss) - tot) < 1e-4
     assert tuple(model.inputs.shape) == (4, 49, 40, 1) and model.endpoints["ranges"].shape == (4, 2)
     with pytest.raises(NotImplementedError):
-        audio_nets.DSCNNLModel(args).build(wavs, labels, is_training=False)
+        audio_nets.Res8Model(args).build(wavs, labels, is_training=False)
+    args10 = argparse.Namespace(**{**vars(args), "num_mfccs": 10, "weight_decay": 0.0})
+    ds = audio_nets.DSCNNLModel(args10)
+    ds.build(wavs, labels, is_training=False)
+    assert tuple(ds.audio.shape) == (4, 49, 10, 1) and ds.total_params == 413736 and tuple(ds.logits.shape) == (4, 12)
     with pytest.raises(NotImplementedError):
         model.build_deployable_model()
 

@@ -90,3 +90,8 @@ def test_engine_argument_errors(emu_lib):
     assert sd["TCResNet8/conv0/weights"].shape == (3, 1, 40, 16) and abs(sd["TCResNet8/conv0/weights"]).max() <= np.sqrt(6.0 / (120 + 48)) + 1e-6
     assert np.all(sd["TCResNet8/conv0/BatchNorm/gamma"] == 1) and np.all(sd["TCResNet8/conv0/BatchNorm/moving_variance"] == 1)
     assert net.total_params() == 65264
+
+
+@pytest.mark.parametrize("size", ["S", "M", "L"])
+def test_dscnn_eval_forward(emu_lib, size):
+    Cm.check_dscnn(emu_lib, size)

@@ -105,3 +105,24 @@ def test_full_batch_train_properties(hip_lib):
     # moving variance uses the Bessel factor n/(n-1) of the ACTUAL count (4096*T), not of the 64-utterance oracle
     k = "TCResNet8/conv0/BatchNorm/moving_mean"
     assert np.abs(net._view(k).cpu().numpy() - ref["new_stats"][k]).max() < 1e-5
+
+
+@pytest.mark.parametrize("size", ["S", "M", "L"])
+def test_dscnn_eval_forward(hip_lib, size):
+    Cm.check_dscnn(hip_lib, size)
+
+
+def test_dscnn_full_batch_independence(hip_lib):
+    """DSCNN-L at batch 4096 (BASELINE.json configs[4]): 64 distinct utterances tiled 64x give identical rows."""
+    from oracle import dscnn_ref as D
+    import dataclasses
+    p, s = D.init_params(D.net_def("L"), seed=0)
+    base = R.synth_waveforms(64, seed=9)
+    fe = Cm.make_frontend(hip_lib, 640, 320, num_mfccs=10)
+    net = T.DSCNN("L", fe.n_frames, 10, 12, device="cuda")
+    sd = dict(p); sd.update(s); net.load_state_dict(sd)
+    logits, probs = net.forward_infer(fe(torch.from_numpy(np.tile(base, (64, 1))).cuda()))
+    l = logits.view(64, 64, 12)
+    assert torch.equal(l, l[:1].expand_as(l))
+    ref = D.forward(D.net_def("L"), p, s, R.mfcc(base, dataclasses.replace(R.FRONTEND_4020, num_mfccs=10)), False)
+    assert np.abs(l[0].cpu().numpy() - ref["logits"]).max() < Cm.LOGIT_TOL

@@ -87,3 +87,15 @@ def test_lr_schedule_and_dropout_mirror():
     assert 0.4 < m.mean() < 0.6 and set(np.unique(m)) == {0.0, 1.0}
     # shard invariance: rows of a shard equal the rows of the global mask
     assert np.array_equal(dropout_mask(7, 16, 8, 48, 0.5), m[16:24])
+
+
+def test_dscnn_oracle_matches_golden_and_shapes():
+    from oracle import dscnn_ref as D
+    fx = Cm.load("dscnn_4020.npz")
+    for size, n, hw in (("S", 23180, (25, 5)), ("M", 136580, (13, 5)), ("L", 413736, (13, 5))):
+        p, s = D.init_params(D.net_def(size), seed=0)
+        assert sum(v.size for v in p.values()) == n
+        r = D.forward(D.net_def(size), p, s, fx["mfcc"], False)
+        assert r["feat"].shape[1:3] == hw                       # 49x10 -> 25x10 -> 13x5
+        assert np.abs(r["logits"] - fx[f"logits_{size}"]).max() < 1e-12
+    assert "DSCNN/conv_ds_5/pw_batch_norm/beta" in p and "DSCNN/conv_1/batch_norm/gamma" not in p      # scale=False
