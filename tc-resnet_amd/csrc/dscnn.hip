@@ -102,13 +102,21 @@ struct DsDwArgs {
 };
 
 __global__ __launch_bounds__(256) void dscnn_depthwise_kernel(const DsDwArgs a) {
+    // one wavefront per (utterance, channel) plane: lanes walk the output map, the 9 taps / scale / shift of the
+    // plane's channel are wave-uniform (scalar loads)
     const int P = a.oh * a.ow;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (int64_t)gridDim.x * 256) {
-        const int rem = (int)(i % P);
-        const int64_t row = i / P;              // b * C + c
-        const int c = (int)(row % a.c);
-        const int oh = rem / a.ow, ow = rem - oh * a.ow;
-        const float* xr = a.x + row * a.ppi + kHalo;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // b * C + c
+    if (row * P >= a.total) return;
+    const int c = (int)(row % a.c);
+    float wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = a.w[(size_t)k * a.c + c];
+    const float sc = a.scale[c], sh = a.shift[c];
+    const float* xr = a.x + row * a.ppi + kHalo;
+    float* yr = a.y + row * a.ppo + kHalo;
+    for (int pos = lane; pos < P; pos += 64) {
+        const int oh = pos / a.ow, ow = pos - oh * a.ow;
         float s = 0.f;
 #pragma unroll
         for (int di = 0; di < 3; ++di) {
@@ -117,11 +125,24 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_kernel(const DsDwArgs a) 
             for (int dj = 0; dj < 3; ++dj) {
                 const int w = ow * a.sw + dj - a.pad_l;
                 const float xv = (h >= 0 && h < a.h_in && w >= 0 && w < a.w_in) ? xr[h * a.w_in + w] : 0.f;
-                s = fmaf(a.w[(size_t)(di * 3 + dj) * a.c + c], xv, s);
+                s = fmaf(wt[di * 3 + dj], xv, s);
             }
         }
-        a.y[row * a.ppo + kHalo + rem] = fmaxf(fmaf(s, a.scale[c], a.shift[c]), 0.f);
+        yr[pos] = fmaxf(fmaf(s, sc, sh), 0.f);
     }
+}
+
+// pooled[b][c][HALO] = mean over the P positions of plane (b, c): one wavefront per plane (coalesced row read +
+// 64-lane shuffle reduction); feeds head_fwd_kernel with T = 1 when the map is large (DS-CNN: 13 x 5 = 65).
+__global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ pooled, int64_t rows, int p, int pp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * pp + kHalo;
+    float s = 0.f;
+    for (int i = lane; i < p; i += 64) s += xr[i];
+    s = wave_sum(s);
+    if (lane == 0) pooled[row * tcr_padded_len(1) + kHalo] = s / (float)p;
 }
 
 struct DsLayer {
@@ -288,8 +309,7 @@ extern "C" int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params
             d.total = (int64_t)batch * l.cin * P; d.c = l.cin; d.h_in = l.h_in; d.w_in = l.w_in;
             d.ppi = tcr_padded_len(l.h_in * l.w_in); d.oh = l.oh; d.ow = l.ow; d.ppo = pp;
             d.sh = l.sh; d.sw = l.sw; d.pad_t = l.pad_t; d.pad_l = l.pad_l;
-            int64_t blocks = ceil_div64(d.total, 256);
-            if (blocks > 8192) blocks = 8192;
+            const int64_t blocks = ceil_div64((int64_t)batch * l.cin, 4);
             hipLaunchKernelGGL(dscnn_depthwise_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d);
             TCR_TRY(check_launch("dscnn_depthwise_kernel"));
             Conv1x1Args c1;
@@ -299,11 +319,16 @@ extern "C" int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params
         }
     }
     const DsLayer& last = net->layers.back();
+    const int P = last.oh * last.ow;
+    const int64_t rows = (int64_t)batch * last.cout;
+    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, s, (const float*)buf[cur], buf[cur ^ 1], rows, P,
+                       tcr_padded_len(P));
+    TCR_TRY(check_launch("plane_mean_kernel"));
     HeadArgs h;
     std::memset(&h, 0, sizeof(h));
-    h.feat = buf[cur]; h.wfc = params + net->fcw_off; h.wfc2 = nullptr; h.bias = params + net->fcb_off;
+    h.feat = buf[cur ^ 1]; h.wfc = params + net->fcw_off; h.wfc2 = nullptr; h.bias = params + net->fcb_off;
     h.logits = logits; h.probs = probs; h.ranges = nullptr;
-    h.batch = batch; h.c = last.cout; h.nc = net->cfg.num_classes; h.t = last.oh * last.ow; h.tp = tcr_padded_len(last.oh * last.ow);
+    h.batch = batch; h.c = last.cout; h.nc = net->cfg.num_classes; h.t = 1; h.tp = tcr_padded_len(1);
     h.keep_prob = 1.0f; h.inv_global_batch = 1.0f;
     return launch_head_fwd(h, false, s);
 }
