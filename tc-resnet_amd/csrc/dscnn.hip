@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict
     float s = 0.f;
     for (int i = lane; i < p; i += 64) s += xr[i];
     s = wave_sum(s);
-    if (lane == 0) pooled[row * tcr_padded_len(1) + kHalo] = s / (float)p;
+    if (lane == 0) pooled[row * (1 + 2 * kHalo) + kHalo] = s / (float)p;
 }
 
 struct DsLayer {

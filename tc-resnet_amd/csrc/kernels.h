@@ -62,6 +62,35 @@ size_t wgrad_partial_floats(int k, int cin, int cout, int npos);
 int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
                       int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s);
 
+// ---- fused.hip : whole-network eval forward, activations resident in LDS ---------------------
+constexpr int kFusedMaxLayers = 32;
+
+struct FusedLayer {
+    int k, stride, cin, cout, tin, tout, pad_lo, relu;
+    int in_buf, out_buf, res_buf;       // LDS buffer ids (res_buf < 0: none)
+    int w_off, ss_off, c_pad;           // float offsets into params / scale-shift table
+};
+
+struct FusedArgs {
+    const float* params;
+    const float* ss;
+    const float* feat;          // [B][C0][Tp0]
+    float* logits;
+    float* probs;
+    float* ranges;              // may be nullptr
+    int batch, group, n_groups, n_layers;
+    int buf_off[3];             // float offset of each LDS buffer
+    int buf_sz[3];              // floats per utterance in each buffer
+    int in_c, in_tp;            // feature rows: channels x padded length
+    int feat_buf;               // buffer holding the last block output
+    int feat_c, feat_t, nc;
+    int fc_off, fc2_off;
+    FusedLayer layer[kFusedMaxLayers];
+};
+
+// returns 1 when the launch could not be configured (caller falls back to the per-layer kernels)
+int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, hipStream_t s);
+
 // ---- bn.hip ---------------------------------------------------------------------------------
 constexpr int kBnMaxLayers = 40;
 

@@ -282,6 +282,62 @@ static int conv_forward_with_down(const ConvLayer& la, const ConvLayer& ld, cons
     return launch_conv_mfma_with_down(a, params + ld.w_off, yd, scd, shd, la.pad_lo, epi, s);
 }
 
+// Whole-network fused launch (fused.hip): three rotating LDS buffers per utterance,
+//   R0: features, later the `down` outputs;  R1: conv0 / block outputs;  R2: conv_a outputs.
+static int forward_infer_fused(const tcr_net& net, const float* params, const float* ss, const float* feat, int batch,
+                               float* logits, float* probs, float* ranges, hipStream_t s) {
+    FusedArgs a;
+    std::memset(&a, 0, sizeof(a));
+    if ((int)net.units.size() > kFusedMaxLayers) return 1;
+    int sz[3] = {0, 0, 0};
+    auto grow = [&](int b, int c, int t) { const int n = (int)align_up((int64_t)c * tcr_padded_len(t), 4); if (n > sz[b]) sz[b] = n; };
+    auto add = [&](int li, int in_buf, int out_buf, int res_buf) {
+        const ConvLayer& l = net.layers[li];
+        FusedLayer& L = a.layer[a.n_layers++];
+        L.k = l.k; L.stride = l.stride; L.cin = l.cin; L.cout = l.cout; L.tin = l.tin; L.tout = l.tout; L.pad_lo = l.pad_lo;
+        L.relu = l.relu; L.in_buf = in_buf; L.out_buf = out_buf; L.res_buf = res_buf;
+        L.w_off = (int)l.w_off; L.ss_off = (int)l.ss_off; L.c_pad = l.c_pad;
+        grow(out_buf, l.cout, l.tout);
+        return l.cin % 4 == 0;
+    };
+    bool ok = true;
+    grow(0, net.cfg.in_channels, net.cfg.t_in);
+    ok &= add(0, 0, 1, -1);
+    for (const Block& b : net.blocks) {
+        if (b.down >= 0) ok &= add(b.down, 1, 0, -1);
+        ok &= add(b.a, 1, 2, -1);
+        ok &= add(b.b, 2, 1, b.down >= 0 ? 0 : 1);
+    }
+    if (!ok || net.param_floats >= (int64_t)1 << 31) return 1;
+    const int per_utt = sz[0] + sz[1] + sz[2];
+    int group = tune_get(TCR_TUNE_FUSED_GROUP);
+    if (group <= 0) {
+        // measured (scripts/fused_test.py, B = 4096): groups of 4 utterances win over the per-layer kernels while the
+        // group's activations stay below ~80 KB of LDS (TCResNet8-1.0 / TCResNet14-1.5 at 49 frames); the 98-frame
+        // front-end doubles every row and the per-layer kernels are as fast or faster there.
+        if ((size_t)4 * per_utt * sizeof(float) > 80 * 1024) return 1;
+        group = 4;
+    }
+    if (group > 16) group = 16;
+    if (group > batch) group = batch;
+    if (group < 1) group = 1;
+    const size_t lds = (size_t)group * per_utt * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    // the head scratch (pooled + logits) lives in a buffer other than the feature buffer
+    if ((int64_t)group * (net.feat_c + net.cfg.num_classes + 2) > (int64_t)group * sz[2] && (int64_t)group * (net.feat_c + net.cfg.num_classes + 2) > (int64_t)group * sz[0]) return 1;
+    a.params = params; a.ss = ss; a.feat = feat; a.logits = logits; a.probs = probs; a.ranges = ranges;
+    a.batch = batch; a.group = group; a.n_groups = ceil_div(batch, group);
+    a.buf_off[0] = 0; a.buf_off[1] = group * sz[0]; a.buf_off[2] = group * (sz[0] + sz[1]);
+    a.buf_sz[0] = sz[0]; a.buf_sz[1] = sz[1]; a.buf_sz[2] = sz[2];
+    a.in_c = net.cfg.in_channels; a.in_tp = tcr_padded_len(net.cfg.t_in);
+    a.feat_buf = 1; a.feat_c = net.feat_c; a.feat_t = net.feat_t; a.nc = net.cfg.num_classes;
+    a.fc_off = (int)net.layers[net.fc].w_off; a.fc2_off = (int)net.layers[net.fc2].w_off;
+    const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+    int grid = 256 * per_cu;
+    if (grid > a.n_groups) grid = a.n_groups;
+    return launch_net_fused(a, lds, grid, s);
+}
+
 }  // namespace tcr
 
 extern "C" int tcr_net_forward_infer(const tcr_net* net, const float* params, const float* stats, const float* feat,
@@ -309,6 +365,11 @@ extern "C" int tcr_net_forward_infer(const tcr_net* net, const float* params, co
         ++f.n;
     }
     TCR_TRY(launch_bn_fold(f, s));
+
+    if (tune_get(TCR_TUNE_NET_FUSED) != 1) {
+        const int rc = forward_infer_fused(*net, params, ss, feat, batch, logits, probs, ranges, s);
+        if (rc != 1) return rc;         // launched (or failed); 1 == does not fit -> per-layer kernels below
+    }
 
     auto run = [&](int li, const float* res) -> int {
         const ConvLayer& l = net->layers[li];
