@@ -96,10 +96,16 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
 }
 
 int chan_reduce_chunks(int npos) {
-    int n = ceil_div(npos, 2048);
-    if (n > 128) n = 128;
+    int n = ceil_div(npos, 512);        // >= 2 positions per thread; many short workgroups hide the load latency
+    if (n > 512) n = 512;
     if (n < 1) n = 1;
     return n;
+}
+
+// number of partial rows launch_chan_reduce() writes for npos positions (grid.x)
+int chan_reduce_launch_chunks(int npos) {
+    const int nchunk = chan_reduce_chunks(npos);
+    return ceil_div(npos, ceil_div(npos, nchunk));
 }
 
 int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t s) {
@@ -129,10 +135,42 @@ int launch_chan_sums(const float* partial, int nchunk, int c, float* sums, hipSt
 }
 
 // Train-mode forward finalize from sums[2][C] over `count` elements.
-__global__ __launch_bounds__(128) void bn_finalize_kernel(const BnFinalizeArgs a) {
-    for (int c = threadIdx.x; c < a.c; c += 128) {
-        const double m = (double)a.sums[c] / a.count;
-        double var = (double)a.sums[a.c + c] / a.count - m * m;
+// Sum of the per-workgroup partial rows (double accumulation, FIXED order: chunk k goes to slice k % nparts, the
+// slices are then added in order), spread over the whole workgroup; or the pre-reduced sums (sync BN).
+// Returns through s_out[which * c + ch]; ends with a barrier.
+__device__ __forceinline__ void reduce_partials(const float* partial, int nchunk, const float* sums, int nc, double* s_slices, double* s_out) {
+    const int n2 = 2 * nc;
+    if (nchunk > 0) {
+        const int nparts = max(1, (int)blockDim.x / n2);
+        const int part = threadIdx.x / n2, col = threadIdx.x - part * n2;     // col = which * nc + ch
+        if (part < nparts) {
+            const int which = col / nc, ch = col - which * nc;
+            double acc = 0.0;
+            for (int k = part; k < nchunk; k += nparts) acc += (double)partial[((size_t)k * 2 + which) * nc + ch];
+            s_slices[part * n2 + col] = acc;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+            double acc = 0.0;
+            for (int p = 0; p < nparts; ++p) acc += s_slices[p * n2 + i];
+            s_out[i] = acc;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) s_out[i] = (double)sums[i];
+    }
+    __syncthreads();
+}
+
+constexpr int kBnMaxC = 256;        // channels per BN layer supported by the finalize kernels
+
+__global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a) {
+    __shared__ double s_slices[512];
+    __shared__ double s_tot[2 * kBnMaxC];
+    reduce_partials(a.partial, a.nchunk, a.sums, a.c, s_slices, s_tot);
+    for (int c = threadIdx.x; c < a.c; c += blockDim.x) {
+        const double s1 = s_tot[c], s2 = s_tot[a.c + c];
+        const double m = s1 / a.count;
+        double var = s2 / a.count - m * m;
         if (var < 0.0) var = 0.0;
         const float meanf = (float)m, varf = (float)var;
         const float inv = 1.0f / sqrtf(varf + a.eps);
@@ -150,7 +188,8 @@ __global__ __launch_bounds__(128) void bn_finalize_kernel(const BnFinalizeArgs a
 }
 
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, s, a);
+    if (a.c > kBnMaxC) { set_error("bn_finalize: %d channels exceed the limit %d", a.c, kBnMaxC); return TCR_ERR_ARG; }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(512), 0, s, a);
     return check_launch("bn_finalize_kernel");
 }
 
@@ -179,9 +218,12 @@ int launch_bn_apply(const BnApplyArgs& a, hipStream_t s) {
 
 // Backward finalize: dgamma, dbeta into the gradient arena + the per-channel coefficients of
 //   dy = k1 * (dz - k2 - (y - mean) * k3),  k1 = gamma*invstd, k2 = dbeta/n, k3 = invstd*dgamma/n
-__global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const BnBwdFinalizeArgs a) {
-    for (int c = threadIdx.x; c < a.c; c += 128) {
-        const float db = a.sums[c], dg = a.sums[a.c + c];
+__global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const BnBwdFinalizeArgs a) {
+    __shared__ double s_slices[512];
+    __shared__ double s_tot[2 * kBnMaxC];
+    reduce_partials(a.partial, a.nchunk, a.sums, a.c, s_slices, s_tot);
+    for (int c = threadIdx.x; c < a.c; c += blockDim.x) {
+        const float db = (float)s_tot[c], dg = (float)s_tot[a.c + c];
         a.dbeta[c] = db * a.grad_scale;
         a.dgamma[c] = dg * a.grad_scale;
         a.k1[c] = a.gamma[c] * a.invstd[c];
@@ -191,7 +233,8 @@ __global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const BnBwdFinaliz
 }
 
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, s, a);
+    if (a.c > kBnMaxC) { set_error("bn_bwd_finalize: %d channels exceed the limit %d", a.c, kBnMaxC); return TCR_ERR_ARG; }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(512), 0, s, a);
     return check_launch("bn_bwd_finalize_kernel");
 }
 

@@ -58,7 +58,7 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s);
 int launch_conv_mfma(int k, int stride, const ConvArgs& a, int epi, hipStream_t s);
 int launch_conv_mfma_with_down(const ConvArgs& a, const float* w_down, float* y_down, const float* scale_down,
                                const float* shift_down, int pad_lo, int epi, hipStream_t s);
-size_t wgrad_partial_floats(int k, int cin, int cout, int npos);
+size_t wgrad_partial_floats(int k, int cin, int cout, int batch);
 int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
                       int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s);
 
@@ -120,6 +120,8 @@ struct ChanReduceArgs {
 };
 
 struct BnFinalizeArgs {
+    const float* partial;       // [nchunk][2][C] per-workgroup partial sums (nchunk > 0), reduced here in double ...
+    int nchunk;                 // ... or 0: take the already reduced (possibly cross-replica) `sums`
     const float* sums;          // [2][C]: sum y, sum y^2
     const float* gamma;
     const float* beta;
@@ -145,6 +147,8 @@ struct BnApplyArgs {
 };
 
 struct BnBwdFinalizeArgs {
+    const float* partial;   // as in BnFinalizeArgs
+    int nchunk;
     const float* sums;      // [2][C]: sum dz, sum dz*xhat
     const float* gamma;
     const float* invstd;
@@ -175,6 +179,7 @@ struct BnBwdApplyArgs {
 
 int launch_bn_fold(const BnFoldArgs& a, hipStream_t s);
 int chan_reduce_chunks(int npos);
+int chan_reduce_launch_chunks(int npos);
 int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t s);
 int launch_chan_sums(const float* partial, int nchunk, int c, float* sums, hipStream_t s);
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);

@@ -329,12 +329,12 @@ struct WgradArgs {
     const float* x;         // [B][Cin][Tpi]   (input activation of the conv, zero halo)
     const float* dy;        // [B][Cout][Tpo]  (gradient wrt the conv output)
     float* partial;         // [nchunk][K][Cin_pad][Cout_pad]
-    int npos;               // B * Tout
+    int batch;
     int cin, cout, cin_pad, cout_pad;   // cout = width of this output-channel slice
     int cout_all, co_base;              // full channel count of dy / first channel of the slice
     int tpi, tout, tpo, stride;
     int xoff;               // HALO - pad_lo
-    int pos_per_block;      // multiple of 16
+    int utt_per_block;
 };
 
 template <int K, int NCO>
@@ -351,28 +351,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradArgs a)
     for (int j = 0; j < K; ++j)
 #pragma unroll
         for (int m = 0; m < NCO; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool cov[NCO];
+    int coc[NCO];
+#pragma unroll
+    for (int m = 0; m < NCO; ++m) {
+        cov[m] = m * 16 + r < a.cout;
+        coc[m] = a.co_base + (cov[m] ? m * 16 + r : 0);
+    }
 
-    const int blk0 = blockIdx.x * a.pos_per_block;
-    const int blk1 = min(blk0 + a.pos_per_block, a.npos);
-    // the 4 waves interleave 4-position steps of the block's range
-    for (int p4 = blk0 + wave * 4; p4 < blk1; p4 += 16) {
-        const int p = p4 + q;
-        const bool pv = p < blk1;
-        const int pc = pv ? p : blk1 - 1;
-        const int n = pc / a.tout, t = pc - n * a.tout;
-        const float* xr = a.x + ((size_t)n * a.cin + cic) * a.tpi + t * a.stride + a.xoff;
-        const float* dr = a.dy + ((size_t)n * a.cout_all + a.co_base) * a.tpo + kHalo + t;
-        float bf[NCO];
+    // The reduction index is (utterance, t): the MFMA k dimension holds 4 consecutive t of one utterance
+    // (lane group q), so operand addresses advance by plain increments -- no per-step division.
+    const int n_begin = blockIdx.x * a.utt_per_block;
+    const int n_end = min(n_begin + a.utt_per_block, a.batch);
+    for (int n = n_begin + wave; n < n_end; n += 4) {
+        const float* xr = a.x + ((size_t)n * a.cin + cic) * a.tpi + a.xoff + q * a.stride;
+        const float* dr = a.dy + (size_t)n * a.cout_all * a.tpo + kHalo + q;
+#pragma unroll 2
+        for (int t0 = 0; t0 < a.tout; t0 += 4) {
+            const bool pv = t0 + q < a.tout;
+            float bf[NCO], af[K];
 #pragma unroll
-        for (int m = 0; m < NCO; ++m) {
-            const int co = m * 16 + r;
-            bf[m] = (pv && co < a.cout) ? dr[(size_t)co * a.tpo] : 0.f;
-        }
+            for (int m = 0; m < NCO; ++m) bf[m] = (pv && cov[m]) ? dr[(size_t)coc[m] * a.tpo + t0] : 0.f;
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const float af = (pv && civ) ? xr[j] : 0.f;
+            for (int j = 0; j < K; ++j) af[j] = (pv && civ) ? xr[t0 * a.stride + j] : 0.f;
 #pragma unroll
-            for (int m = 0; m < NCO; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[m], acc[j][m], 0, 0, 0);
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int m = 0; m < NCO; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[m], acc[j][m], 0, 0, 0);
         }
     }
     // combine the 4 waves in LDS (fixed order), then write the slab
@@ -402,36 +407,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradArgs a)
     }
 }
 
-// dw[j][ci][co] = sum_chunk partial[chunk][j][ci][co]   (fixed order)
+// dw[j][ci][co] = sum_chunk partial[chunk][j][ci][co].  Four lanes per output walk interleaved chunk subsets and are
+// combined with a fixed two-step shuffle tree, so the result is bitwise reproducible.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int nchunk, int k, int cin, int cout, int cin_pad, int cout_pad,
                                                            int cout_all, int co_base) {
     const int total = k * cin * cout;
     const size_t slab = (size_t)k * cin_pad * cout_pad;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int co = i % cout;
-        const int r = i / cout;
-        const int ci = r % cin;
-        const int j = r / cin;
-        const size_t off = ((size_t)j * cin_pad + ci) * cout_pad + co;
-        float s = 0.f;
-        for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * slab + off];
-        dw[((size_t)j * cin + ci) * cout_all + co_base + co] = s;
-    }
+    const int part = threadIdx.x & 3;
+    const int i = min((int)((blockIdx.x * 256 + threadIdx.x) >> 2), total - 1);
+    const bool live = (int)((blockIdx.x * 256 + threadIdx.x) >> 2) < total;
+    const int co = i % cout;
+    const int r = i / cout;
+    const int ci = r % cin;
+    const int j = r / cin;
+    const size_t off = ((size_t)j * cin_pad + ci) * cout_pad + co;
+    float s = 0.f;
+    for (int c = part; c < nchunk; c += 4) s += partial[(size_t)c * slab + off];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (live && part == 0) dw[((size_t)j * cin + ci) * cout_all + co_base + co] = s;
 }
 
-int wgrad_chunks(int npos) {
-    int n = ceil_div(npos, 1024);       // >= 1024 positions per workgroup
-    if (n > 256) n = 256;
+int wgrad_chunks(int batch) {
+    int n = ceil_div(batch, 16);        // >= 16 utterances (4 per wave) per workgroup
+    if (n > 128) n = 128;
     if (n < 1) n = 1;
     return n;
 }
 
-size_t wgrad_partial_floats(int k, int cin, int cout, int npos) {
+size_t wgrad_partial_floats(int k, int cin, int cout, int batch) {
     const int cin_pad = ceil_div(cin, 16) * 16;
     const int cs = cout > 80 ? 80 : cout;
     const int cout_pad = ceil_div(cs, 16) * 16;
-    return (size_t)wgrad_chunks(npos) * k * cin_pad * cout_pad;
+    return (size_t)wgrad_chunks(batch) * k * cin_pad * cout_pad;
 }
 
 template <int K>
@@ -454,7 +463,7 @@ int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float
     for (int co_base = 0; co_base < cout; co_base += 80) {
         WgradArgs a;
         a.x = x; a.dy = dy; a.partial = scratch;
-        a.npos = batch * tout;
+        a.batch = batch;
         a.cin = cin;
         a.cout = (cout - co_base) > 80 ? 80 : (cout - co_base);
         a.cout_all = cout; a.co_base = co_base;
@@ -462,9 +471,9 @@ int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float
         a.cout_pad = ceil_div(a.cout, 16) * 16;
         a.tpi = tpi; a.tout = tout; a.tpo = tpo; a.stride = stride;
         a.xoff = kHalo - pad_lo;
-        const int nchunk = wgrad_chunks(a.npos);
-        a.pos_per_block = ceil_div(ceil_div(a.npos, nchunk), 16) * 16;
-        const dim3 grid(ceil_div(a.npos, a.pos_per_block), a.cin_pad / 16);
+        const int nchunk = wgrad_chunks(batch);
+        a.utt_per_block = ceil_div(batch, nchunk);
+        const dim3 grid(ceil_div(batch, a.utt_per_block), a.cin_pad / 16);
         const int nco = a.cout_pad / 16;
         int rc;
         if (k == 9) rc = launch_wgrad_k<9>(a, nco, grid, s);
@@ -472,7 +481,7 @@ int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float
         else rc = launch_wgrad_k<1>(a, nco, grid, s);
         TCR_TRY(rc);
         const int total = k * cin * a.cout;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)scratch, dw,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total * 4, 256)), dim3(256), 0, s, (const float*)scratch, dw,
                            (int)grid.x, k, cin, a.cout, a.cin_pad, a.cout_pad, cout, co_base);
         TCR_TRY(check_launch("wgrad_reduce_kernel"));
     }

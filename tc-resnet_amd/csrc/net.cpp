@@ -87,11 +87,11 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
         cmax = l.cout > cmax ? l.cout : cmax;
         const int64_t wsz = (int64_t)l.k * l.cin * l.cout;
         wmax = wsz > wmax ? wsz : wmax;
-        const int64_t wg = (int64_t)wgrad_partial_floats(l.k, l.cin, l.cout, batch * l.tout);
+        const int64_t wg = (int64_t)wgrad_partial_floats(l.k, l.cin, l.cout, batch);
         wgmax = wg > wgmax ? wg : wgmax;
     }
     if (train) {
-        w.partial = take((int64_t)128 * 2 * cmax);
+        w.partial = take((int64_t)512 * 2 * cmax);
         w.sums = take(2 * cmax);
         w.kcoef = take(3 * (int64_t)align_up(cmax, 64));
         const int c = net.feat_c, nc = net.cfg.num_classes;
@@ -410,6 +410,7 @@ extern "C" int tcr_net_forward_infer(const tcr_net* net, const float* params, co
 namespace tcr {
 
 struct TrainCtx {
+    bool sync_bn;           // cross-replica statistics: partial rows are pre-reduced into `sums` for the host all-reduce
     const tcr_net* net;
     Workspace w;
     float* base;
@@ -459,6 +460,7 @@ static int fwd_unit_pre(const TrainCtx& c, int li) {
     r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout);
     int nchunk = 0;
     TCR_TRY(launch_chan_reduce(0, r, &nchunk, c.s));
+    if (!c.sync_bn) return TCR_OK;          // the finalize kernel sums the partial rows itself
     return launch_chan_sums(c.base + c.w.partial, nchunk, l.cout, c.base + c.w.sums, c.s);
 }
 
@@ -467,6 +469,8 @@ static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* r
     const ConvLayer& l = c.net->layers[li];
     float* ss = c.base + c.w.ss + l.ss_off;
     BnFinalizeArgs f;
+    f.partial = c.base + c.w.partial;
+    f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout);
     f.sums = c.base + c.w.sums;
     f.gamma = c.params + l.gamma_off; f.beta = c.params + l.beta_off;
     f.moving_mean = stats + l.mean_off; f.moving_var = stats + l.var_off;
@@ -510,6 +514,7 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
     }
     c.base = static_cast<float*>(workspace); c.params = params; c.feat = feat; c.batch = batch;
     c.bn_batch = sync_bn ? (double)global_batch : (double)batch;
+    c.sync_bn = sync_bn != 0;
     c.s = static_cast<hipStream_t>(stream);
     const int nu = (int)net->units.size();
     TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_forward_train: bad stage range [%d, %d)", stage_begin, stage_end);
@@ -621,6 +626,7 @@ static int bwd_unit_pre(const TrainCtx& c, const BwdUnit& u) {
     r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout); r.bcast = u.da_bcast;
     int nchunk = 0;
     TCR_TRY(launch_chan_reduce(1, r, &nchunk, c.s));
+    if (!c.sync_bn) return TCR_OK;
     return launch_chan_sums(c.base + c.w.partial, nchunk, l.cout, c.base + c.w.sums, c.s);
 }
 
@@ -631,6 +637,8 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     float* kc = c.base + c.w.kcoef;
     const int64_t kstride = align_up(l.cout, 64);
     BnBwdFinalizeArgs f;
+    f.partial = c.base + c.w.partial;
+    f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout);
     f.sums = c.base + c.w.sums; f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[u.li];
     f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
     f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
@@ -697,6 +705,7 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     }
     c.base = static_cast<float*>(workspace); c.params = params; c.feat = feat; c.batch = batch;
     c.bn_batch = sync_bn ? (double)global_batch : (double)batch;
+    c.sync_bn = sync_bn != 0;
     c.s = static_cast<hipStream_t>(stream);
     const std::vector<int> order = backward_order(*net);
     const int nu = (int)order.size();

@@ -246,12 +246,16 @@ class TCResNet(_Base):
             raise TcrError(f"features must be planar [B, {want[0]}, {want[1]}], got {tuple(feat.shape)}")
 
     # ---- compute ------------------------------------------------------------------------------
-    def forward_infer(self, feat: torch.Tensor, want_ranges: bool = False):
+    def forward_infer(self, feat: torch.Tensor, want_ranges: bool = False, out=None):
+        """Eval-mode forward.  `out=(logits, probs)` reuses caller-owned output tensors (stream pipelines)."""
         self._check_feat(feat)
         b = feat.shape[0]
         ws = self.workspace(b, False)
-        logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
-        probs = torch.empty_like(logits)
+        if out is not None:
+            logits, probs = out
+        else:
+            logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
+            probs = torch.empty_like(logits)
         ranges = torch.empty((b, 2), dtype=torch.float32, device=self.device) if want_ranges else None
         self.lib.check(self.lib.tcr_net_forward_infer(self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(), b,
                                                       ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(),

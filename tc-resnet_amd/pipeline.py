@@ -1,0 +1,54 @@
+"""Two-stream inference pipeline: the front-end of batch k+1 overlaps the network of batch k.
+
+The fused MFCC kernel is VALU/latency-bound and the network kernels run on the matrix cores, so the two
+co-reside on the CUs; features and outputs are double-buffered and ordered with HIP events
+(front-end(k+2) waits for network(k) before reusing its feature buffer)."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from ._lib import padded_len
+
+
+class InferencePipeline:
+    def __init__(self, frontend, net, batch: int, depth: int = 2):
+        self.fe, self.net, self.batch, self.depth = frontend, net, int(batch), int(depth)
+        dev = frontend.device
+        self.s_fe, self.s_net = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        self.feat = [torch.empty((batch, frontend.n_coef, padded_len(frontend.n_frames)), device=dev) for _ in range(depth)]
+        self.out = [(torch.empty((batch, net.num_classes), device=dev), torch.empty((batch, net.num_classes), device=dev))
+                    for _ in range(depth)]
+        self.net.workspace(batch, False)                 # allocate before the streams start
+        self._fe_done: List[torch.cuda.Event] = [torch.cuda.Event() for _ in range(depth)]
+        self._net_done: List[torch.cuda.Event] = [torch.cuda.Event() for _ in range(depth)]
+        self._k = 0
+        self.fe_events = None                            # optional (start, end) timing events per step
+
+    def submit(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Enqueue one batch; returns the (logits, probs) buffers it will land in (valid after `sync()` or after
+        `depth` further submits have been synchronised by the caller)."""
+        i = self._k % self.depth
+        cur = torch.cuda.current_stream(self.fe.device)
+        with torch.cuda.stream(self.s_fe):
+            self.s_fe.wait_stream(cur)                          # the caller produced `wav` on its current stream
+            if self._k >= self.depth:
+                self.s_fe.wait_event(self._net_done[i])         # feature buffer i is free again
+            if self.fe_events is not None:
+                self.fe_events[self._k][0].record(self.s_fe)
+            self.fe(wav, out=self.feat[i])
+            if self.fe_events is not None:
+                self.fe_events[self._k][1].record(self.s_fe)
+            self._fe_done[i].record(self.s_fe)
+        with torch.cuda.stream(self.s_net):
+            self.s_net.wait_event(self._fe_done[i])
+            self.net.forward_infer(self.feat[i], out=self.out[i])
+            self._net_done[i].record(self.s_net)
+        self._k += 1
+        return self.out[i]
+
+    def sync(self):
+        cur = torch.cuda.current_stream(self.fe.device)
+        cur.wait_stream(self.s_fe)
+        cur.wait_stream(self.s_net)
