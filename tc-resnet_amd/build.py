@@ -68,4 +68,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    try:
+        print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    except Exception as e:      # noqa: BLE001
+        print("BUILD FAILED:", str(e)[-1500:])
+        sys.exit(1)

@@ -20,6 +20,12 @@ struct ConvArgs {
     int tpi, tout, tpo;
     int xoff;               // HALO - pad_lo
     int relu;
+    // data-gradient use of the MFMA conv (EPI_RAW): output position t lands at row index t * ostride + ooff, and an
+    // optional tensor is accumulated into the result (the block's shortcut-branch gradient)
+    int ostride, ooff;      // 1, 0 for a forward conv (0 is read as 1)
+    const float* add;       // [B][Cout][Tpo] (or [B][Cout] when add_bcast), or nullptr
+    const float* add_mask;  // add is gated by [add_mask > 0]
+    int add_bcast;
 };
 
 struct DgradArgs {
@@ -56,6 +62,10 @@ struct Conv1x1Args {
 int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s);
 // implicit-GEMM k x 1 conv on the matrix cores; returns 1 (nothing launched) when the shape does not fit
 int launch_conv_mfma(int k, int stride, const ConvArgs& a, int epi, hipStream_t s);
+// dx = dgrad of a (k, stride) conv, computed as stride-1 MFMA convs over dy with re-arranged weights (scratch `wt`);
+// returns 1 when the shape is not covered
+int launch_conv_dgrad_mfma(int k, int stride, int pad_lo, const float* w, float* wt, const float* dy, float* dx, const float* add,
+                           const float* add_mask, int add_bcast, int batch, int cin, int cout, int tin, int tout, hipStream_t s);
 int launch_conv_mfma_with_down(const ConvArgs& a, const float* w_down, float* y_down, const float* scale_down,
                                const float* shift_down, int pad_lo, int epi, hipStream_t s);
 size_t wgrad_partial_floats(int k, int cin, int cout, int batch);

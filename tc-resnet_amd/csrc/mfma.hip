@@ -6,6 +6,8 @@
 //
 // Fragment layout of the 16x16x4 f32 MFMA (wave64): A[i = lane & 15][k = lane >> 4],
 // B[k = lane >> 4][j = lane & 15], D[row = 4 * (lane >> 4) + reg][col = lane & 15].
+#include <cstring>
+
 #include "kernels.h"
 
 namespace tcr {
@@ -111,10 +113,17 @@ struct ConvDownArgs {
     int relu;
 };
 
+struct ConvStoreExtra {
+    int ostride, ooff;
+    const float* add;
+    const float* add_mask;
+    int add_bcast;
+};
+
 template <int MT, int EPI>
 __device__ __forceinline__ void conv_mfma_store(const f32x4 (&acc)[MT][2], float* y, const float* scale, const float* shift,
                                                 const float* res, int relu, int cot0, int cout, int tout, int tpo,
-                                                int p_base, int wg_p1, int r, int q) {
+                                                int p_base, int wg_p1, int r, int q, const ConvStoreExtra ex) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int p = p_base + nt * 16 + r;
@@ -127,16 +136,22 @@ __device__ __forceinline__ void conv_mfma_store(const f32x4 (&acc)[MT][2], float
                 const int co = (cot0 + m) * 16 + q * 4 + reg;
                 if (co >= cout) continue;
                 float v = acc[m][nt][reg];
-                const size_t o = ((size_t)n * cout + co) * tpo + kHalo + t;
+                const size_t o = ((size_t)n * cout + co) * tpo + kHalo + t * ex.ostride + ex.ooff;
                 if (EPI == EPI_AFFINE) {
                     v = fmaf(v, scale[co], shift[co]);
                     if (res) v = fmaxf(v + res[o], 0.f);            // net += layer_in; relu  (tc_resnet.py:40-41)
                     else if (relu) v = fmaxf(v, 0.f);
+                } else if (ex.add) {
+                    float av = ex.add_bcast ? ex.add[(size_t)n * cout + co] : ex.add[o];
+                    if (ex.add_mask && !(ex.add_mask[o] > 0.f)) av = 0.f;
+                    v += av;
                 }
                 float* dst = y + o;
                 dst[0] = v;
-                if (t == 0) { dst[-4] = 0.f; dst[-3] = 0.f; dst[-2] = 0.f; dst[-1] = 0.f; }
-                if (t == tout - 1) { dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f; dst[4] = 0.f; }
+                if (ex.ostride == 1) {      // (strided data-gradient phases leave the halo alone: nothing reads it)
+                    if (t == 0) { dst[-4] = 0.f; dst[-3] = 0.f; dst[-2] = 0.f; dst[-1] = 0.f; }
+                    if (t == tout - 1) { dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f; dst[4] = 0.f; }
+                }
             }
     }
 }
@@ -239,7 +254,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a, const 
         j = j2;
         c0 = c2;
     }
-    conv_mfma_store<MT, EPI>(acc, a.y, a.scale, a.shift, a.res, a.relu, cot0, a.cout, a.tout, a.tpo, p_base, wg_p1, r, q);
+    const ConvStoreExtra ex = {a.ostride > 0 ? a.ostride : 1, a.ooff, a.add, a.add_mask, a.add_bcast};
+    conv_mfma_store<MT, EPI>(acc, a.y, a.scale, a.shift, a.res, a.relu, cot0, a.cout, a.tout, a.tpo, p_base, wg_p1, r, q, ex);
 
     if (DOWN) {
         f32x4 acc2[MT][2];
@@ -258,7 +274,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a, const 
             }
             mma_chunk(d.tap, cc, afA, acc2);
         }
-        conv_mfma_store<MT, EPI>(acc2, d.y, d.scale, d.shift, nullptr, d.relu, cot0, a.cout, a.tout, a.tpo, p_base, wg_p1, r, q);
+        const ConvStoreExtra ex2 = {1, 0, nullptr, nullptr, 0};
+        conv_mfma_store<MT, EPI>(acc2, d.y, d.scale, d.shift, nullptr, d.relu, cot0, a.cout, a.tout, a.tpo, p_base, wg_p1, r, q, ex2);
     }
 }
 
@@ -308,6 +325,71 @@ int launch_conv_mfma(int k, int stride, const ConvArgs& a, int epi, hipStream_t 
     if (k == 9 && stride == 1) return launch_conv_mfma_ks<9, 1>(a, nullptr, epi, s);
     if (k == 9 && stride == 2) return launch_conv_mfma_ks<9, 2>(a, nullptr, epi, s);
     return 1;
+}
+
+// ---- data gradient on the matrix cores -------------------------------------------------------------------------
+// dx[ci][tin] = sum_{j,co} dy[co][(tin + pad_lo - j) / S] * W[j][ci][co] over taps with S | (tin + pad_lo - j).
+// For each output phase r = tin mod S this is a stride-1 convolution over dy:
+//   dx[ci][S*u + r] = sum_{i'} sum_co dy[co][u + i' + d_min] * Wr[i'][co][ci],   Wr[i'] = W[r + pad_lo - S*(i' + d_min)]^T
+// so the forward implicit-GEMM kernel is reused with re-arranged weights, an output stride of S and offset r.
+__global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int k, int cin, int cout,
+                                                            int stride, int pad_lo) {
+    // wt holds the phases back to back: phase r has taps j = j0_r, j0_r + S, ... ; entry [i'][co][ci]
+    const int total = k * cin * cout;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int ci = idx % cin;
+        const int rest = idx / cin;
+        const int co = rest % cout;
+        const int slot = rest / cout;               // 0 .. k-1 over all phases
+        // enumerate phases in order, taps of a phase by increasing i' (i.e. decreasing j)
+        int base = 0, j = -1;
+        for (int r = 0; r < stride && j < 0; ++r) {
+            // taps of phase r: j == (r + pad_lo) mod S; jmax = the largest such j <= k-1 (may be < 0: empty phase)
+            const int jmax = (k - 1) - (((k - 1) - ((r + pad_lo) % stride) + stride) % stride);
+            const int cnt = jmax < 0 ? 0 : jmax / stride + 1;      // taps jmax, jmax - S, ..., >= 0
+            if (slot < base + cnt) j = jmax - (slot - base) * stride;
+            base += cnt;
+        }
+        wt[idx] = w[((size_t)j * cin + ci) * cout + co];
+    }
+}
+
+int launch_conv_dgrad_mfma(int k, int stride, int pad_lo, const float* w, float* wt, const float* dy, float* dx, const float* add,
+                           const float* add_mask, int add_bcast, int batch, int cin, int cout, int tin, int tout, hipStream_t s) {
+    if (cout % 4 != 0 || stride < 1 || stride > 2 || k > 9) return 1;
+    if (tune_get(TCR_TUNE_CONV_PATH) == 1) return 1;
+    hipLaunchKernelGGL(dgrad_weights_kernel, dim3(ceil_div(k * cin * cout, 256)), dim3(256), 0, s, w, wt, k, cin, cout, stride, pad_lo);
+    TCR_TRY(check_launch("dgrad_weights_kernel"));
+    int base = 0;
+    for (int r = 0; r < stride; ++r) {
+        const int res_mod = (r + pad_lo) % stride;
+        const int jmax = (k - 1) - (((k - 1) - res_mod + stride) % stride);
+        if (jmax < 0) continue;
+        const int cnt = jmax / stride + 1;
+        const int d_min = (r + pad_lo - jmax) / stride;      // (exact division: same residue)
+        const int nu = (tin - r + stride - 1) / stride;      // positions tin = S*u + r < Tin
+        if (nu <= 0) { base += cnt; continue; }
+        ConvArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.x = dy; a.w = wt + (size_t)base * cout * cin; a.y = dx;
+        a.npos = batch * nu; a.cin = cout; a.cout = cin;
+        a.tpi = tcr_padded_len(tout); a.tout = nu; a.tpo = tcr_padded_len(tin);
+        a.xoff = kHalo + d_min; a.relu = 0;
+        a.ostride = stride; a.ooff = r;
+        a.add = add; a.add_mask = add_mask; a.add_bcast = add_bcast;
+        int rc;
+        switch (cnt) {
+            case 1: rc = launch_conv_mfma_ks<1, 1>(a, nullptr, EPI_RAW, s); break;
+            case 3: rc = launch_conv_mfma_ks<3, 1>(a, nullptr, EPI_RAW, s); break;
+            case 4: rc = launch_conv_mfma_ks<4, 1>(a, nullptr, EPI_RAW, s); break;
+            case 5: rc = launch_conv_mfma_ks<5, 1>(a, nullptr, EPI_RAW, s); break;
+            case 9: rc = launch_conv_mfma_ks<9, 1>(a, nullptr, EPI_RAW, s); break;
+            default: set_error("dgrad: %d-tap phase has no instantiation", cnt); return TCR_ERR_ARG;
+        }
+        if (rc != TCR_OK) return rc == 1 ? TCR_ERR_ARG : rc;
+        base += cnt;
+    }
+    return TCR_OK;
 }
 
 // 9x1 stride-2 conv + the block's 1x1 stride-2 "down" conv in one launch (shared LDS image).

@@ -257,6 +257,7 @@ static int conv_forward(const tcr_net& net, const ConvLayer& l, const float* x, 
         return launch_conv1x1(a, epi == EPI_AFFINE ? MF_AFFINE : MF_RAW, s);
     }
     ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
     a.x = x; a.w = params + l.w_off; a.y = y; a.scale = scale; a.shift = shift; a.res = res;
     a.npos = batch * l.tout; a.cin = l.cin; a.cout = l.cout;
     a.tpi = tcr_padded_len(l.tin); a.tout = l.tout; a.tpo = tcr_padded_len(l.tout);
@@ -275,6 +276,7 @@ static int conv_forward_with_down(const ConvLayer& la, const ConvLayer& ld, cons
                                   int epi, int batch, hipStream_t s) {
     if (tune_get(TCR_TUNE_CONV_PATH) == 1 || la.k != 9 || la.stride != 2 || ld.k != 1 || ld.stride != 2) return 1;
     ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
     a.x = x; a.w = params + la.w_off; a.y = ya; a.scale = sca; a.shift = sha; a.res = nullptr;
     a.npos = batch * la.tout; a.cin = la.cin; a.cout = la.cout;
     a.tpi = tcr_padded_len(la.tin); a.tout = la.tout; a.tpo = tcr_padded_len(la.tout);
@@ -656,25 +658,34 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     TCR_TRY(launch_conv_wgrad(l.k, l.stride, l.pad_lo, x, dy, grads + l.w_off, c.base + c.w.wgrad_scratch,
                               c.batch, l.cin, l.cout, tpi, l.tout, tp, c.s));
     if (l.in_act < 0) return TCR_OK;        // no gradient flows into the features
-    // data gradient into gact[in_act]
+    // data gradient into gact[in_act]; the shortcut branch of the block adds its contribution in the same pass
     float* wt = c.base + c.w.wt;
-    TCR_TRY(launch_transpose_weights(c.params + l.w_off, wt, l.k, l.cin, l.cout, c.s));
-    DgradArgs d;
-    std::memset(&d, 0, sizeof(d));
-    d.dy = dy; d.wt = wt; d.dx = c.base + c.w.gact[l.in_act];
-    d.ugrp = ceil_div(l.tin, l.stride); d.ngrp = c.batch * d.ugrp;
-    d.cin = l.cin; d.cout = l.cout; d.tin = l.tin; d.tpi = tpi; d.tout = l.tout; d.tpo = tp; d.pad_lo = l.pad_lo;
-    // second contribution to the block input: the shortcut branch
+    float* dx = c.base + c.w.gact[l.in_act];
+    const float* add = nullptr;
+    const float* add_mask = nullptr;
+    int add_bcast = 0;
     for (size_t bi = 0; bi < net.blocks.size(); ++bi) {
         const Block& b = net.blocks[bi];
         if (u.li == b.down) {               // conv_a's dgrad ran first and already wrote gact[in]
-            d.add = d.dx;
+            add = dx;
         } else if (u.li == b.a && b.down < 0) {     // identity shortcut: + dOut * [out > 0]
-            if (b.b == net.blocks.back().b) { d.add = dpool; d.add_bcast = 1; }
-            else d.add = c.base + c.w.gact[b.b];
-            d.add_mask = c.base + c.w.act[b.b];
+            if (b.b == net.blocks.back().b) { add = dpool; add_bcast = 1; }
+            else add = c.base + c.w.gact[b.b];
+            add_mask = c.base + c.w.act[b.b];
         }
     }
+    {
+        const int rc = launch_conv_dgrad_mfma(l.k, l.stride, l.pad_lo, c.params + l.w_off, wt, dy, dx, add, add_mask, add_bcast,
+                                              c.batch, l.cin, l.cout, l.tin, l.tout, c.s);
+        if (rc != 1) return rc;
+    }
+    TCR_TRY(launch_transpose_weights(c.params + l.w_off, wt, l.k, l.cin, l.cout, c.s));
+    DgradArgs d;
+    std::memset(&d, 0, sizeof(d));
+    d.dy = dy; d.wt = wt; d.dx = dx;
+    d.ugrp = ceil_div(l.tin, l.stride); d.ngrp = c.batch * d.ugrp;
+    d.cin = l.cin; d.cout = l.cout; d.tin = l.tin; d.tpi = tpi; d.tout = l.tout; d.tpo = tp; d.pad_lo = l.pad_lo;
+    d.add = add; d.add_mask = add_mask; d.add_bcast = add_bcast;
     return launch_conv_dgrad(l.k, l.stride, d, c.s);
 }
 
