@@ -52,51 +52,53 @@ __global__ __launch_bounds__(256) void net_fused_kernel(const FusedArgs a) {
             const float* w = a.params + L.w_off;
             const float* scale = a.ss + L.ss_off;
             const float* shift = scale + L.c_pad;
+            const int wstep = 4 * L.cout;                   // weight floats per K-step (4 input channels of one tap)
+            const int xstep = 4 * tpi;                      // LDS floats per K-step within a tap
             for (int job = wave; job < ncp * nrt; job += 4) {
                 const int cp = job / nrt, m = job - cp * nrt;
-                const int co_a = m * 16 + r;                // A-fragment column of this lane
-                const bool wv = co_a < L.cout;
-                const float* wl = w + (size_t)q * L.cout + (wv ? co_a : 0);
-                int xo[2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int p = min(cp * 32 + nt * 16 + r, npos - 1);
-                    const int g = p / L.tout, t = p - g * L.tout;
-                    xo[nt] = g * in_sz + q * tpi + t * L.stride + kHalo - L.pad_lo;
+                // A-fragment element of this lane: W[j][4*c4 + q][16*m + r]; rows beyond Cout are clamped (never stored)
+                const int aidx = q * L.cout + min(m * 16 + r, L.cout - 1);
+                int xo0, xo1;
+                {
+                    const int p0 = min(cp * 32 + r, npos - 1), p1 = min(cp * 32 + 16 + r, npos - 1);
+                    const int g0 = p0 / L.tout, g1 = p1 / L.tout;
+                    xo0 = g0 * in_sz + q * tpi + (p0 - g0 * L.tout) * L.stride + kHalo - L.pad_lo;
+                    xo1 = g1 * in_sz + q * tpi + (p1 - g1 * L.tout) * L.stride + kHalo - L.pad_lo;
                 }
                 f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                // K-steps are (tap j, 4 input channels c4) pairs, linearised tap-major; weights are fetched one chunk
-                // (CH steps) ahead of the MFMAs that consume them
-                // K-steps are (tap j, 4 input channels c4) pairs, linearised tap-major; weights are fetched one chunk
-                // (CH steps) ahead of the MFMAs that consume them.  (Also prefetching the LDS operands into registers
-                // was measured SLOWER -- 338 vs 259 us -- the extra address arithmetic costs more than the latency saved.)
-                float afA[CH], afB[CH];
-                auto load_chunk = [&](int s0, float (&af)[CH]) {
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) {
-                        const int s = s0 + i;
-                        af[i] = (s < nsteps && wv) ? wl[(size_t)s * 4 * L.cout] : 0.f;   // (j*Cin + 4*c4) * Cout == s * 4 * Cout
-                    }
-                };
-                auto mma_chunk = [&](int s0, int& j, int& c4, const float (&af)[CH]) {
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) {
-                        if (s0 + i < nsteps) {
-                            const int off = 4 * c4 * tpi + j;
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], xin[xo[0] + off], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], xin[xo[1] + off], acc1, 0, 0, 0);
-                            if (++c4 == C4) { c4 = 0; ++j; }
-                        }
-                    }
-                };
-                int j = 0, c4 = 0;
-                load_chunk(0, afA);
-                for (int s0 = 0; s0 < nsteps; s0 += 2 * CH) {
-                    load_chunk(s0 + CH, afB);
-                    mma_chunk(s0, j, c4, afA);
-                    load_chunk(s0 + 2 * CH, afA);
-                    mma_chunk(s0 + CH, j, c4, afB);
+                // K-steps s = (tap j, channel quad c4), tap-major.  Weights come from L1/L2 through a 4-deep register
+                // ring (uniform base + 32-bit lane offset, clamped instead of branched at the tail); activations are read
+                // from the LDS rows at xo + off, where off = c4 * xstep + j is advanced with scalar increments.
+                const int last = nsteps - 1;
+                float a0 = w[aidx], a1 = w[aidx + min(1, last) * wstep], a2 = w[aidx + min(2, last) * wstep],
+                      a3 = w[aidx + min(3, last) * wstep];
+                // LDS operands are read one step ahead of the MFMAs that consume them (b0/b1 = current step,
+                // nb0/nb1 = next step), so the matrix pipe never waits on a ds_read it has just issued.
+                int off = xstep, c4 = 1, j = 0;
+                if (C4 == 1) { c4 = 0; off = j = 1; }
+                float b0 = xin[xo0], b1 = xin[xo1];
+#define TCR_FUSED_STEP(AREG, NEXT)                                                                      \
+    {                                                                                                   \
+        const float nb0 = xin[xo0 + off], nb1 = xin[xo1 + off];     /* (one step past the end: inside the pad) */ \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(AREG, b0, acc0, 0, 0, 0);                           \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(AREG, b1, acc1, 0, 0, 0);                           \
+        AREG = w[aidx + min(NEXT, last) * wstep];                                                       \
+        b0 = nb0;                                                                                       \
+        b1 = nb1;                                                                                       \
+        off += xstep;                                                                                   \
+        if (++c4 == C4) { c4 = 0; off = ++j; }                                                          \
+    }
+                int s0 = 0;
+                for (; s0 + 4 <= nsteps; s0 += 4) {
+                    TCR_FUSED_STEP(a0, s0 + 4)
+                    TCR_FUSED_STEP(a1, s0 + 5)
+                    TCR_FUSED_STEP(a2, s0 + 6)
+                    TCR_FUSED_STEP(a3, s0 + 7)
                 }
+                if (s0 < nsteps) TCR_FUSED_STEP(a0, last)
+                if (s0 + 1 < nsteps) TCR_FUSED_STEP(a1, last)
+                if (s0 + 2 < nsteps) TCR_FUSED_STEP(a2, last)
+#undef TCR_FUSED_STEP
                 // ---- epilogue: folded BN (+ shortcut) (+ ReLU) -> LDS rows of the output buffer ----
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {

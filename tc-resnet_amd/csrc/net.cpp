@@ -317,13 +317,13 @@ static int forward_infer_fused(const tcr_net& net, const float* params, const fl
         // measured (scripts/fused_test.py, B = 4096): groups of 4 utterances win over the per-layer kernels while the
         // group's activations stay below ~80 KB of LDS (TCResNet8-1.0 / TCResNet14-1.5 at 49 frames); the 98-frame
         // front-end doubles every row and the per-layer kernels are as fast or faster there.
-        if ((size_t)4 * per_utt * sizeof(float) > 80 * 1024) return 1;
+        if (((size_t)4 * per_utt + 64) * sizeof(float) > 80 * 1024) return 1;
         group = 4;
     }
     if (group > 16) group = 16;
     if (group > batch) group = batch;
     if (group < 1) group = 1;
-    const size_t lds = (size_t)group * per_utt * sizeof(float);
+    const size_t lds = ((size_t)group * per_utt + 64) * sizeof(float);      // + pad: operand prefetch reads one step past the end
     if (lds > 160 * 1024) return 1;
     // the head scratch (pooled + logits) lives in a buffer other than the feature buffer
     if ((int64_t)group * (net.feat_c + net.cfg.num_classes + 2) > (int64_t)group * sz[2] && (int64_t)group * (net.feat_c + net.cfg.num_classes + 2) > (int64_t)group * sz[0]) return 1;

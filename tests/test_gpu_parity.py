@@ -126,3 +126,48 @@ def test_dscnn_full_batch_independence(hip_lib):
     assert torch.equal(l, l[:1].expand_as(l))
     ref = D.forward(D.net_def("L"), p, s, R.mfcc(base, dataclasses.replace(R.FRONTEND_4020, num_mfccs=10)), False)
     assert np.abs(l[0].cpu().numpy() - ref["logits"]).max() < Cm.LOGIT_TOL
+
+
+def test_every_kernel_path_agrees(hip_lib):
+    """The alternative kernels behind the tcr_tune knobs (scalar-fed VALU convs, LDS-image MFMA convs, per-layer vs
+    whole-network fused eval kernel, front-end variants) all reproduce the default path: bit-exact where the
+    arithmetic order is identical (MFMA variants), within the logit tolerance otherwise."""
+    fx = Cm.load("tcresnet8_1.0_4020.npz")
+    arch, p, s = Cm.fixture_params(fx, "TCResNet8", 1.0)
+    fe = Cm.make_frontend(hip_lib, fx["win"], fx["hop"])
+    wav = Cm.to_dev(hip_lib, np.tile(fx["wav"], (40, 1)))          # 160 utterances: several workgroups / groups
+    labels = Cm.to_dev(hip_lib, np.tile(fx["labels"], (40, 1)))
+    net = Cm.make_net(hip_lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+    try:
+        feat0 = fe(wav).clone()
+        for v in (1, 2, 3, 4):
+            hip_lib.tcr_tune(1, v)
+            assert torch.equal(fe(wav), feat0), f"front-end variant {v}"
+        hip_lib.tcr_tune(1, 0)
+        base, _ = net.forward_infer(feat0)
+        assert np.abs(base[:4].cpu().numpy() - fx["eval_logits"]).max() < Cm.LOGIT_TOL
+        results = {}
+        for name, knobs in (("per-layer mfma", {3: 1}), ("per-layer mfma, LDS image", {3: 1, 2: 1}), ("per-layer valu", {3: 1, 0: 1}),
+                            ("fused g=3", {4: 3}), ("fused g=8", {4: 8})):
+            for k, v in knobs.items():
+                hip_lib.tcr_tune(k, v)
+            results[name] = net.forward_infer(feat0)[0].clone()
+            for k in knobs:
+                hip_lib.tcr_tune(k, 0)
+        for name, r in results.items():
+            if "valu" in name:
+                assert (r - base).abs().max() < 2e-5, name
+            else:
+                assert torch.equal(r, base), name
+        # training: MFMA vs VALU conv/dgrad paths give the same gradients up to f32 re-association
+        grads = []
+        for path in (0, 1):
+            hip_lib.tcr_tune(0, path)
+            sd = dict(p); sd.update(s); net.load_state_dict(sd)
+            net.forward_train(feat0, labels, keep_prob=0.5, seed=7)
+            grads.append(net.backward().clone())
+        hip_lib.tcr_tune(0, 0)
+        assert (grads[0] - grads[1]).abs().max() < 2e-4 * max(1.0, float(grads[0].abs().max()))
+    finally:
+        for k in range(5):
+            hip_lib.tcr_tune(k, 0)
