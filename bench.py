@@ -209,6 +209,24 @@ def main():
         out["train"] = {"value": round(world * B * tsteps / tdt, 1), "unit": "utterances/s", "ms_per_step": round(tdt / tsteps * 1e3, 4),
                         "steps": tsteps, "workload": "TCResNet8-1.0 train step: MFCC + train-mode BN fwd + bwd + momentum (wd 1e-3, keep_prob 0.5), "
                                                      "batch 4096/GPU" + (", RCCL all-reduce of the flat gradient arena" if dist_on else "")}
+        # ---------------- TCResNet14-1.5 training (configs[3]: global batch 32768 = 8 x 4096 over RCCL) ----------------
+        net14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, fe.n_frames, 12, device=dev)
+        net14.init_xavier(0)
+        dp14 = DataParallel(net14)
+
+        def train14_step():
+            step_no[0] += 1
+            f = fe(wav, out=feat)
+            dp14.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
+            dp14.backward()
+            net14.sgd_momentum_step(0.1, 0.9, 0.001)
+
+        t14 = max(4, args.steps // 4)
+        dt14 = timed(train14_step, t14, 2, dist_on)
+        out["train_tcresnet14_1.5"] = {"value": round(world * B * t14 / dt14, 1), "unit": "utterances/s", "ms_per_step": round(dt14 / t14 * 1e3, 4),
+                                       "steps": t14, "workload": f"TCResNet14-1.5 train step, batch 4096/GPU (global {world * B}), 303 144 params"
+                                                                 + (", RCCL all-reduce of the 1.21 MB gradient arena" if dist_on else "")}
+        del net14, dp14
         # ---------------- 30/10 ms front-end (98x40, the reference's training scripts) ----------------
         fe2, net2 = build("3010")
         feat2 = torch.empty((B, 40, fe2.n_frames + 8), device=dev)
