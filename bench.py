@@ -88,11 +88,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    local_rank %= max(torch.cuda.device_count(), 1)       # (lets a 1-GPU box rehearse the N > 1 control flow over gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_on = world > 1
     if dist_on:
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        backend = os.environ.get("TCR_BENCH_BACKEND", "nccl")    # "nccl" == RCCL over xGMI; "gloo" only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = args.batch
 

@@ -119,6 +119,8 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
     __shared__ float s_p[FPR * PLD];                // power (or magnitude) spectrum
     __shared__ float s_ud[FPR * 2 * (NSEG + 1)];    // per-segment up / down partial sums
     __shared__ float s_lm[NMEL * 65];               // log-mel [mel][frame], 64 frames
+    __shared__ float2 s_wud[NBINS];                 // mel slopes per bin (LDS copy: the mel loop is latency-bound on them)
+    __shared__ int s_seg[NSEG + 1];
 
     const int tid = threadIdx.x;
     const int f = tid / LPF;                // frame slot in the round
@@ -144,6 +146,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
     }
 
 #define TCR_SYNC() do { if (WSYNC) wave_sync(); else __syncthreads(); } while (0)
+    for (int i = threadIdx.x; i < NBINS; i += 256) s_wud[i] = a.wud[i];
+    for (int i = threadIdx.x; i <= NSEG; i += 256) s_seg[i] = a.seg_start[i];
+    const float2 twmid = a.tw_real[NC / 2];
+    __syncthreads();
     float2 xa[16];
     auto load_frame = [&](int rr, float2 (&dst)[16]) {
         int g = blockIdx.x * 64 + rr * FPR + f;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
                 if (SUB == 2) z = csub(E[0], O[0]);         // Z[256] = E[0] - O[0]
                 else z = E[NC / 2];
                 float plo, phi;
-                real_pair_power(z, z, a.tw_real[NC / 2], plo, phi);
+                real_pair_power(z, z, twmid, plo, phi);
                 if (a.magnitude) plo = sqrtf(plo);
                 P[NC / 2] = plo;
             }
@@ -223,11 +229,20 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
                 const int j = (i & 1) ? (i + 1) * LPF - 1 - lf : i * LPF + lf;
                 if (i * LPF >= NSEG) break;
                 if (j < NSEG) {
-                    const int k0 = a.seg_start[j], k1 = a.seg_start[j + 1];
+                    const int k0 = s_seg[j], k1 = s_seg[j + 1];
                     float up = 0.f, dn = 0.f;
-                    for (int k = k0; k < k1; ++k) {
+                    int k = k0;
+                    for (; k + 4 <= k1; k += 4) {           // 4 bins per trip: the 8 LDS reads are independent
+                        const float p0 = P[k], p1 = P[k + 1], p2 = P[k + 2], p3 = P[k + 3];
+                        const float2 w0 = s_wud[k], w1 = s_wud[k + 1], w2 = s_wud[k + 2], w3 = s_wud[k + 3];
+                        up = fmaf(w0.x, p0, up); dn = fmaf(w0.y, p0, dn);
+                        up = fmaf(w1.x, p1, up); dn = fmaf(w1.y, p1, dn);
+                        up = fmaf(w2.x, p2, up); dn = fmaf(w2.y, p2, dn);
+                        up = fmaf(w3.x, p3, up); dn = fmaf(w3.y, p3, dn);
+                    }
+                    for (; k < k1; ++k) {
                         const float p = P[k];
-                        const float2 w = a.wud[k];
+                        const float2 w = s_wud[k];
                         up = fmaf(w.x, p, up);
                         dn = fmaf(w.y, p, dn);
                     }
