@@ -26,9 +26,9 @@ def overlapped(K):
             sb.wait_event(fe_done[k]); net.forward_infer(feats[k & 1]); net_done[k].record(sb)
     torch.cuda.current_stream().wait_stream(sa); torch.cuda.current_stream().wait_stream(sb)
 
-for fv in (0, 1, 2):
-    lib.tcr_tune(1, fv)
+for fused_off in (0, 1):
+    lib.tcr_tune(3, fused_off)
     for name, fn in (("sequential", seq), ("2-stream", overlapped)):
         fn(5); torch.cuda.synchronize()
         t0 = time.perf_counter(); fn(40); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"frontend_var={fv} {name:10s}: {dt/40*1e3:.3f} ms/step  {B*40/dt/1e6:.2f} M utt/s")
+        print(f"net={('per-layer' if fused_off else 'fused')} {name:10s}: {dt/40*1e3:.3f} ms/step  {B*40/dt/1e6:.2f} M utt/s")
