@@ -229,6 +229,37 @@ def main():
                                   "net_tflops": round(world * B * dsteps / dt3 * ds_flops / 1e12 / world, 2),
                                   "workload": "DSCNNLModel eval forward, waveform->softmax, 49x10 MFCC, batch 4096/GPU"}
 
+        # ---------------- DS-CNN-L training step (configs[4], training half): Adam lr 5e-4 ----------------
+        dpd = DataParallel(ds)
+        ds_step = [0]
+
+        def train_ds():
+            ds_step[0] += 1
+            fe3(wav, out=feat3)
+            dpd.forward_train(feat3, labels)
+            dpd.backward()
+            ds.adam_step(5e-4, ds_step[0])
+
+        tds = max(3, args.steps // 6)
+        dtd = timed(train_ds, tds, 1, dist_on)
+        out["dscnn_l_train"] = {"value": round(world * B * tds / dtd, 1), "unit": "utterances/s", "ms_per_step": round(dtd / tds * 1e3, 4),
+                                "steps": tds, "net_tflops": round(B * tds / dtd * 3.0 * ds_flops / 1e12, 2),
+                                "workload": "DSCNNLModel train step: MFCC + train-mode BN fwd + bwd + Adam, batch 4096/GPU"
+                                            + (", RCCL all-reduce of the gradient arena" if dist_on else "")}
+        # ---------------- TCResNet8 training with the 30/10 ms front-end (the reference's training scripts) ----------------
+        dp2 = DataParallel(net2)
+
+        def train2_step():
+            step_no[0] += 1
+            f = fe2(wav, out=feat2)
+            dp2.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
+            dp2.backward()
+            net2.sgd_momentum_step(0.1, 0.9, 0.001)
+
+        tdt2 = timed(train2_step, tsteps, 2, dist_on)
+        out["train_3010"] = {"value": round(world * B * tsteps / tdt2, 1), "unit": "utterances/s", "ms_per_step": round(tdt2 / tsteps * 1e3, 4),
+                             "steps": tsteps, "workload": "TCResNet8-1.0 train step, 98x40 MFCC (30/10 ms), batch 4096/GPU"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

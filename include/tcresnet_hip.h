@@ -207,6 +207,19 @@ size_t tcr_dscnn_workspace_bytes(const tcr_dscnn* net, int batch);
 int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params, const float* stats, const float* feat,
                             int batch, void* workspace, size_t workspace_bytes, float* logits, float* probs, void* stream);
 
+/* Train-mode forward of DSCNN() (is_training=True: batch statistics, moving averages updated with decay 0.96 --
+ * DSCNN_arg_scope, ds_cnn.py:104-118) + softmax cross-entropy (factory/audio_nets.py:161-173); no dropout is applied
+ * in the graph (ds_cnn.py:89-101).  Arguments as tcr_net_forward_train; the workspace keeps what backward needs. */
+size_t tcr_dscnn_train_workspace_bytes(const tcr_dscnn* net, int batch);
+int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params, float* stats, const float* feat, const float* labels,
+                            int batch, int global_batch, float label_smoothing, void* workspace, size_t workspace_bytes,
+                            float* logits, float* probs, float* loss_out, void* stream);
+/* Gradient of the model loss wrt every trainable of the arena (tf.gradients inside slim.learning.create_train_op,
+ * helper/trainer.py:205-211; the reference trains DS-CNN with Adam -> tcr_adam_step).  The conv / depthwise /
+ * pointwise biases feed a train-mode BN, so their gradient is identically zero and is written as 0. */
+int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, const float* feat, int batch,
+                       void* workspace, size_t workspace_bytes, float* grads, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Optimiser (helper/trainer.py:171-197) and L2 (factory/audio_nets.py:175-182)                */
 /* ------------------------------------------------------------------------------------------ */

@@ -134,6 +134,48 @@ def make_dscnn():
         out[f"probs_{size}"] = r["probs"]
         out[f"n_params_{size}"] = sum(v.size for v in p.values())
     np.savez_compressed(os.path.join(OUT, "dscnn_4020.npz"), **out)
+    # training: 3 Adam steps (lr 5e-4, the reference's DS-CNN schedule).  S is stored in full; L keeps the small tensors.
+    # The waveform seed is the one (of 40 candidates) whose BN pre-activations stay farthest from the ReLU kink in the first
+    # step: an f32 implementation cannot be expected to land on the same side of an input within round-off (~1e-6) of 0,
+    # and one flipped mask changes that channel's gradient by O(1 / elements per channel).
+    labels = R.synth_labels(3).astype(np.float64)
+    tr = {"labels": labels, "train_lr": 5e-4, "init_seed": 0}
+    for size in ("S", "L"):
+        blocks = D.net_def(size)
+        margin, wav_seed = -1.0, None
+        for cand in range(2468, 2508):
+            p, s = D.init_params(blocks, seed=0)
+            f = D.forward(blocks, p, s, R.mfcc(R.synth_waveforms(3, seed=cand), cfg), True)
+            mg = min(np.abs(c["xhat"] + p[k + "/beta"]).min() for k, c in f["cache"].items() if isinstance(c, dict))
+            if mg > margin:
+                margin, wav_seed = mg, cand
+        assert margin > 5e-6, margin
+        x = R.mfcc(R.synth_waveforms(3, seed=wav_seed), cfg)
+        tr[f"{size}:wav_seed"] = wav_seed
+        tr[f"{size}:relu_margin"] = margin
+        m = {k: np.zeros_like(v) for k, v in p.items()}
+        v = {k: np.zeros_like(w) for k, w in p.items()}
+        keep = (lambda k: True) if size == "S" else (lambda k: ("pointwise_conv/weights" not in k) or k.startswith("DSCNN/conv_ds_3/"))
+        keep_w = (lambda k: True) if size == "S" else (lambda k: "pointwise_conv/weights" not in k)
+        for step in range(3):
+            p, s, m, v, info = D.train_step(blocks, p, s, m, v, x, labels, 5e-4, step + 1)
+            if step == 0:
+                tr[f"{size}:train_logits"] = info["logits"]
+                tr[f"{size}:train_model_loss"] = info["model_loss"]
+                for k, g in info["grads"].items():
+                    if keep(k):
+                        tr[f"{size}:grad:" + k] = g
+                for k, w in s.items():
+                    tr[f"{size}:stat1:" + k] = w
+                for k, w in p.items():
+                    if keep_w(k):
+                        tr[f"{size}:param1:" + k] = w
+        for k, w in p.items():
+            if keep_w(k):
+                tr[f"{size}:param3:" + k] = w
+        for k, w in s.items():
+            tr[f"{size}:stat3:" + k] = w
+    np.savez_compressed(os.path.join(OUT, "dscnn_train_4020.npz"), **tr)
 
 
 def main():

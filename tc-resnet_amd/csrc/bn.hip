@@ -140,7 +140,14 @@ int launch_chan_sums(const float* partial, int nchunk, int c, float* sums, hipSt
 // Returns through s_out[which * c + ch]; ends with a barrier.
 __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk, const float* sums, int nc, double* s_slices, double* s_out) {
     const int n2 = 2 * nc;
-    if (nchunk > 0) {
+    if (nchunk > 0 && n2 > (int)blockDim.x) {       // wide layers (DS-CNN, 276 channels): one thread per column, several columns each
+        for (int col = threadIdx.x; col < n2; col += blockDim.x) {
+            const int which = col / nc, ch = col - which * nc;
+            double acc = 0.0;
+            for (int k = 0; k < nchunk; ++k) acc += (double)partial[((size_t)k * 2 + which) * nc + ch];
+            s_out[col] = acc;
+        }
+    } else if (nchunk > 0) {
         const int nparts = max(1, (int)blockDim.x / n2);
         const int part = threadIdx.x / n2, col = threadIdx.x - part * n2;     // col = which * nc + ch
         if (part < nparts) {
@@ -161,7 +168,7 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk
     __syncthreads();
 }
 
-constexpr int kBnMaxC = 256;        // channels per BN layer supported by the finalize kernels
+constexpr int kBnMaxC = 512;        // channels per BN layer supported by the finalize kernels
 
 __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a) {
     __shared__ double s_slices[512];
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a
         if (var < 0.0) var = 0.0;
         const float meanf = (float)m, varf = (float)var;
         const float inv = 1.0f / sqrtf(varf + a.eps);
-        const float sc = a.gamma[c] * inv;
+        const float sc = a.gamma ? a.gamma[c] * inv : inv;         // DS-CNN: scale=False (ds_cnn.py:104-118)
         a.scale[c] = sc;
         a.shift[c] = fmaf(-meanf, sc, a.beta[c]);
         a.mean[c] = meanf;
@@ -225,8 +232,8 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const BnBwdFinaliz
     for (int c = threadIdx.x; c < a.c; c += blockDim.x) {
         const float db = (float)s_tot[c], dg = (float)s_tot[a.c + c];
         a.dbeta[c] = db * a.grad_scale;
-        a.dgamma[c] = dg * a.grad_scale;
-        a.k1[c] = a.gamma[c] * a.invstd[c];
+        if (a.dgamma) a.dgamma[c] = dg * a.grad_scale;
+        a.k1[c] = a.gamma ? a.gamma[c] * a.invstd[c] : a.invstd[c];
         a.k2[c] = (float)((double)db / a.count);
         a.k3[c] = (float)((double)a.invstd[c] * (double)dg / a.count);
     }

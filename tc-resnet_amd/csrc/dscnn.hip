@@ -1,4 +1,5 @@
-// DS-CNN (S / M / L) eval-mode forward for gfx950: the depthwise-separable baseline of BASELINE.json configs[4].
+// DS-CNN (S / M / L) for gfx950: the depthwise-separable baseline of BASELINE.json configs[4] -- eval-mode forward,
+// train-mode forward and backward.
 //
 // Replaces DSCNN() + DSCNN_arg_scope (audio_nets/ds_cnn.py:19-118): conv_1 (10x4, +bias) -> BN(no scale)+ReLU,
 // N x [depthwise 3x3 (+bias) -> BN+ReLU -> pointwise 1x1 (+bias) -> BN+ReLU], global average pool,
@@ -29,6 +30,7 @@ struct DsConv1Args {
     int npos;               // B * OH * OW
     int cout, h_in, w_in, tp_in, oh, ow, pp;
     int kh, sh, sw, pad_t, pad_l;
+    int relu;               // scale == nullptr: y = acc + shift (conv bias, train-mode raw output)
 };
 
 // D[row = co][col = (b, oh, ow)] = sum_{i < kh, j < 4} W[i][j][co] * x[oh*sh + i - pad_t][ow*sw + j - pad_l]
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256) void dscnn_conv1_kernel(const DsConv1Args a) {
             for (int reg = 0; reg < 4; ++reg) {
                 const int co = (cot0 + m) * 16 + q * 4 + reg;
                 if (co >= a.cout) continue;
-                const float v = fmaxf(fmaf(acc[m][nt][reg], a.scale[co], a.shift[co]), 0.f);
+                float v = fmaf(acc[m][nt][reg], a.scale ? a.scale[co] : 1.0f, a.shift[co]);
+                if (a.relu) v = fmaxf(v, 0.f);
                 a.y[((size_t)n * a.cout + co) * a.pp + kHalo + rem] = v;
             }
     }
@@ -99,6 +102,7 @@ struct DsDwArgs {
     float* y;               // [B][C][Ppo]
     int64_t total;          // B * C * OH * OW
     int c, h_in, w_in, ppi, oh, ow, ppo, sh, sw, pad_t, pad_l;
+    int relu;
 };
 
 __global__ __launch_bounds__(256) void dscnn_depthwise_kernel(const DsDwArgs a) {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_kernel(const DsDwArgs a) 
     float wt[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wt[k] = a.w[(size_t)k * a.c + c];
-    const float sc = a.scale[c], sh = a.shift[c];
+    const float sc = a.scale ? a.scale[c] : 1.0f, sh = a.shift[c];
     const float* xr = a.x + row * a.ppi + kHalo;
     float* yr = a.y + row * a.ppo + kHalo;
     for (int pos = lane; pos < P; pos += 64) {
@@ -128,7 +132,8 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_kernel(const DsDwArgs a) 
                 s = fmaf(wt[di * 3 + dj], xv, s);
             }
         }
-        yr[pos] = fmaxf(fmaf(s, sc, sh), 0.f);
+        const float v = fmaf(s, sc, sh);
+        yr[pos] = a.relu ? fmaxf(v, 0.f) : v;
     }
 }
 
@@ -298,7 +303,7 @@ extern "C" int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params
             DsConv1Args a;
             a.feat = feat; a.w = params + l.w_off; a.scale = ss + l.ss_off; a.shift = ss + l.ss_off + cp; a.y = buf[cur];
             a.npos = batch * P; a.cout = l.cout; a.h_in = l.h_in; a.w_in = l.w_in; a.tp_in = tcr_padded_len(l.h_in);
-            a.oh = l.oh; a.ow = l.ow; a.pp = pp; a.kh = l.kh; a.sh = l.sh; a.sw = l.sw; a.pad_t = l.pad_t; a.pad_l = l.pad_l;
+            a.oh = l.oh; a.ow = l.ow; a.pp = pp; a.kh = l.kh; a.sh = l.sh; a.sw = l.sw; a.pad_t = l.pad_t; a.pad_l = l.pad_l; a.relu = 1;
             const int tiles = ceil_div(l.cout, 16);
             const dim3 grid(ceil_div(a.npos, 256), ceil_div(tiles, 3));
             hipLaunchKernelGGL((dscnn_conv1_kernel<3>), grid, dim3(256), 0, s, a);
@@ -308,7 +313,7 @@ extern "C" int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params
             d.x = buf[cur]; d.w = params + l.w_off; d.scale = ss + l.ss_off; d.shift = ss + l.ss_off + cp; d.y = buf[cur ^ 1];
             d.total = (int64_t)batch * l.cin * P; d.c = l.cin; d.h_in = l.h_in; d.w_in = l.w_in;
             d.ppi = tcr_padded_len(l.h_in * l.w_in); d.oh = l.oh; d.ow = l.ow; d.ppo = pp;
-            d.sh = l.sh; d.sw = l.sw; d.pad_t = l.pad_t; d.pad_l = l.pad_l;
+            d.sh = l.sh; d.sw = l.sw; d.pad_t = l.pad_t; d.pad_l = l.pad_l; d.relu = 1;
             const int64_t blocks = ceil_div64((int64_t)batch * l.cin, 4);
             hipLaunchKernelGGL(dscnn_depthwise_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d);
             TCR_TRY(check_launch("dscnn_depthwise_kernel"));
@@ -331,4 +336,254 @@ extern "C" int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params
     h.batch = batch; h.c = last.cout; h.nc = net->cfg.num_classes; h.t = 1; h.tp = tcr_padded_len(1);
     h.keep_prob = 1.0f; h.inv_global_batch = 1.0f;
     return launch_head_fwd(h, false, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training (is_training=True graph of DSCNN() + tf.gradients, helper/trainer.py:199-222).
+// A "unit" is one convolution followed by its BN(no scale)+ReLU: conv_1, then (depthwise, pointwise) per block.
+// Train-mode forward keeps, per unit, the raw conv output (+bias) and the activation; backward walks the units in
+// reverse: BN backward (bn.hip) -> filter gradient -> data gradient.
+// The conv biases feed a train-mode BN, which subtracts the batch mean: their gradient is analytically zero (TF
+// computes round-off noise there) and is written as exactly 0.
+// ---------------------------------------------------------------------------------------------------------------
+namespace tcr {
+
+enum DsUnitKind { DS_CONV1 = 0, DS_DW = 1, DS_PW = 2 };
+
+struct DsUnit {
+    int kind, layer;
+    int c, P;                   // channels / output positions of this unit
+    int64_t w_off, b_off, beta_off, mean_off, var_off, ss_off;
+};
+
+static std::vector<DsUnit> ds_units(const tcr_dscnn& net) {
+    std::vector<DsUnit> u;
+    for (size_t li = 0; li < net.layers.size(); ++li) {
+        const DsLayer& l = net.layers[li];
+        const int P = l.oh * l.ow;
+        if (!l.separable) {
+            u.push_back({DS_CONV1, (int)li, l.cout, P, l.w_off, l.b_off, l.beta_off, l.mean_off, l.var_off, l.ss_off});
+        } else {
+            u.push_back({DS_DW, (int)li, l.cin, P, l.w_off, l.b_off, l.beta_off, l.mean_off, l.var_off, l.ss_off});
+            u.push_back({DS_PW, (int)li, l.cout, P, l.pw_off, l.pb_off, l.pbeta_off, l.pmean_off, l.pvar_off, l.pss_off});
+        }
+    }
+    return u;
+}
+
+struct DsTrainWs {
+    int64_t ss, kcoef, partial, pooled, dropped, dscale, dlogits, loss_utt, dpool, fc_partial, scratch, wt, ga, dz, total;
+    std::vector<int64_t> raw, act, mean, invstd;
+};
+
+static DsTrainWs ds_carve(const tcr_dscnn& net, int batch) {
+    DsTrainWs w;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t at = o; o += ds_align(n); return at; };
+    const std::vector<DsUnit> units = ds_units(net);
+    const int cp = net.c_pad, nc = net.cfg.num_classes;
+    const int cl = net.layers.back().cout;
+    w.ss = take(net.ss_floats);
+    w.kcoef = take(3 * (int64_t)cp);
+    int maxpos = 0;
+    int64_t max_act = 0, scratch = 0;
+    for (const DsUnit& u : units) {
+        const int64_t n = (int64_t)batch * u.c * tcr_padded_len(u.P);
+        w.raw.push_back(take(n));
+        w.act.push_back(take(n));
+        w.mean.push_back(take(cp));
+        w.invstd.push_back(take(cp));
+        max_act = n > max_act ? n : max_act;
+        maxpos = batch * u.P > maxpos ? batch * u.P : maxpos;
+        const DsLayer& l = net.layers[u.layer];
+        int64_t sc = 0;
+        if (u.kind == DS_CONV1) sc = (int64_t)dscnn_conv1_wgrad_partial_floats(batch, l.kh, l.cout);
+        else if (u.kind == DS_DW) sc = (int64_t)dscnn_dw_wgrad_partial_floats(batch, u.c);
+        else sc = (int64_t)wgrad_partial_floats(1, l.cin, l.cout, batch);
+        scratch = sc > scratch ? sc : scratch;
+    }
+    w.partial = take((int64_t)chan_reduce_chunks(maxpos) * 2 * cp);
+    w.pooled = take((int64_t)batch * cl * tcr_padded_len(1));
+    w.dropped = take((int64_t)batch * cl);
+    w.dscale = take((int64_t)batch * cl);
+    w.dlogits = take((int64_t)batch * nc);
+    w.loss_utt = take(batch);
+    w.dpool = take((int64_t)batch * cl);
+    w.fc_partial = take((int64_t)fc_wgrad_chunks(batch) * cl * nc);
+    w.scratch = take(scratch);
+    w.wt = take((int64_t)net.cfg.depth * net.cfg.depth);
+    w.ga = take(max_act);
+    w.dz = take(max_act);
+    w.total = o;
+    return w;
+}
+
+}  // namespace tcr
+
+extern "C" size_t tcr_dscnn_train_workspace_bytes(const tcr_dscnn* net, int batch) {
+    if (!net || batch <= 0) return 0;
+    return (size_t)ds_carve(*net, batch).total * sizeof(float);
+}
+
+extern "C" int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params, float* stats, const float* feat, const float* labels,
+                                       int batch, int global_batch, float label_smoothing, void* workspace, size_t workspace_bytes,
+                                       float* logits, float* probs, float* loss_out, void* stream) {
+    TCR_REQUIRE(net && params && stats && feat && labels && workspace && logits && probs && loss_out, "tcr_dscnn_forward_train: null argument");
+    TCR_REQUIRE(batch > 0 && global_batch >= batch, "tcr_dscnn_forward_train: batch %d / global_batch %d", batch, global_batch);
+    const DsTrainWs w = ds_carve(*net, batch);
+    if ((size_t)w.total * sizeof(float) > workspace_bytes) {
+        set_error("tcr_dscnn_forward_train: workspace %zu bytes < required %zu", workspace_bytes, (size_t)w.total * sizeof(float));
+        return TCR_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* base = static_cast<float*>(workspace);
+    const std::vector<DsUnit> units = ds_units(*net);
+    const int cp = net->c_pad;
+    const float* x = nullptr;               // activation feeding the current unit (nullptr: the features)
+    for (size_t ui = 0; ui < units.size(); ++ui) {
+        const DsUnit& u = units[ui];
+        const DsLayer& l = net->layers[u.layer];
+        const int pp = tcr_padded_len(u.P);
+        float* raw = base + w.raw[ui];
+        if (u.kind == DS_CONV1) {
+            DsConv1Args a;
+            a.feat = feat; a.w = params + u.w_off; a.scale = nullptr; a.shift = params + u.b_off; a.y = raw;
+            a.npos = batch * u.P; a.cout = l.cout; a.h_in = l.h_in; a.w_in = l.w_in; a.tp_in = tcr_padded_len(l.h_in);
+            a.oh = l.oh; a.ow = l.ow; a.pp = pp; a.kh = l.kh; a.sh = l.sh; a.sw = l.sw; a.pad_t = l.pad_t; a.pad_l = l.pad_l; a.relu = 0;
+            const int tiles = ceil_div(l.cout, 16);
+            hipLaunchKernelGGL((dscnn_conv1_kernel<3>), dim3(ceil_div(a.npos, 256), ceil_div(tiles, 3)), dim3(256), 0, s, a);
+            TCR_TRY(check_launch("dscnn_conv1_kernel"));
+        } else if (u.kind == DS_DW) {
+            DsDwArgs d;
+            d.x = x; d.w = params + u.w_off; d.scale = nullptr; d.shift = params + u.b_off; d.y = raw;
+            d.total = (int64_t)batch * l.cin * u.P; d.c = l.cin; d.h_in = l.h_in; d.w_in = l.w_in;
+            d.ppi = tcr_padded_len(l.h_in * l.w_in); d.oh = l.oh; d.ow = l.ow; d.ppo = pp;
+            d.sh = l.sh; d.sw = l.sw; d.pad_t = l.pad_t; d.pad_l = l.pad_l; d.relu = 0;
+            hipLaunchKernelGGL(dscnn_depthwise_kernel, dim3((unsigned)ceil_div64((int64_t)batch * l.cin, 4)), dim3(256), 0, s, d);
+            TCR_TRY(check_launch("dscnn_depthwise_kernel"));
+        } else {
+            Conv1x1Args c1;
+            c1.x = x; c1.w = params + u.w_off; c1.y = raw; c1.scale = nullptr; c1.shift = params + u.b_off;
+            c1.npos = batch * u.P; c1.cin = l.cin; c1.cout = l.cout; c1.tpi = pp; c1.tout = u.P; c1.tpo = pp; c1.stride = 1; c1.relu = 0;
+            TCR_TRY(launch_conv1x1(c1, MF_AFFINE, s));
+        }
+        // batch statistics -> scale/shift (+ moving averages), normalise + ReLU
+        ChanReduceArgs r;
+        std::memset(&r, 0, sizeof(r));
+        r.y = raw; r.partial = base + w.partial; r.npos = batch * u.P; r.c = u.c; r.t = u.P; r.tp = pp;
+        int nchunk = 0;
+        TCR_TRY(launch_chan_reduce(0, r, &nchunk, s));
+        float* ss = base + w.ss + u.ss_off;
+        BnFinalizeArgs f;
+        f.partial = base + w.partial; f.nchunk = nchunk; f.sums = nullptr;
+        f.gamma = nullptr; f.beta = params + u.beta_off;
+        f.moving_mean = stats + u.mean_off; f.moving_var = stats + u.var_off;
+        f.scale = ss; f.shift = ss + cp; f.mean = base + w.mean[ui]; f.invstd = base + w.invstd[ui];
+        f.c = u.c; f.count = (double)batch * (double)u.P; f.decay = net->cfg.bn_decay; f.eps = net->cfg.bn_eps;
+        TCR_TRY(launch_bn_finalize(f, s));
+        BnApplyArgs ap;
+        ap.y = raw; ap.scale = ss; ap.shift = ss + cp; ap.res = nullptr; ap.out = base + w.act[ui];
+        ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.relu = 1;
+        TCR_TRY(launch_bn_apply(ap, s));
+        x = base + w.act[ui];
+    }
+    const DsLayer& last = net->layers.back();
+    const int P = last.oh * last.ow;
+    const int64_t rows = (int64_t)batch * last.cout;
+    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, s, x, base + w.pooled, rows, P, tcr_padded_len(P));
+    TCR_TRY(check_launch("plane_mean_kernel"));
+    HeadArgs h;
+    std::memset(&h, 0, sizeof(h));
+    h.feat = base + w.pooled; h.wfc = params + net->fcw_off; h.wfc2 = nullptr; h.bias = params + net->fcb_off;
+    h.labels = labels; h.logits = logits; h.probs = probs; h.ranges = nullptr;
+    h.dropped = base + w.dropped; h.dscale = base + w.dscale; h.dlogits = base + w.dlogits; h.loss_utt = base + w.loss_utt;
+    h.batch = batch; h.c = last.cout; h.nc = net->cfg.num_classes; h.t = 1; h.tp = tcr_padded_len(1);
+    h.keep_prob = 1.0f;                                     // slim.dropout is arg-scoped but never called (ds_cnn.py:89-101)
+    h.inv_global_batch = 1.0f / (float)global_batch; h.label_smoothing = label_smoothing;
+    h.pool_scale = 1.0f / (float)P;
+    TCR_TRY(launch_head_fwd(h, true, s));
+    return launch_sum_vector(base + w.loss_utt, batch, loss_out, s);
+}
+
+extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, const float* feat, int batch,
+                                  void* workspace, size_t workspace_bytes, float* grads, void* stream) {
+    TCR_REQUIRE(net && params && feat && workspace && grads, "tcr_dscnn_backward: null argument");
+    TCR_REQUIRE(batch > 0, "tcr_dscnn_backward: batch must be positive (got %d)", batch);
+    const DsTrainWs w = ds_carve(*net, batch);
+    if ((size_t)w.total * sizeof(float) > workspace_bytes) {
+        set_error("tcr_dscnn_backward: workspace %zu bytes < required %zu", workspace_bytes, (size_t)w.total * sizeof(float));
+        return TCR_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* base = static_cast<float*>(workspace);
+    const std::vector<DsUnit> units = ds_units(*net);
+    const int cp = net->c_pad, nc = net->cfg.num_classes;
+    const int cl = net->layers.back().cout;
+    // zero the arena: padding and the conv biases (exactly-zero gradient, see above)
+    if (hipMemsetAsync(grads, 0, (size_t)net->param_floats * sizeof(float), s) != hipSuccess) {
+        set_error("tcr_dscnn_backward: hipMemsetAsync failed");
+        return TCR_ERR_HIP;
+    }
+    TCR_TRY(launch_fc_wgrad(base + w.dropped, base + w.dlogits, base + w.fc_partial, grads + net->fcw_off, batch, cl, nc, s));
+    TCR_TRY(launch_bias_grad(base + w.dlogits, batch, nc, grads + net->fcb_off, s));
+    TCR_TRY(launch_head_bwd(base + w.dlogits, params + net->fcw_off, base + w.dscale, base + w.dpool, batch, cl, nc, s));
+
+    const float* da = base + w.dpool;       // gradient wrt the current unit's activation
+    int bcast = 1;                          // ([B][C] broadcast over the map for the last unit: average-pool backward)
+    float* ga = base + w.ga;
+    float* dz = base + w.dz;
+    float* kc = base + w.kcoef;
+    for (int ui = (int)units.size() - 1; ui >= 0; --ui) {
+        const DsUnit& u = units[ui];
+        const DsLayer& l = net->layers[u.layer];
+        const int pp = tcr_padded_len(u.P);
+        const float* raw = base + w.raw[ui];
+        const float* act = base + w.act[ui];
+        ChanReduceArgs r;
+        std::memset(&r, 0, sizeof(r));
+        r.y = raw; r.da = da; r.m1 = act; r.m2 = nullptr; r.mean = base + w.mean[ui]; r.invstd = base + w.invstd[ui];
+        r.partial = base + w.partial; r.npos = batch * u.P; r.c = u.c; r.t = u.P; r.tp = pp; r.bcast = bcast;
+        int nchunk = 0;
+        TCR_TRY(launch_chan_reduce(1, r, &nchunk, s));
+        BnBwdFinalizeArgs f;
+        f.partial = base + w.partial; f.nchunk = nchunk; f.sums = nullptr; f.gamma = nullptr; f.invstd = base + w.invstd[ui];
+        f.dgamma = nullptr; f.dbeta = grads + u.beta_off;
+        f.k1 = kc; f.k2 = kc + cp; f.k3 = kc + 2 * cp;
+        f.c = u.c; f.count = (double)batch * (double)u.P; f.grad_scale = 1.0f;
+        TCR_TRY(launch_bn_bwd_finalize(f, s));
+        BnBwdApplyArgs ap;
+        ap.y = raw; ap.da = da; ap.m1 = act; ap.m2 = nullptr; ap.mean = base + w.mean[ui];
+        ap.k1 = f.k1; ap.k2 = f.k2; ap.k3 = f.k3; ap.dy = dz;
+        ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.bcast = bcast;
+        TCR_TRY(launch_bn_bwd_apply(ap, s));
+        const float* xin = ui > 0 ? base + w.act[ui - 1] : nullptr;
+        if (u.kind == DS_PW) {
+            TCR_TRY(launch_conv_wgrad(1, 1, 0, xin, dz, grads + u.w_off, base + w.scratch, batch, l.cin, l.cout, pp, u.P, pp, s));
+            TCR_TRY(launch_transpose_weights(params + u.w_off, base + w.wt, 1, l.cin, l.cout, s));
+            Conv1x1Args c1;
+            c1.x = dz; c1.w = base + w.wt; c1.y = ga; c1.scale = nullptr; c1.shift = nullptr;
+            c1.npos = batch * u.P; c1.cin = l.cout; c1.cout = l.cin; c1.tpi = pp; c1.tout = u.P; c1.tpo = pp; c1.stride = 1; c1.relu = 0;
+            TCR_TRY(launch_conv1x1(c1, MF_RAW, s));
+        } else if (u.kind == DS_DW) {
+            const int ppi = tcr_padded_len(l.h_in * l.w_in);
+            DsDwWgradArgs g;
+            g.x = xin; g.dz = dz; g.partial = base + w.scratch; g.batch = batch; g.c = u.c; g.h_in = l.h_in; g.w_in = l.w_in; g.ppi = ppi;
+            g.oh = l.oh; g.ow = l.ow; g.ppo = pp; g.sh = l.sh; g.sw = l.sw; g.pad_t = l.pad_t; g.pad_l = l.pad_l; g.utt_per_block = 0;
+            TCR_TRY(launch_dscnn_dw_wgrad(g, grads + u.w_off, s));
+            DsDwBwdArgs d;
+            d.dz = dz; d.w = params + u.w_off; d.dx = ga; d.planes = (int64_t)batch * u.c; d.c = u.c; d.h_in = l.h_in; d.w_in = l.w_in;
+            d.ppi = ppi; d.oh = l.oh; d.ow = l.ow; d.ppo = pp; d.sh = l.sh; d.sw = l.sw; d.pad_t = l.pad_t; d.pad_l = l.pad_l;
+            TCR_TRY(launch_dscnn_dw_dgrad(d, s));
+        } else {
+            DsConv1WgradArgs g;
+            std::memset(&g, 0, sizeof(g));
+            g.feat = feat; g.dz = dz; g.partial = base + w.scratch; g.batch = batch; g.cout = l.cout;
+            g.h_in = l.h_in; g.w_in = l.w_in; g.tp_in = tcr_padded_len(l.h_in); g.oh = l.oh; g.ow = l.ow; g.pp = pp;
+            g.kh = l.kh; g.sh = l.sh; g.sw = l.sw; g.pad_t = l.pad_t; g.pad_l = l.pad_l;
+            TCR_TRY(launch_dscnn_conv1_wgrad(g, grads + u.w_off, s));
+        }
+        da = ga;
+        bcast = 0;
+    }
+    return TCR_OK;
 }

@@ -1,0 +1,205 @@
+// Backward kernels of DS-CNN (audio_nets/ds_cnn.py:46-101 under tf.gradients, helper/trainer.py:205-211):
+//   * depthwise 3x3: data gradient (transposed stencil) and filter gradient (9 sums per channel over batch x map)
+//   * conv_1 (10x4, one input channel): filter gradient as a [taps] x [positions] x [Cout] contraction on the
+//     exact-f32 MFMA -- the reduction index (positions) is the MFMA k dimension.
+// The pointwise 1x1 convolutions reuse the matrix-core kernels of mfma.hip (data gradient = 1x1 conv with the
+// transposed weight, filter gradient = conv_wgrad_mfma_kernel<1, .>); BN reuses bn.hip.
+// Every cross-workgroup sum goes through per-workgroup partial slabs added in a FIXED order (bitwise reproducible).
+#include "kernels.h"
+
+namespace tcr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// dx[h][w] = sum_{di,dj} W[di][dj] * dz[(h + pad_t - di) / sh][(w + pad_l - dj) / sw]  over taps that divide evenly.
+// One wavefront per (utterance, channel) plane; the 9 taps are wave-uniform.
+__global__ __launch_bounds__(256) void dscnn_dw_dgrad_kernel(const DsDwBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.planes) return;
+    const int c = (int)(row % a.c);
+    float wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = a.w[(size_t)k * a.c + c];
+    const float* dz = a.dz + row * a.ppo + kHalo;
+    float* dx = a.dx + row * a.ppi + kHalo;
+    const int pin = a.h_in * a.w_in;
+    for (int pos = lane; pos < pin; pos += 64) {
+        const int h = pos / a.w_in, w = pos - h * a.w_in;
+        float s = 0.f;
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const int hh = h + a.pad_t - di;
+            const int oh = hh / a.sh;
+            const bool hv = hh >= 0 && oh * a.sh == hh && oh < a.oh;
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const int ww = w + a.pad_l - dj;
+                const int ow = ww / a.sw;
+                const bool v = hv && ww >= 0 && ow * a.sw == ww && ow < a.ow;
+                const float g = v ? dz[oh * a.ow + ow] : 0.f;
+                s = fmaf(wt[di * 3 + dj], g, s);
+            }
+        }
+        dx[pos] = s;
+    }
+}
+
+int launch_dscnn_dw_dgrad(const DsDwBwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(dscnn_dw_dgrad_kernel, dim3((unsigned)ceil_div64(a.planes, 4)), dim3(256), 0, s, a);
+    return check_launch("dscnn_dw_dgrad_kernel");
+}
+
+// partial[chunk][tap][c] = sum_{n in chunk, oh, ow} x[n][c][oh*sh + di - pad_t][ow*sw + dj - pad_l] * dz[n][c][oh][ow]
+// One wavefront per (chunk of utterances, channel); lanes walk the flattened (utterance, position) index.
+__global__ __launch_bounds__(256) void dscnn_dw_wgrad_kernel(const DsDwWgradArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= a.c) return;
+    const int n0 = blockIdx.x * a.utt_per_block;
+    const int cnt = min(a.utt_per_block, a.batch - n0);
+    const int P = a.oh * a.ow;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    for (int idx = lane; idx < cnt * P; idx += 64) {
+        const int dn = idx / P, pos = idx - dn * P;
+        const int oh = pos / a.ow, ow = pos - oh * a.ow;
+        const size_t plane = (size_t)(n0 + dn) * a.c + c;
+        const float g = a.dz[plane * a.ppo + kHalo + pos];
+        const float* xr = a.x + plane * a.ppi + kHalo;
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const int h = oh * a.sh + di - a.pad_t;
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const int w = ow * a.sw + dj - a.pad_l;
+                const float xv = (h >= 0 && h < a.h_in && w >= 0 && w < a.w_in) ? xr[h * a.w_in + w] : 0.f;
+                acc[di * 3 + dj] = fmaf(xv, g, acc[di * 3 + dj]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) a.partial[((size_t)blockIdx.x * 9 + k) * a.c + c] = v;
+    }
+}
+
+static int dw_wgrad_chunks(int batch) {
+    int n = ceil_div(batch, 32);
+    if (n > 128) n = 128;
+    return n < 1 ? 1 : n;
+}
+
+size_t dscnn_dw_wgrad_partial_floats(int batch, int c) { return (size_t)dw_wgrad_chunks(batch) * 9 * c; }
+
+int launch_dscnn_dw_wgrad(DsDwWgradArgs a, float* dw, hipStream_t s) {
+    a.utt_per_block = ceil_div(a.batch, dw_wgrad_chunks(a.batch));
+    const dim3 grid(ceil_div(a.batch, a.utt_per_block), ceil_div(a.c, 4));
+    hipLaunchKernelGGL(dscnn_dw_wgrad_kernel, grid, dim3(256), 0, s, a);
+    TCR_TRY(check_launch("dscnn_dw_wgrad_kernel"));
+    // dw[tap][c] = sum_chunk partial[chunk][tap][c]: the reduction kernel of mfma.hip with k = 9 taps, Cin = 1, Cout = C
+    return launch_wgrad_reduce(a.partial, dw, (int)grid.x, 9, 1, a.c, 1, a.c, a.c, 0, s);
+}
+
+// conv_1 filter gradient: dW[i][j][co] = sum_{n,oh,ow} feat[n][ow*sw + j - pad_l][oh*sh + i - pad_t] * dz[n][co][oh][ow].
+// A = feature patches (tap tile x 4 positions, gathered from the small L1/L2-resident feature map), B = dz
+// (4 positions x 16 output channels), D = [tap][co].  A wave owns all tap tiles (3 x 16 >= 10 x 4) and NCO
+// channel tiles, so dz -- the large operand -- is read exactly once; workgroups split the batch (split-K).
+template <int NCO>
+__global__ __launch_bounds__(256) void dscnn_conv1_wgrad_kernel(const DsConv1WgradArgs a) {
+    constexpr int MT = 3;
+    __shared__ float s_acc[MT * 16 * NCO * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int co0 = blockIdx.y * NCO * 16;
+
+    f32x4 acc[MT][NCO];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int m = 0; m < NCO; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int ti[MT], tj[MT];
+    bool tv[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int tap = t * 16 + r;
+        tv[t] = tap < a.taps;
+        ti[t] = tap >> 2;               // kernel row  (kw == 4)
+        tj[t] = tap & 3;                // kernel column
+    }
+    bool cov[NCO];
+    int coc[NCO];
+#pragma unroll
+    for (int m = 0; m < NCO; ++m) {
+        const int co = co0 + m * 16 + r;
+        cov[m] = co < a.cout;
+        coc[m] = cov[m] ? co : 0;
+    }
+    const int n_begin = blockIdx.x * a.utt_per_block;
+    const int n_end = min(n_begin + a.utt_per_block, a.batch);
+    for (int n = n_begin + wave; n < n_end; n += 4) {
+        const float* fr = a.feat + (size_t)n * a.w_in * a.tp_in + kHalo;
+        const float* dr = a.dz + (size_t)n * a.cout * a.pp + kHalo;
+        for (int oh = 0; oh < a.oh; ++oh) {
+            for (int ow0 = 0; ow0 < a.ow; ow0 += 4) {
+                const int ow = ow0 + q;
+                const bool pv = ow < a.ow;
+                float bf[NCO], af[MT];
+#pragma unroll
+                for (int m = 0; m < NCO; ++m) bf[m] = (pv && cov[m]) ? dr[(size_t)coc[m] * a.pp + oh * a.ow + ow] : 0.f;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const int h = oh * a.sh + ti[t] - a.pad_t;
+                    const int wc = ow * a.sw + tj[t] - a.pad_l;
+                    const bool v = pv && tv[t] && h >= 0 && h < a.h_in && wc >= 0 && wc < a.w_in;
+                    af[t] = v ? fr[(size_t)wc * a.tp_in + h] : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int m = 0; m < NCO; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bf[m], acc[t][m], 0, 0, 0);
+            }
+        }
+    }
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int m = 0; m < NCO; ++m)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int idx = ((t * 16 + q * 4 + reg) * NCO + m) * 16 + r;
+                        if (wv == 0) s_acc[idx] = acc[t][m][reg];
+                        else s_acc[idx] += acc[t][m][reg];
+                    }
+        }
+        __syncthreads();
+    }
+    float* dst = a.partial + (size_t)blockIdx.x * a.taps_pad * a.cout_pad;
+    for (int i = threadIdx.x; i < MT * 16 * NCO * 16; i += 256) {
+        const int col = i % (NCO * 16), tap = i / (NCO * 16);
+        if (tap < a.taps_pad && co0 + col < a.cout_pad) dst[(size_t)tap * a.cout_pad + co0 + col] = s_acc[i];
+    }
+}
+
+size_t dscnn_conv1_wgrad_partial_floats(int batch, int kh, int cout) {
+    return (size_t)wgrad_chunks(batch) * (size_t)(ceil_div(kh * 4, 16) * 16) * (size_t)(ceil_div(cout, 16) * 16);
+}
+
+int launch_dscnn_conv1_wgrad(DsConv1WgradArgs a, float* dw, hipStream_t s) {
+    a.taps = a.kh * 4;
+    a.taps_pad = ceil_div(a.taps, 16) * 16;
+    a.cout_pad = ceil_div(a.cout, 16) * 16;
+    if (a.taps_pad > 48) { set_error("conv_1 wgrad: %d x 4 kernel exceeds the 48-tap tile", a.kh); return TCR_ERR_ARG; }
+    a.utt_per_block = ceil_div(a.batch, wgrad_chunks(a.batch));
+    const dim3 grid(ceil_div(a.batch, a.utt_per_block), ceil_div(a.cout_pad / 16, 2));
+    hipLaunchKernelGGL((dscnn_conv1_wgrad_kernel<2>), grid, dim3(256), 0, s, a);
+    TCR_TRY(check_launch("dscnn_conv1_wgrad_kernel"));
+    // dW[tap][0][co]: k = 1, "Cin" = taps
+    return launch_wgrad_reduce(a.partial, dw, (int)grid.x, 1, a.taps, a.cout, a.taps_pad, a.cout_pad, a.cout, 0, s);
+}
+
+}  // namespace tcr

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
         for (int t = 0; t < a.t; ++t) sum += row[t];
         float pooled = sum / (float)a.t;                                    // tc_resnet.py:43
         if (TRAIN) {
-            float ds = 1.0f / (float)a.t;
+            float ds = a.pool_scale > 0.f ? a.pool_scale : 1.0f / (float)a.t;     // d(pooled)/d(position)
             if (a.keep_prob < 1.0f) {                                       // tf.nn.dropout: div(x, keep_prob) * mask
                 const float rnd = uniform01(a.seed, (uint64_t)(a.sample_offset + n) * (uint64_t)a.c + (uint64_t)cc);
                 const bool keep = rnd < a.keep_prob;
@@ -193,6 +193,31 @@ int launch_fc_wgrad(const float* dropped, const float* dlogits, float* partial, 
     TCR_TRY(check_launch("fc_wgrad_kernel"));
     hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(c * nc, 256)), dim3(256), 0, s, (const float*)partial, grid, c * nc, dw);
     return check_launch("sum_partials_kernel");
+}
+
+// db[o] = sum_b dlogits[b][o]   (bias gradient of slim.fully_connected, ds_cnn.py:99; single workgroup, double
+// accumulation: 16 interleaved batch slices per class, added in a fixed order)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dlogits, int batch, int nc, float* __restrict__ db) {
+    __shared__ double s_part[16][64];
+    for (int o0 = 0; o0 < nc; o0 += 16) {
+        const int o = o0 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+        double s = 0.0;
+        if (o < nc)
+            for (int b = part; b < batch; b += 16) s += (double)dlogits[(size_t)b * nc + o];
+        s_part[part][threadIdx.x & 15] = s;
+        __syncthreads();
+        if (threadIdx.x < 16 && o0 + threadIdx.x < nc) {
+            double tot = 0.0;
+            for (int k = 0; k < 16; ++k) tot += s_part[k][threadIdx.x];
+            db[o0 + threadIdx.x] = (float)tot;
+        }
+        __syncthreads();
+    }
+}
+
+int launch_bias_grad(const float* dlogits, int batch, int nc, float* db, hipStream_t s) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(1), dim3(256), 0, s, dlogits, batch, nc, db);
+    return check_launch("bias_grad_kernel");
 }
 
 // out[0] = sum_i in[i]   (single workgroup, double accumulation, fixed order)

@@ -69,6 +69,9 @@ int launch_conv_dgrad_mfma(int k, int stride, int pad_lo, const float* w, float*
 int launch_conv_mfma_with_down(const ConvArgs& a, const float* w_down, float* y_down, const float* scale_down,
                                const float* shift_down, int pad_lo, int epi, hipStream_t s);
 size_t wgrad_partial_floats(int k, int cin, int cout, int batch);
+int wgrad_chunks(int batch);
+int launch_wgrad_reduce(const float* partial, float* dw, int nchunk, int k, int cin, int cout, int cin_pad, int cout_pad,
+                        int cout_all, int co_base, hipStream_t s);
 int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
                       int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s);
 
@@ -217,6 +220,7 @@ struct HeadArgs {
     int64_t sample_offset;
     float inv_global_batch;
     float label_smoothing;
+    float pool_scale;           // (train) overrides 1/t in dscale when feat is an already pooled [B][C] map (DS-CNN), or 0
 };
 
 int launch_head_fwd(const HeadArgs& a, bool train, hipStream_t s);
@@ -224,5 +228,37 @@ int launch_head_bwd(const float* dlogits, const float* wfc, const float* dscale,
 int fc_wgrad_chunks(int batch);
 int launch_fc_wgrad(const float* dropped, const float* dlogits, float* partial, float* dw, int batch, int c, int nc, hipStream_t s);
 int launch_sum_vector(const float* in, int n, float* out, hipStream_t s);
+int launch_bias_grad(const float* dlogits, int batch, int nc, float* db, hipStream_t s);
+
+// ---- dscnn_bwd.hip : backward kernels of the depthwise-separable baseline ----------------------
+struct DsDwBwdArgs {
+    const float* dz;        // [B][C][Ppo] gradient wrt the depthwise conv output
+    const float* w;         // [3][3][C][1]
+    float* dx;              // [B][C][Ppi]
+    int64_t planes;         // B * C
+    int c, h_in, w_in, ppi, oh, ow, ppo, sh, sw, pad_t, pad_l;
+};
+int launch_dscnn_dw_dgrad(const DsDwBwdArgs& a, hipStream_t s);
+
+struct DsDwWgradArgs {
+    const float* x;         // [B][C][Ppi] input of the depthwise conv
+    const float* dz;        // [B][C][Ppo]
+    float* partial;         // [nchunk][9][C]
+    int batch, c, h_in, w_in, ppi, oh, ow, ppo, sh, sw, pad_t, pad_l;
+    int utt_per_block;
+};
+size_t dscnn_dw_wgrad_partial_floats(int batch, int c);
+int launch_dscnn_dw_wgrad(DsDwWgradArgs a, float* dw, hipStream_t s);
+
+struct DsConv1WgradArgs {
+    const float* feat;      // [B][W_in][Tp_in] front-end planar features
+    const float* dz;        // [B][Cout][Pp]
+    float* partial;         // [nchunk][taps_pad][Cout_pad]
+    int batch, cout, cout_pad, taps, taps_pad;
+    int h_in, w_in, tp_in, oh, ow, pp, kh, sh, sw, pad_t, pad_l;
+    int utt_per_block;
+};
+size_t dscnn_conv1_wgrad_partial_floats(int batch, int kh, int cout);
+int launch_dscnn_conv1_wgrad(DsConv1WgradArgs a, float* dw, hipStream_t s);
 
 }  // namespace tcr

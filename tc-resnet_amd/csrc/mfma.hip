@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
                 if (co >= a.cout) continue;
                 float v = acc[m][nt][reg];
                 if (EPI == MF_AFFINE) {
-                    v = fmaf(v, a.scale[co], a.shift[co]);
+                    v = fmaf(v, a.scale ? a.scale[co] : 1.0f, a.shift[co]);    // (scale == nullptr: conv bias only)
                     if (a.relu) v = fmaxf(v, 0.f);
                 }
                 float* o = a.y + ((size_t)n * a.cout + co) * a.tpo + kHalo + t;
@@ -511,6 +511,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (live && part == 0) dw[((size_t)j * cin + ci) * cout_all + co_base + co] = s;
 }
 
+int launch_wgrad_reduce(const float* partial, float* dw, int nchunk, int k, int cin, int cout, int cin_pad, int cout_pad,
+                        int cout_all, int co_base, hipStream_t s) {
+    const int total = k * cin * cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total * 4, 256)), dim3(256), 0, s, partial, dw, nchunk, k, cin, cout, cin_pad,
+                       cout_pad, cout_all, co_base);
+    return check_launch("wgrad_reduce_kernel");
+}
+
 int wgrad_chunks(int batch) {
     int n = ceil_div(batch, 16);        // >= 16 utterances (4 per wave) per workgroup
     if (n > 128) n = 128;
@@ -562,10 +570,7 @@ int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float
         else if (k == 3) rc = launch_wgrad_k<3>(a, nco, grid, s);
         else rc = launch_wgrad_k<1>(a, nco, grid, s);
         TCR_TRY(rc);
-        const int total = k * cin * a.cout;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total * 4, 256)), dim3(256), 0, s, (const float*)scratch, dw,
-                           (int)grid.x, k, cin, a.cout, a.cin_pad, a.cout_pad, cout, co_base);
-        TCR_TRY(check_launch("wgrad_reduce_kernel"));
+        TCR_TRY(launch_wgrad_reduce(scratch, dw, (int)grid.x, k, cin, a.cout, a.cin_pad, a.cout_pad, cout, co_base, s));
     }
     return TCR_OK;
 }

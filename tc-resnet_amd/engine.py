@@ -340,7 +340,7 @@ class TCResNet(_Base):
 
 
 class DSCNN(_Base):
-    """DS-CNN S / M / L, eval-mode forward (audio_nets/ds_cnn.py:19-118 of the reference)."""
+    """DS-CNN S / M / L: eval forward, train forward / backward, Adam (audio_nets/ds_cnn.py:19-118 of the reference)."""
 
     NET_DEFS = {            # depth, separable blocks, conv_1 stride, conv_ds_1 stride  (ds_cnn.py:19-43)
         "S": (64, 4, (2, 2), (1, 1)),
@@ -368,7 +368,10 @@ class DSCNN(_Base):
             self.tensors[ti.name.decode()] = ti
         self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
         self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.slots: Dict[str, torch.Tensor] = {}
         self._ws: Dict[int, torch.Tensor] = {}
+        self._train_ws: Dict[int, torch.Tensor] = {}
         for n, ti in self.tensors.items():
             if ti.kind == 4:
                 self._view(n).fill_(1.0)
@@ -382,8 +385,13 @@ class DSCNN(_Base):
             pass
 
     _view = TCResNet._view
+    grad_view = TCResNet.grad_view
+    trainable_names = TCResNet.trainable_names
     state_dict = TCResNet.state_dict
     load_state_dict = TCResNet.load_state_dict
+    _slot = TCResNet._slot
+    adam_step = TCResNet.adam_step
+    sgd_momentum_step = TCResNet.sgd_momentum_step
 
     def total_params(self) -> int:
         return sum(int(ti.size) for ti in self.tensors.values() if ti.arena == 0)
@@ -402,11 +410,50 @@ class DSCNN(_Base):
             lim = math.sqrt(6.0 / (fan_in + fan_out))
             self._view(n).copy_(((torch.rand(shape, generator=gen) * 2.0 - 1.0) * lim).to(self.device))
 
-    def forward_infer(self, feat: torch.Tensor):
+    def _check_feat(self, feat: torch.Tensor):
         self._check_tensor(feat, "features")
         want = (self.w_in, padded_len(self.h_in))
         if feat.dim() != 3 or tuple(feat.shape[1:]) != want:
             raise TcrError(f"features must be planar [B, {want[0]}, {want[1]}], got {tuple(feat.shape)}")
+
+    def train_workspace(self, batch: int) -> torch.Tensor:
+        ws = self._train_ws.get(batch)
+        if ws is None:
+            nbytes = self.lib.tcr_dscnn_train_workspace_bytes(self._h, batch)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            self._train_ws[batch] = ws
+        return ws
+
+    def forward_train(self, feat: torch.Tensor, labels: torch.Tensor, global_batch: Optional[int] = None,
+                      label_smoothing: float = 0.0, **_unused):
+        """Train-mode forward (batch statistics, moving averages updated).  Returns (logits, probs, loss_sum) like
+        TCResNet.forward_train; the graph applies no dropout (ds_cnn.py:89-101), so keep_prob / seed are ignored."""
+        if _unused.get("sync_hook") is not None:
+            raise NotImplementedError("cross-replica BN statistics are built for TC-ResNet only; DS-CNN replicas use per-replica BN")
+        self._check_feat(feat)
+        self._check_tensor(labels, "labels")
+        b = feat.shape[0]
+        ws = self.train_workspace(b)
+        logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
+        probs = torch.empty_like(logits)
+        loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self.lib.check(self.lib.tcr_dscnn_forward_train(self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(),
+                                                        labels.data_ptr(), b, int(global_batch or b), float(label_smoothing),
+                                                        ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(),
+                                                        loss.data_ptr(), self._stream()), "tcr_dscnn_forward_train")
+        self._last = (feat, b)
+        return logits, probs, loss[0]
+
+    def backward(self) -> torch.Tensor:
+        """Gradient of the mean cross-entropy wrt every trainable, into self.grads."""
+        feat, b = self._last
+        ws = self.train_workspace(b)
+        self.lib.check(self.lib.tcr_dscnn_backward(self._h, self.params.data_ptr(), feat.data_ptr(), b, ws.data_ptr(),
+                                                   ws.numel() * 4, self.grads.data_ptr(), self._stream()), "tcr_dscnn_backward")
+        return self.grads
+
+    def forward_infer(self, feat: torch.Tensor):
+        self._check_feat(feat)
         b = feat.shape[0]
         ws = self._ws.get(b)
         if ws is None:

@@ -192,8 +192,8 @@ class TCResNet14Model(_TCResNetModel):
 
 
 class _DSCNNModel(AudioNetModel):
-    """DS-CNN S / M / L (factory/audio_nets.py:299-359 of the reference): eval-mode build on the HIP kernels.
-    The training kernels of this family (BN without scale, biases, Adam) are not built yet."""
+    """DS-CNN S / M / L (factory/audio_nets.py:299-359 of the reference) on the HIP kernels: eval-mode and training
+    builds (BN without scale, conv biases; the reference's scripts train this family with --optimizer adam)."""
     size = None
 
     @staticmethod
@@ -202,8 +202,6 @@ class _DSCNNModel(AudioNetModel):
 
     def build_inference(self, inputs, is_training):
         from ..engine import DSCNN
-        if is_training:
-            raise NotImplementedError("DS-CNN training (train-mode BN / backward / Adam) is not built yet; eval-mode forward is")
         key = ("DSCNN", self.size, int(inputs.shape[1]), int(inputs.shape[2]), self.args.num_classes, id(runtime.default_lib()))
         eng = tc_resnet._engines.get(key)
         if eng is None:
@@ -213,6 +211,14 @@ class _DSCNNModel(AudioNetModel):
             tc_resnet._engines[key] = eng
         self.engine = eng
         self._loss_sum = None
+        if is_training:     # read-only build of the training graph (see _TCResNetModel.build_inference)
+            planar = self._preprocessor.planar
+            saved = eng.stats.clone()
+            logits, probs, loss_sum = eng.forward_train(planar, self.labels, label_smoothing=float(getattr(self.args, "label_smoothing", 0.0)))
+            eng.stats.copy_(saved)
+            self._loss_sum, self._mean_loss = loss_sum, loss_sum / float(planar.shape[0])
+            self._probs = probs
+            return logits, {"engine": eng}
         logits, probs = eng.forward_infer(self._preprocessor.planar)
         self._probs = probs
         return logits, {"engine": eng}

@@ -153,3 +153,61 @@ def check_dscnn(lib, size):
     assert np.array_equal(logits.cpu().numpy().argmax(1), fx[f"logits_{size}"].argmax(1))
     assert np.abs(probs.cpu().numpy() - fx[f"probs_{size}"]).max() < 1e-5
     return err
+
+
+def check_dscnn_train(lib, size, steps=3, grad_rtol=2e-4):
+    """DS-CNN train-mode forward + backward + Adam for `steps` steps against the fixture (lr 5e-4)."""
+    from oracle import dscnn_ref as D
+    fx0, fx = load("dscnn_4020.npz"), load("dscnn_train_4020.npz")
+    p, s = D.init_params(D.net_def(size), seed=int(fx["init_seed"]))
+    pre = f"{size}:"
+    wav = R.synth_waveforms(3, seed=int(fx[pre + "wav_seed"]))
+    fe = make_frontend(lib, fx0["win"], fx0["hop"], num_mfccs=10)
+    feat = fe(to_dev(lib, wav))
+    labels = to_dev(lib, fx["labels"])
+    net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
+    sd = dict(p)
+    sd.update(s)
+    net.load_state_dict(sd)
+    lr = float(fx["train_lr"])
+    b = wav.shape[0]
+    keys = [k[len(pre):] for k in fx if k.startswith(pre)]
+    worst = 0.0
+    for step in range(steps):
+        logits, probs, loss_sum = net.forward_train(feat, labels)
+        net.backward()
+        if step == 0:
+            assert np.abs(logits.cpu().numpy() - fx[pre + "train_logits"]).max() < LOGIT_TOL
+            assert abs(float(loss_sum) / b - float(fx[pre + "train_model_loss"])) < 1e-4
+            for k in [k for k in keys if k.startswith("grad:")]:
+                n = k[len("grad:"):]
+                ref = fx[pre + k]
+                got = net.grad_view(n).cpu().numpy().reshape(ref.shape).astype(np.float64)
+                if n.endswith("/biases") and "fc1" not in n:
+                    # bias ahead of a train-mode BN: zero gradient (round-off noise in TF); the library writes exactly 0
+                    assert np.abs(ref).max() < 1e-10 and np.all(got == 0.0), n
+                    continue
+                scale = max(np.abs(ref).max(), 1e-3)
+                e = np.abs(got - ref).max() / scale
+                worst = max(worst, e)
+                assert e < grad_rtol, f"{n}: grad rel err {e}"
+        net.adam_step(lr, step + 1)
+        if step == 0:
+            for k in [k for k in keys if k.startswith("stat1:")]:
+                ref = fx[pre + k]
+                assert np.abs(net._view(k[len("stat1:"):]).cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), k
+            for k in [k for k in keys if k.startswith("param1:")]:
+                ref = fx[pre + k]
+                # Adam's first step moves every weight by lr * g / (|g| + eps'): entries whose gradient is within f32
+                # round-off of zero may differ by a fraction of lr
+                d = np.abs(net._view(k[len("param1:"):]).cpu().numpy().reshape(ref.shape) - ref)
+                assert d.max() < 2.5 * lr and np.mean(d > 2e-5) < 0.01, (k, d.max(), np.mean(d > 2e-5))
+    if steps == 3:
+        for k in [k for k in keys if k.startswith("stat3:")]:
+            ref = fx[pre + k]
+            assert np.abs(net._view(k[len("stat3:"):]).cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k
+        for k in [k for k in keys if k.startswith("param3:")]:
+            ref = fx[pre + k]
+            d = np.abs(net._view(k[len("param3:"):]).cpu().numpy().reshape(ref.shape) - ref)
+            assert d.max() < 4 * lr and np.mean(d > 1e-4) < 0.01, (k, d.max(), np.mean(d > 1e-4))
+    return worst

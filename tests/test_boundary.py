@@ -89,6 +89,12 @@ def test_model_build_matches_oracle(emu_runtime):
     ds = audio_nets.DSCNNLModel(args10)
     ds.build(wavs, labels, is_training=False)
     assert tuple(ds.audio.shape) == (4, 49, 10, 1) and ds.total_params == 413736 and tuple(ds.logits.shape) == (4, 12)
+    # DS-CNN trains with Adam (scripts/commands/DSCNN*Model*.sh): the training build and one optimisation step run
+    ds_s = audio_nets.DSCNNSModel(args10)
+    ds_s.build(wavs, labels, is_training=True)
+    before = ds_s.engine.params.clone()
+    tot, mdl = ds_s.train_step(wavs, labels, 5e-4, optimizer="adam")
+    assert np.isfinite(float(tot)) and abs(float(mdl) - float(ds_s.model_loss)) < 1e-6 and not torch.equal(before, ds_s.engine.params)
     with pytest.raises(NotImplementedError):
         model.build_deployable_model()
 

@@ -95,3 +95,9 @@ def test_engine_argument_errors(emu_lib):
 @pytest.mark.parametrize("size", ["S", "M", "L"])
 def test_dscnn_eval_forward(emu_lib, size):
     Cm.check_dscnn(emu_lib, size)
+
+
+@pytest.mark.parametrize("size", ["S", "L"])
+def test_dscnn_train_steps(emu_lib, size):
+    """Train-mode forward + backward + Adam (3 steps) of DS-CNN; S: (2,2)/(1,1) strides, L: (2,1)/(2,2) and 276 channels."""
+    Cm.check_dscnn_train(emu_lib, size, steps=3 if size == "S" else 1)

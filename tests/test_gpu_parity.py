@@ -128,6 +128,47 @@ def test_dscnn_full_batch_independence(hip_lib):
     assert np.abs(l[0].cpu().numpy() - ref["logits"]).max() < Cm.LOGIT_TOL
 
 
+@pytest.mark.parametrize("size", ["S", "L"])
+def test_dscnn_train_steps(hip_lib, size):
+    """DS-CNN train-mode forward + backward + Adam against the oracle fixture (BASELINE.json configs[4], training half)."""
+    Cm.check_dscnn_train(hip_lib, size, steps=3)
+
+
+def test_dscnn_train_full_batch(hip_lib):
+    """DSCNN-L training step at batch 4096: 64 distinct utterances tiled 64x have the batch statistics of the 64, so
+    logits / loss equal the oracle's on the 64, every tile gets identical rows, gradients agree, and the step is
+    bitwise reproducible."""
+    from oracle import dscnn_ref as D
+    import dataclasses
+    blocks = D.net_def("L")
+    p, s = D.init_params(blocks, seed=0)
+    base = R.synth_waveforms(64, seed=9)
+    labels64 = R.synth_labels(64).astype(np.float64)
+    fe = Cm.make_frontend(hip_lib, 640, 320, num_mfccs=10)
+    net = T.DSCNN("L", fe.n_frames, 10, 12, device="cuda")
+    sd = dict(p); sd.update(s); net.load_state_dict(sd)
+    feat = fe(torch.from_numpy(np.tile(base, (64, 1))).cuda())
+    labels = torch.from_numpy(np.tile(labels64, (64, 1)).astype(np.float32)).cuda()
+    stats0 = net.stats.clone()
+    logits, probs, loss_sum = net.forward_train(feat, labels)
+    g1 = net.backward().clone()
+    l = logits.view(64, 64, 12)
+    assert torch.equal(l, l[:1].expand_as(l))
+    ref = D.forward(blocks, p, s, R.mfcc(base, dataclasses.replace(R.FRONTEND_4020, num_mfccs=10)), True)
+    assert np.abs(l[0].cpu().numpy() - ref["logits"]).max() < Cm.LOGIT_TOL
+    assert abs(float(loss_sum) / 4096 - D.loss(ref["logits"], labels64)) < 1e-4
+    gref = D.backward(blocks, p, ref, labels64)
+    # (a few of the ~5 M ReLU inputs sit within f32 round-off of the kink, so individual channels may differ slightly)
+    for k in ("DSCNN/fc1/weights", "DSCNN/fc1/biases", "DSCNN/conv_ds_5/pointwise_conv/weights", "DSCNN/conv_ds_3/depthwise_conv/depthwise_weights",
+              "DSCNN/conv_ds_1/dw_batch_norm/beta", "DSCNN/conv_1/weights"):
+        got = net.grad_view(k).cpu().numpy().reshape(gref[k].shape)
+        assert np.abs(got - gref[k]).max() < 2e-2 * np.abs(gref[k]).max(), k
+    net.stats.copy_(stats0)
+    logits2, _, loss2 = net.forward_train(feat, labels)
+    g2 = net.backward()
+    assert torch.equal(logits, logits2) and torch.equal(g1, g2) and float(loss_sum) == float(loss2)
+
+
 def test_every_kernel_path_agrees(hip_lib):
     """The alternative kernels behind the tcr_tune knobs (scalar-fed VALU convs, LDS-image MFMA convs, per-layer vs
     whole-network fused eval kernel, front-end variants) all reproduce the default path: bit-exact where the

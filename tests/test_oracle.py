@@ -99,3 +99,58 @@ def test_dscnn_oracle_matches_golden_and_shapes():
         assert r["feat"].shape[1:3] == hw                       # 49x10 -> 25x10 -> 13x5
         assert np.abs(r["logits"] - fx[f"logits_{size}"]).max() < 1e-12
     assert "DSCNN/conv_ds_5/pw_batch_norm/beta" in p and "DSCNN/conv_1/batch_norm/gamma" not in p      # scale=False
+
+
+def test_dscnn_training_oracle_matches_autograd_and_fixture():
+    """The analytic NumPy backward of DS-CNN equals torch autograd (f64) of an independently written forward, and the
+    committed training fixture is what the oracle produces today."""
+    import torch.nn.functional as F
+    from oracle import dscnn_ref as D
+    fx = Cm.load("dscnn_train_4020.npz")
+    blocks = D.net_def("S")
+    p, s = D.init_params(blocks, seed=int(fx["init_seed"]))
+    import dataclasses
+    x = R.mfcc(R.synth_waveforms(3, seed=int(fx["S:wav_seed"])), dataclasses.replace(R.FRONTEND_4020, num_mfccs=10))
+    y = fx["labels"]
+    f = D.forward(blocks, p, s, x, True)
+    g = D.backward(blocks, p, f, y)
+    assert np.abs(f["logits"] - fx["S:train_logits"]).max() < 1e-12
+    for k, v in g.items():
+        assert np.abs(v - fx["S:grad:" + k]).max() < 1e-12, k
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+
+    def same(t, kh, kw, sh, sw):
+        _, pt, pb = R.same_pad(t.shape[2], kh, sh)
+        _, pl, pr = R.same_pad(t.shape[3], kw, sw)
+        return F.pad(t, (pl, pr, pt, pb))
+
+    def bn_relu(z, beta):
+        mean = z.mean(dim=(0, 2, 3), keepdim=True)
+        var = ((z - mean) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+        return torch.relu((z - mean) / torch.sqrt(var + R.BN_EPS) + beta.view(1, -1, 1, 1))
+
+    net = torch.tensor(x)[:, None]
+    for b in blocks:
+        pre, (kh, kw) = f"DSCNN/{b.scope}", b.kernel
+        if b.type == "conv":
+            net = F.conv2d(same(net, kh, kw, *b.stride), tp[pre + "/weights"].permute(3, 2, 0, 1), tp[pre + "/biases"], stride=b.stride)
+            net = bn_relu(net, tp[pre + "/batch_norm/beta"])
+        else:
+            w = tp[pre + "/depthwise_conv/depthwise_weights"].permute(2, 3, 0, 1)
+            net = F.conv2d(same(net, kh, kw, *b.stride), w, tp[pre + "/depthwise_conv/biases"], stride=b.stride, groups=w.shape[0])
+            net = bn_relu(net, tp[pre + "/dw_batch_norm/beta"])
+            net = F.conv2d(net, tp[pre + "/pointwise_conv/weights"].permute(3, 2, 0, 1), tp[pre + "/pointwise_conv/biases"])
+            net = bn_relu(net, tp[pre + "/pw_batch_norm/beta"])
+    logits = net.mean(dim=(2, 3)) @ tp["DSCNN/fc1/weights"] + tp["DSCNN/fc1/biases"]
+    assert np.abs(logits.detach().numpy() - f["logits"]).max() < 1e-12
+    loss = -(torch.tensor(y) * torch.log_softmax(logits, 1)).sum(1).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - D.loss(f["logits"], y)) < 1e-12
+    for k, v in g.items():
+        assert np.abs(tp[k].grad.numpy() - v).max() < 1e-11, k
+    # Adam (tf.train.AdamOptimizer): first step moves every entry by lr * g / (|g| + eps / sqrt(1 - beta2)) ~ lr * sign(g)
+    m0 = {k: np.zeros_like(v) for k, v in p.items()}
+    p1, _, _ = D.adam_step(p, m0, dict(m0), g, 5e-4, 1)
+    k = "DSCNN/fc1/weights"
+    assert np.allclose(p1[k], p[k] - 5e-4 * g[k] / (np.abs(g[k]) + 1e-8 / np.sqrt(1 - 0.999)), atol=1e-12)
+    assert np.abs(p1[k] - fx["S:param1:" + k]).max() < 1e-12
