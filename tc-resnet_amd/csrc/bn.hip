@@ -135,23 +135,19 @@ int launch_chan_sums(const float* partial, int nchunk, int c, float* sums, hipSt
 }
 
 // Train-mode forward finalize from sums[2][C] over `count` elements.
-// Sum of the per-workgroup partial rows (double accumulation, FIXED order: chunk k goes to slice k % nparts, the
-// slices are then added in order), spread over the whole workgroup; or the pre-reduced sums (sync BN).
-// Returns through s_out[which * c + ch]; ends with a barrier.
-__device__ __forceinline__ void reduce_partials(const float* partial, int nchunk, const float* sums, int nc, double* s_slices, double* s_out) {
-    const int n2 = 2 * nc;
-    if (nchunk > 0 && n2 > (int)blockDim.x) {       // wide layers (DS-CNN, 276 channels): one thread per column, several columns each
-        for (int col = threadIdx.x; col < n2; col += blockDim.x) {
-            const int which = col / nc, ch = col - which * nc;
-            double acc = 0.0;
-            for (int k = 0; k < nchunk; ++k) acc += (double)partial[((size_t)k * 2 + which) * nc + ch];
-            s_out[col] = acc;
-        }
-    } else if (nchunk > 0) {
-        const int nparts = max(1, (int)blockDim.x / n2);
-        const int part = threadIdx.x / n2, col = threadIdx.x - part * n2;     // col = which * nc + ch
+// A workgroup owns kBnCB consecutive channels.  Sum of the per-workgroup partial rows (double accumulation, FIXED
+// order: chunk k goes to slice k % nparts, the slices are then added in order), spread over the whole workgroup; or
+// the pre-reduced sums (sync BN).  Returns through s_out[which * cb + (ch - c0)]; ends with a barrier.
+constexpr int kBnCB = 32;           // channels per finalize workgroup (64 columns x 8 slices of chunks)
+
+__device__ __forceinline__ void reduce_partials(const float* partial, int nchunk, const float* sums, int nc, int c0, int cb,
+                                                double* s_slices, double* s_out) {
+    const int n2 = 2 * cb;
+    if (nchunk > 0) {
+        const int nparts = (int)blockDim.x / n2;
+        const int part = threadIdx.x / n2, col = threadIdx.x - part * n2;     // col = which * cb + (ch - c0)
         if (part < nparts) {
-            const int which = col / nc, ch = col - which * nc;
+            const int which = col / cb, ch = c0 + col - which * cb;
             double acc = 0.0;
             for (int k = part; k < nchunk; k += nparts) acc += (double)partial[((size_t)k * 2 + which) * nc + ch];
             s_slices[part * n2 + col] = acc;
@@ -163,19 +159,22 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk
             s_out[i] = acc;
         }
     } else {
-        for (int i = threadIdx.x; i < n2; i += blockDim.x) s_out[i] = (double)sums[i];
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+            const int which = i / cb;
+            s_out[i] = (double)sums[which * nc + c0 + i - which * cb];
+        }
     }
     __syncthreads();
 }
 
-constexpr int kBnMaxC = 512;        // channels per BN layer supported by the finalize kernels
-
 __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a) {
     __shared__ double s_slices[512];
-    __shared__ double s_tot[2 * kBnMaxC];
-    reduce_partials(a.partial, a.nchunk, a.sums, a.c, s_slices, s_tot);
-    for (int c = threadIdx.x; c < a.c; c += blockDim.x) {
-        const double s1 = s_tot[c], s2 = s_tot[a.c + c];
+    __shared__ double s_tot[2 * kBnCB];
+    const int c0 = blockIdx.x * kBnCB, cb = min(kBnCB, a.c - c0);
+    reduce_partials(a.partial, a.nchunk, a.sums, a.c, c0, cb, s_slices, s_tot);
+    for (int i = threadIdx.x; i < cb; i += blockDim.x) {
+        const int c = c0 + i;
+        const double s1 = s_tot[i], s2 = s_tot[cb + i];
         const double m = s1 / a.count;
         double var = s2 / a.count - m * m;
         if (var < 0.0) var = 0.0;
@@ -195,8 +194,7 @@ __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a
 }
 
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
-    if (a.c > kBnMaxC) { set_error("bn_finalize: %d channels exceed the limit %d", a.c, kBnMaxC); return TCR_ERR_ARG; }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(a.c, kBnCB)), dim3(512), 0, s, a);
     return check_launch("bn_finalize_kernel");
 }
 
@@ -227,10 +225,12 @@ int launch_bn_apply(const BnApplyArgs& a, hipStream_t s) {
 //   dy = k1 * (dz - k2 - (y - mean) * k3),  k1 = gamma*invstd, k2 = dbeta/n, k3 = invstd*dgamma/n
 __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const BnBwdFinalizeArgs a) {
     __shared__ double s_slices[512];
-    __shared__ double s_tot[2 * kBnMaxC];
-    reduce_partials(a.partial, a.nchunk, a.sums, a.c, s_slices, s_tot);
-    for (int c = threadIdx.x; c < a.c; c += blockDim.x) {
-        const float db = (float)s_tot[c], dg = (float)s_tot[a.c + c];
+    __shared__ double s_tot[2 * kBnCB];
+    const int c0 = blockIdx.x * kBnCB, cb = min(kBnCB, a.c - c0);
+    reduce_partials(a.partial, a.nchunk, a.sums, a.c, c0, cb, s_slices, s_tot);
+    for (int i = threadIdx.x; i < cb; i += blockDim.x) {
+        const int c = c0 + i;
+        const float db = (float)s_tot[i], dg = (float)s_tot[cb + i];
         a.dbeta[c] = db * a.grad_scale;
         if (a.dgamma) a.dgamma[c] = dg * a.grad_scale;
         a.k1[c] = a.gamma ? a.gamma[c] * a.invstd[c] : a.invstd[c];
@@ -240,8 +240,7 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const BnBwdFinaliz
 }
 
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
-    if (a.c > kBnMaxC) { set_error("bn_bwd_finalize: %d channels exceed the limit %d", a.c, kBnMaxC); return TCR_ERR_ARG; }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(a.c, kBnCB)), dim3(512), 0, s, a);
     return check_launch("bn_bwd_finalize_kernel");
 }
 

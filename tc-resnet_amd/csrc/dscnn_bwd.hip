@@ -13,7 +13,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // dx[h][w] = sum_{di,dj} W[di][dj] * dz[(h + pad_t - di) / sh][(w + pad_l - dj) / sw]  over taps that divide evenly.
 // One wavefront per (utterance, channel) plane; the 9 taps are wave-uniform.
+// SH / SW: compile-time strides (1 or 2: the divisions below become shifts), or 0 for the run-time values.
+template <int SH, int SW>
 __global__ __launch_bounds__(256) void dscnn_dw_dgrad_kernel(const DsDwBwdArgs a) {
+    const int sh = SH ? SH : a.sh, sw = SW ? SW : a.sw;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.planes) return;
@@ -30,13 +33,13 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_kernel(const DsDwBwdArgs a
 #pragma unroll
         for (int di = 0; di < 3; ++di) {
             const int hh = h + a.pad_t - di;
-            const int oh = hh / a.sh;
-            const bool hv = hh >= 0 && oh * a.sh == hh && oh < a.oh;
+            const int oh = hh / sh;
+            const bool hv = hh >= 0 && oh * sh == hh && oh < a.oh;
 #pragma unroll
             for (int dj = 0; dj < 3; ++dj) {
                 const int ww = w + a.pad_l - dj;
-                const int ow = ww / a.sw;
-                const bool v = hv && ww >= 0 && ow * a.sw == ww && ow < a.ow;
+                const int ow = ww / sw;
+                const bool v = hv && ww >= 0 && ow * sw == ww && ow < a.ow;
                 const float g = v ? dz[oh * a.ow + ow] : 0.f;
                 s = fmaf(wt[di * 3 + dj], g, s);
             }
@@ -46,7 +49,10 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_kernel(const DsDwBwdArgs a
 }
 
 int launch_dscnn_dw_dgrad(const DsDwBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(dscnn_dw_dgrad_kernel, dim3((unsigned)ceil_div64(a.planes, 4)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)ceil_div64(a.planes, 4));
+    if (a.sh == 1 && a.sw == 1) hipLaunchKernelGGL((dscnn_dw_dgrad_kernel<1, 1>), grid, dim3(256), 0, s, a);
+    else if (a.sh == 2 && a.sw == 2) hipLaunchKernelGGL((dscnn_dw_dgrad_kernel<2, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dscnn_dw_dgrad_kernel<0, 0>), grid, dim3(256), 0, s, a);
     return check_launch("dscnn_dw_dgrad_kernel");
 }
 

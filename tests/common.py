@@ -201,7 +201,7 @@ def check_dscnn_train(lib, size, steps=3, grad_rtol=2e-4):
                 # Adam's first step moves every weight by lr * g / (|g| + eps'): entries whose gradient is within f32
                 # round-off of zero may differ by a fraction of lr
                 d = np.abs(net._view(k[len("param1:"):]).cpu().numpy().reshape(ref.shape) - ref)
-                assert d.max() < 2.5 * lr and np.mean(d > 2e-5) < 0.01, (k, d.max(), np.mean(d > 2e-5))
+                assert d.max() < 2.5 * lr and np.mean(d > 2e-5) < 0.03, (k, d.max(), np.mean(d > 2e-5))
     if steps == 3:
         for k in [k for k in keys if k.startswith("stat3:")]:
             ref = fx[pre + k]
@@ -209,5 +209,5 @@ def check_dscnn_train(lib, size, steps=3, grad_rtol=2e-4):
         for k in [k for k in keys if k.startswith("param3:")]:
             ref = fx[pre + k]
             d = np.abs(net._view(k[len("param3:"):]).cpu().numpy().reshape(ref.shape) - ref)
-            assert d.max() < 4 * lr and np.mean(d > 1e-4) < 0.01, (k, d.max(), np.mean(d > 1e-4))
+            assert d.max() < 4 * lr and np.mean(d > 1e-4) < 0.03, (k, d.max(), np.mean(d > 1e-4))
     return worst
