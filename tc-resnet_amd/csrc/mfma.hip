@@ -537,6 +537,7 @@ struct PwWgradArgs {
 
 __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) {
     constexpr int BT = 96;                                  // block edge: 6 MFMA tiles
+    constexpr int NV = 14;                                  // float4 per thread per utterance: 2 * 96 * pp / 4 <= 14 * 256
     float* xs = reinterpret_cast<float*>(dyn_lds());
     float* ds = xs + BT * a.pp;
     const int tid = threadIdx.x;
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) 
     const int r = lane & 15, q = lane >> 4;
     const int ci0 = blockIdx.y * BT, co0 = blockIdx.z * BT;
     const int xrows = min(BT, a.cin - ci0), drows = min(BT, a.cout - co0);
-    const int xn = xrows * a.pp, dn = drows * a.pp;
+    const int xv = xrows * a.pp / 4, dv = drows * a.pp / 4;             // float4 counts (host checks divisibility)
     for (int i = tid; i < 2 * BT * a.pp; i += 256) xs[i] = 0.f;          // rows past the channel count stay zero
     const int wm = (wave >> 1) * 3, wn = (wave & 1) * 3;
     f32x4 acc[3][3];
@@ -560,23 +561,49 @@ __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) 
     }
     const int n_begin = blockIdx.x * a.utt_per_block;
     const int n_end = min(n_begin + a.utt_per_block, a.batch);
+    // The next utterance's rows travel global -> registers while the current one is multiplied out of LDS.
+    // (Every lane always loads from a valid address -- clamped past the end; 14 named registers rather than an array,
+    // which the compiler kept in scratch memory.)
+    float4 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, p13;
+    const float4 *xg4, *dg4;
+#define TCR_PW_LD(I_, P_) { const int v = tid + (I_) * 256; P_ = *(v < xv ? xg4 + v : dg4 + min(v - xv, dv - 1)); }
+#define TCR_PW_ST(I_, P_) { const int v = tid + (I_) * 256; if (v < xv) xs4[v] = P_; else if (v - xv < dv) ds4[v - xv] = P_; }
+#define TCR_PW_ALL(OP_) OP_(0, p0) OP_(1, p1) OP_(2, p2) OP_(3, p3) OP_(4, p4) OP_(5, p5) OP_(6, p6) OP_(7, p7) OP_(8, p8) OP_(9, p9) \
+                        OP_(10, p10) OP_(11, p11) OP_(12, p12) OP_(13, p13)
+#define TCR_PW_PREFETCH(N_)                                                                         \
+    {                                                                                               \
+        xg4 = reinterpret_cast<const float4*>(a.x + ((size_t)(N_) * a.cin + ci0) * a.pp);           \
+        dg4 = reinterpret_cast<const float4*>(a.dz + ((size_t)(N_) * a.cout + co0) * a.pp);         \
+        TCR_PW_ALL(TCR_PW_LD)                                                                       \
+    }
+    static_assert(NV == 14, "TCR_PW_ALL lists 14 registers");
+    if (n_begin < n_end) TCR_PW_PREFETCH(n_begin)
+    float4* xs4 = reinterpret_cast<float4*>(xs);
+    float4* ds4 = reinterpret_cast<float4*>(ds);
     for (int n = n_begin; n < n_end; ++n) {
         __syncthreads();
-        const float* xg = a.x + ((size_t)n * a.cin + ci0) * a.pp;
-        const float* dg = a.dz + ((size_t)n * a.cout + co0) * a.pp;
-        for (int i = tid; i < xn; i += 256) xs[i] = xg[i];
-        for (int i = tid; i < dn; i += 256) ds[i] = dg[i];
+        TCR_PW_ALL(TCR_PW_ST)
         __syncthreads();
-        for (int k0 = 0; k0 < a.p; k0 += 4) {
-            float af[3], bf[3];
+        if (n + 1 < n_end) TCR_PW_PREFETCH(n + 1)
+        float af[3], bf[3];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) { af[m] = xs[ao[m] + k0]; bf[m] = ds[bo[m] + k0]; }
+        for (int m = 0; m < 3; ++m) { af[m] = xs[ao[m]]; bf[m] = ds[bo[m]]; }
+        for (int k0 = 0; k0 < a.p; k0 += 4) {
+            float an[3], bn[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { an[m] = xs[ao[m] + k0 + 4]; bn[m] = ds[bo[m] + k0 + 4]; }   // (past the end: next row's halo / pad)
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
                 for (int nn = 0; nn < 3; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nn], acc[m][nn], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { af[m] = an[m]; bf[m] = bn[m]; }
         }
     }
+#undef TCR_PW_PREFETCH
+#undef TCR_PW_ALL
+#undef TCR_PW_ST
+#undef TCR_PW_LD
     float* dst = a.partial + (size_t)blockIdx.x * a.cin_pad * a.cout_pad;
 #pragma unroll
     for (int m = 0; m < 3; ++m)
@@ -596,7 +623,9 @@ static int pw_wgrad_chunks(int batch) {
 }
 
 static bool pw_wgrad_fits(int k, int stride, int cin, int cout, int tpi, int tpo) {
-    return k == 1 && stride == 1 && tpi == tpo && cin > 80 && cout > 80 && (size_t)2 * 96 * tpi * sizeof(float) <= 128 * 1024;
+    // rows are copied as float4: every 96-row block of an utterance must start and end on a 16-byte boundary, and the
+    // two blocks must fit the kernel's 14 float4 per thread
+    return k == 1 && stride == 1 && tpi == tpo && cin > 80 && cout > 80 && cin % 4 == 0 && cout % 4 == 0 && 2 * 96 * tpi <= 14 * 256 * 4;
 }
 
 static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float* scratch, int batch, int cin, int cout, int tpi, int tout,
@@ -605,7 +634,7 @@ static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float
     a.x = x; a.dz = dy; a.partial = scratch; a.batch = batch; a.cin = cin; a.cout = cout;
     a.cin_pad = ceil_div(cin, 16) * 16; a.cout_pad = ceil_div(cout, 16) * 16; a.p = tout; a.pp = tpi;
     a.utt_per_block = ceil_div(batch, pw_wgrad_chunks(batch));
-    const size_t lds = (size_t)2 * 96 * tpi * sizeof(float);
+    const size_t lds = ((size_t)2 * 96 * tpi + 16) * sizeof(float);      // (+ pad: the one-step operand lookahead)
 #if !defined(TCR_HOST_EMULATION)
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
@@ -624,7 +653,7 @@ static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float
 
 int wgrad_chunks(int batch) {
     int n = ceil_div(batch, 16);        // >= 16 utterances (4 per wave) per workgroup
-    if (n > 128) n = 128;
+    if (n > 128) n = 128;           // (measured at batch 4096: 64 / 256 / 512 split-K workgroups are 3-15 % slower per training step)
     if (n < 1) n = 1;
     return n;
 }
