@@ -20,10 +20,13 @@ for tag, win, hop in (("4020", 640, 320), ("3010", 480, 160)):
         lib.tcr_tune(3, 1); ref, _ = net.forward_infer(feat); t_layer = timeit(lambda: net.forward_infer(feat))
         lib.tcr_tune(3, 0)
         res = []
-        for g in (0, 2, 3, 4, 6, 8, 10):
-            lib.tcr_tune(4, g)
-            out, _ = net.forward_infer(feat); torch.cuda.synchronize()
-            err = float((out - ref).abs().max())
-            res.append((g, timeit(lambda: net.forward_infer(feat)), err))
-        lib.tcr_tune(4, 0)
-        print(f"{name} {tag}: per-layer {t_layer:.1f} us | fused " + " ".join(f"G{g}:{t:.1f}us(err {e:.1e})" for g, t, e in res))
+        for nf in (0,):
+          lib.tcr_tune(3, nf)
+          for w in (0, 404, 408, 416, 808, 816):
+            for g in (0, 7, 8):
+                lib.tcr_tune(4, g); lib.tcr_tune(5, w)
+                out, _ = net.forward_infer(feat); torch.cuda.synchronize()
+                err = float((out - ref).abs().max())
+                res.append((f"{nf}/{w}/{g}", timeit(lambda: net.forward_infer(feat)), err))
+        lib.tcr_tune(4, 0); lib.tcr_tune(5, 0); lib.tcr_tune(3, 0)
+        print(f"{name} {tag}: per-layer {t_layer:.1f} us | fused " + " ".join(f"W/G{g}:{t:.1f}us({e:.0e})" for g, t, e in res))

@@ -16,8 +16,105 @@ namespace tcr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void net_fused_kernel(const FusedArgs a) {
-    constexpr int CH = 8;                                   // weight lookahead: K-steps (of 4 input channels) per chunk
+// NW: wavefronts per workgroup (jobs of a layer are dealt round-robin to them).  R: depth of the weight register ring.
+// One layer of the walk for the group's `ng` utterances.  xin: input rows (LDS buffer, or -- first layer -- the feature
+// rows in global memory, which then never occupy LDS), in_sz floats per utterance.
+template <int NW, int R>
+__device__ __forceinline__ void fused_layer(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
+                                            float* lds, const int ng, const int wave, const int r, const int q) {
+    const int tpi = L.tin + 2 * kHalo, tpo = L.tout + 2 * kHalo;
+    float* yout = lds + a.buf_off[L.out_buf];
+    const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
+    const int out_sz = a.buf_sz[L.out_buf];
+    const int res_sz = L.res_buf >= 0 ? a.buf_sz[L.res_buf] : 0;
+    const int npos = ng * L.tout;
+    const int ncp = (npos + 31) / 32;               // column pairs (32 positions)
+    const int nrt = (L.cout + 15) / 16;             // row tiles (16 output channels)
+    const int C4 = L.cin >> 2;
+    const int nsteps = L.k * C4;
+    const float* w = a.params + L.w_off;
+    const float* scale = a.ss + L.ss_off;
+    const float* shift = scale + L.c_pad;
+    const int wstep = 4 * L.cout;                   // weight floats per K-step (4 input channels of one tap)
+    const int xstep = 4 * tpi;                      // LDS floats per K-step within a tap
+    // position -> (utterance of the group, frame) without an integer division: (p + 0.5) / tout is never within
+    // float round-off of an integer for the p < 2^16 that occur here
+    const float inv_tout = 1.0f / (float)L.tout;
+    for (int job = wave; job < ncp * nrt; job += NW) {
+        const int cp = job / nrt, m = job - cp * nrt;
+        // A-fragment element of this lane: W[j][4*c4 + q][16*m + r]; rows beyond Cout are clamped (never stored)
+        const int aidx = q * L.cout + min(m * 16 + r, L.cout - 1);
+        const int p0 = min(cp * 32 + r, npos - 1), p1 = min(cp * 32 + 16 + r, npos - 1);
+        const int g0 = (int)(((float)p0 + 0.5f) * inv_tout), g1 = (int)(((float)p1 + 0.5f) * inv_tout);
+        const int t0 = p0 - g0 * L.tout, t1 = p1 - g1 * L.tout;
+        const int xo0 = g0 * in_sz + q * tpi + t0 * L.stride + kHalo - L.pad_lo;
+        const int xo1 = g1 * in_sz + q * tpi + t1 * L.stride + kHalo - L.pad_lo;
+        // folded-BN scale / shift of this lane's 4 output channels: fetched now, consumed after the K loop
+        float sc[4], sh[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int co = min(m * 16 + q * 4 + reg, L.cout - 1);
+            sc[reg] = scale[co];
+            sh[reg] = shift[co];
+        }
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // K-steps s = (tap j, channel quad c4), tap-major.  Weights come from L1/L2 through a 4-deep register
+        // ring (uniform base + 32-bit lane offset, clamped instead of branched at the tail); activations are read
+        // from the LDS rows at xo + off, where off = c4 * xstep + j is advanced with scalar increments.
+        const int last = nsteps - 1;
+        float ar[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) ar[i] = w[aidx + min(i, last) * wstep];
+        // LDS operands are read one step ahead of the MFMAs that consume them (b0/b1 = current step,
+        // nb0/nb1 = next step), so the matrix pipe never waits on a ds_read it has just issued.
+        int off = xstep, c4 = 1, j = 0;
+        if (C4 == 1) { c4 = 0; off = j = 1; }
+        float b0 = xin[xo0], b1 = xin[xo1];
+#define TCR_FUSED_STEP(AREG, RELOAD)                                                                    \
+    {                                                                                                   \
+const float nb0 = xin[xo0 + off], nb1 = xin[xo1 + off];     /* (one step past the end: inside the pad) */ \
+acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(AREG, b0, acc0, 0, 0, 0);                           \
+acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(AREG, b1, acc1, 0, 0, 0);                           \
+RELOAD                                                                                          \
+b0 = nb0;                                                                                       \
+b1 = nb1;                                                                                       \
+off += xstep;                                                                                   \
+if (++c4 == C4) { c4 = 0; off = ++j; }                                                          \
+    }
+        int s0 = 0;
+        for (; s0 + R <= nsteps; s0 += R) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) TCR_FUSED_STEP(ar[i], ar[i] = w[aidx + min(s0 + R + i, last) * wstep];)
+        }
+#pragma unroll
+        for (int i = 0; i < R - 1; ++i)
+            if (s0 + i < nsteps) TCR_FUSED_STEP(ar[i], )
+#undef TCR_FUSED_STEP
+        // ---- epilogue: folded BN (+ shortcut) (+ ReLU) -> LDS rows of the output buffer ----
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if (cp * 32 + nt * 16 + r >= npos) continue;
+            const int g = nt == 0 ? g0 : g1, t = nt == 0 ? t0 : t1;
+            const f32x4 ac = nt == 0 ? acc0 : acc1;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = m * 16 + q * 4 + reg;
+                if (co >= L.cout) continue;
+                float v = fmaf(ac[reg], sc[reg], sh[reg]);
+                if (res) v = fmaxf(v + res[g * res_sz + co * tpo + kHalo + t], 0.f);      // tc_resnet.py:40-41
+                else if (L.relu) v = fmaxf(v, 0.f);
+                float* dst = yout + g * out_sz + co * tpo + kHalo + t;
+                dst[0] = v;
+                if (t == 0) { dst[-4] = 0.f; dst[-3] = 0.f; dst[-2] = 0.f; dst[-1] = 0.f; }
+                if (t == L.tout - 1) { dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f; dst[4] = 0.f; }
+            }
+        }
+    }
+}
+
+template <int NW, int R>
+__global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
+    constexpr int NT = NW * 64;
     float* lds = reinterpret_cast<float*>(dyn_lds());
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -26,101 +123,21 @@ __global__ __launch_bounds__(256) void net_fused_kernel(const FusedArgs a) {
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
-        // ---- stage the group's feature rows (contiguous in global memory) ----
-        {
-            const int row = a.in_c * a.in_tp;
+        const int row = a.in_c * a.in_tp;
+        if (!a.in_global) {
+            // ---- stage the group's feature rows (contiguous in global memory) ----
             const float4* src = reinterpret_cast<const float4*>(a.feat + (size_t)n0 * row);
             float4* dst = reinterpret_cast<float4*>(lds + a.buf_off[0]);
             const int nvec = ng * row / 4;
-            for (int i = tid; i < nvec; i += 256) dst[i] = src[i];
+            for (int i = tid; i < nvec; i += NT) dst[i] = src[i];
+            __syncthreads();
         }
-        __syncthreads();
 
         for (int li = 0; li < a.n_layers; ++li) {
             const FusedLayer L = a.layer[li];
-            const int tpi = L.tin + 2 * kHalo, tpo = L.tout + 2 * kHalo;
-            const float* xin = lds + a.buf_off[L.in_buf];
-            float* yout = lds + a.buf_off[L.out_buf];
-            const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
-            const int in_sz = a.buf_sz[L.in_buf], out_sz = a.buf_sz[L.out_buf];
-            const int res_sz = L.res_buf >= 0 ? a.buf_sz[L.res_buf] : 0;
-            const int npos = ng * L.tout;
-            const int ncp = (npos + 31) / 32;               // column pairs (32 positions)
-            const int nrt = (L.cout + 15) / 16;             // row tiles (16 output channels)
-            const int C4 = L.cin >> 2;
-            const int nsteps = L.k * C4;
-            const float* w = a.params + L.w_off;
-            const float* scale = a.ss + L.ss_off;
-            const float* shift = scale + L.c_pad;
-            const int wstep = 4 * L.cout;                   // weight floats per K-step (4 input channels of one tap)
-            const int xstep = 4 * tpi;                      // LDS floats per K-step within a tap
-            for (int job = wave; job < ncp * nrt; job += 4) {
-                const int cp = job / nrt, m = job - cp * nrt;
-                // A-fragment element of this lane: W[j][4*c4 + q][16*m + r]; rows beyond Cout are clamped (never stored)
-                const int aidx = q * L.cout + min(m * 16 + r, L.cout - 1);
-                int xo0, xo1;
-                {
-                    const int p0 = min(cp * 32 + r, npos - 1), p1 = min(cp * 32 + 16 + r, npos - 1);
-                    const int g0 = p0 / L.tout, g1 = p1 / L.tout;
-                    xo0 = g0 * in_sz + q * tpi + (p0 - g0 * L.tout) * L.stride + kHalo - L.pad_lo;
-                    xo1 = g1 * in_sz + q * tpi + (p1 - g1 * L.tout) * L.stride + kHalo - L.pad_lo;
-                }
-                f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                // K-steps s = (tap j, channel quad c4), tap-major.  Weights come from L1/L2 through a 4-deep register
-                // ring (uniform base + 32-bit lane offset, clamped instead of branched at the tail); activations are read
-                // from the LDS rows at xo + off, where off = c4 * xstep + j is advanced with scalar increments.
-                const int last = nsteps - 1;
-                float a0 = w[aidx], a1 = w[aidx + min(1, last) * wstep], a2 = w[aidx + min(2, last) * wstep],
-                      a3 = w[aidx + min(3, last) * wstep];
-                // LDS operands are read one step ahead of the MFMAs that consume them (b0/b1 = current step,
-                // nb0/nb1 = next step), so the matrix pipe never waits on a ds_read it has just issued.
-                int off = xstep, c4 = 1, j = 0;
-                if (C4 == 1) { c4 = 0; off = j = 1; }
-                float b0 = xin[xo0], b1 = xin[xo1];
-#define TCR_FUSED_STEP(AREG, NEXT)                                                                      \
-    {                                                                                                   \
-        const float nb0 = xin[xo0 + off], nb1 = xin[xo1 + off];     /* (one step past the end: inside the pad) */ \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(AREG, b0, acc0, 0, 0, 0);                           \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(AREG, b1, acc1, 0, 0, 0);                           \
-        AREG = w[aidx + min(NEXT, last) * wstep];                                                       \
-        b0 = nb0;                                                                                       \
-        b1 = nb1;                                                                                       \
-        off += xstep;                                                                                   \
-        if (++c4 == C4) { c4 = 0; off = ++j; }                                                          \
-    }
-                int s0 = 0;
-                for (; s0 + 4 <= nsteps; s0 += 4) {
-                    TCR_FUSED_STEP(a0, s0 + 4)
-                    TCR_FUSED_STEP(a1, s0 + 5)
-                    TCR_FUSED_STEP(a2, s0 + 6)
-                    TCR_FUSED_STEP(a3, s0 + 7)
-                }
-                if (s0 < nsteps) TCR_FUSED_STEP(a0, last)
-                if (s0 + 1 < nsteps) TCR_FUSED_STEP(a1, last)
-                if (s0 + 2 < nsteps) TCR_FUSED_STEP(a2, last)
-#undef TCR_FUSED_STEP
-                // ---- epilogue: folded BN (+ shortcut) (+ ReLU) -> LDS rows of the output buffer ----
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int p = cp * 32 + nt * 16 + r;
-                    if (p >= npos) continue;
-                    const int g = p / L.tout, t = p - g * L.tout;
-                    const f32x4 ac = nt == 0 ? acc0 : acc1;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int co = m * 16 + q * 4 + reg;
-                        if (co >= L.cout) continue;
-                        float v = fmaf(ac[reg], scale[co], shift[co]);
-                        if (res) v = fmaxf(v + res[g * res_sz + co * tpo + kHalo + t], 0.f);      // tc_resnet.py:40-41
-                        else if (L.relu) v = fmaxf(v, 0.f);
-                        float* dst = yout + g * out_sz + co * tpo + kHalo + t;
-                        dst[0] = v;
-                        if (t == 0) { dst[-4] = 0.f; dst[-3] = 0.f; dst[-2] = 0.f; dst[-1] = 0.f; }
-                        if (t == L.tout - 1) { dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f; dst[4] = 0.f; }
-                    }
-                }
-            }
-            __syncthreads();
+            if (li == 0 && a.in_global) fused_layer<NW, R>(a, L, a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
+            else fused_layer<NW, R>(a, L, lds + a.buf_off[L.in_buf], a.buf_sz[L.in_buf], lds, ng, wave, r, q);
+            if (!L.no_barrier) __syncthreads();         // (a block's shortcut conv and its first conv read the same input: one phase)
         }
 
         // ---- head: global average pool -> fc / fc2 -> softmax / sigmoid (tc_resnet.py:43-52) ----
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(256) void net_fused_kernel(const FusedArgs a) {
             const float* fb = lds + a.buf_off[a.feat_buf];
             const int fsz = a.buf_sz[a.feat_buf], tp = a.feat_t + 2 * kHalo;
             float* pooled = lds + a.buf_off[(a.feat_buf + 1) % 3];         // any buffer other than the feature buffer
-            for (int i = tid; i < ng * a.feat_c; i += 256) {
+            for (int i = tid; i < ng * a.feat_c; i += NT) {
                 const int g = i / a.feat_c, c = i - g * a.feat_c;
                 const float* row = fb + g * fsz + c * tp + kHalo;
                 float s = 0.f;
@@ -138,34 +155,37 @@ __global__ __launch_bounds__(256) void net_fused_kernel(const FusedArgs a) {
             __syncthreads();
             float* lg = pooled + a.group * a.feat_c;                        // [ng][nc + 2]
             const int no = a.nc + 2;
-            for (int i = tid; i < ng * no; i += 256) {
+            for (int i = tid; i < ng * no; i += NT) {
                 const int g = i / no, o = i - g * no;
                 const float* pv = pooled + g * a.feat_c;
                 float s = 0.f;
                 if (o < a.nc) {
                     const float* wf = a.params + a.fc_off + o;
+#pragma unroll 8
                     for (int c = 0; c < a.feat_c; ++c) s = fmaf(pv[c], wf[(size_t)c * a.nc], s);
                 } else {
                     const float* wf = a.params + a.fc2_off + (o - a.nc);
+#pragma unroll 8
                     for (int c = 0; c < a.feat_c; ++c) s = fmaf(pv[c], wf[(size_t)c * 2], s);
                 }
                 lg[i] = s;
             }
             __syncthreads();
-            for (int g = tid; g < ng; g += 256) {
+            // softmax / sigmoid: one thread per (utterance, output); the max and the sum are recomputed per thread
+            // from the LDS row in the SAME order as the single-thread form (bitwise identical results)
+            for (int i = tid; i < ng * no; i += NT) {
+                const int g = i / no, o = i - g * no;
                 const float* z = lg + g * no;
-                float mx = z[0];
-                for (int o = 1; o < a.nc; ++o) mx = fmaxf(mx, z[o]);
-                float se = 0.f;
-                for (int o = 0; o < a.nc; ++o) se += expf(z[o] - mx);
                 const size_t n = (size_t)(n0 + g);
-                for (int o = 0; o < a.nc; ++o) {
+                if (o < a.nc) {
+                    float mx = z[0];
+                    for (int k = 1; k < a.nc; ++k) mx = fmaxf(mx, z[k]);
+                    float se = 0.f;
+                    for (int k = 0; k < a.nc; ++k) se += expf(z[k] - mx);
                     a.logits[n * a.nc + o] = z[o];
                     a.probs[n * a.nc + o] = expf(z[o] - mx) / se;
-                }
-                if (a.ranges) {
-                    a.ranges[n * 2] = 1.0f / (1.0f + expf(-z[a.nc]));
-                    a.ranges[n * 2 + 1] = 1.0f / (1.0f + expf(-z[a.nc + 1]));
+                } else if (a.ranges) {
+                    a.ranges[n * 2 + (o - a.nc)] = 1.0f / (1.0f + expf(-z[o]));
                 }
             }
             __syncthreads();
@@ -173,18 +193,21 @@ __global__ __launch_bounds__(256) void net_fused_kernel(const FusedArgs a) {
     }
 }
 
-int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, hipStream_t s) {
+int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, int ring, hipStream_t s) {
+    void (*kern)(const FusedArgs) = nullptr;
+#define TCR_FK(NW_, R_) if (waves == NW_ && ring == R_) kern = net_fused_kernel<NW_, R_>;
+    TCR_FK(4, 4) TCR_FK(4, 8) TCR_FK(4, 16) TCR_FK(8, 4) TCR_FK(8, 8) TCR_FK(8, 16) TCR_FK(16, 4) TCR_FK(16, 8) TCR_FK(16, 16)
+#undef TCR_FK
+    if (!kern) { set_error("fused kernel: no instantiation for %d waves / ring %d", waves, ring); return TCR_ERR_ARG; }
 #if !defined(TCR_HOST_EMULATION)
-    static size_t configured = 0;
-    if (lds_bytes > 64 * 1024 && lds_bytes > configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(net_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+    if (lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
             (void)hipGetLastError();
             return 1;       // caller falls back to the per-layer kernels
         }
-        configured = lds_bytes;
     }
 #endif
-    hipLaunchKernelGGL(net_fused_kernel, dim3(grid), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds_bytes, s, a);
     return check_launch("net_fused_kernel");
 }
 

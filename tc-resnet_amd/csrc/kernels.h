@@ -82,6 +82,7 @@ struct FusedLayer {
     int k, stride, cin, cout, tin, tout, pad_lo, relu;
     int in_buf, out_buf, res_buf;       // LDS buffer ids (res_buf < 0: none)
     int w_off, ss_off, c_pad;           // float offsets into params / scale-shift table
+    int no_barrier;                     // the next layer reads the same input and writes another buffer: no s_barrier in between
 };
 
 struct FusedArgs {
@@ -98,11 +99,12 @@ struct FusedArgs {
     int feat_buf;               // buffer holding the last block output
     int feat_c, feat_t, nc;
     int fc_off, fc2_off;
+    int in_global;              // the first layer reads the feature rows straight from global memory (no LDS copy)
     FusedLayer layer[kFusedMaxLayers];
 };
 
 // returns 1 when the launch could not be configured (caller falls back to the per-layer kernels)
-int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, hipStream_t s);
+int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, int ring, hipStream_t s);
 
 // ---- bn.hip ---------------------------------------------------------------------------------
 constexpr int kBnMaxLayers = 40;

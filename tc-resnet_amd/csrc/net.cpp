@@ -303,27 +303,34 @@ static int forward_infer_fused(const tcr_net& net, const float* params, const fl
         return l.cin % 4 == 0;
     };
     bool ok = true;
-    grow(0, net.cfg.in_channels, net.cfg.t_in);
+    const bool in_global = tune_get(TCR_TUNE_NET_FUSED) != 2;
+    if (!in_global) grow(0, net.cfg.in_channels, net.cfg.t_in);
     ok &= add(0, 0, 1, -1);
     for (const Block& b : net.blocks) {
-        if (b.down >= 0) ok &= add(b.down, 1, 0, -1);
+        if (b.down >= 0) {
+            ok &= add(b.down, 1, 0, -1);
+            a.layer[a.n_layers - 1].no_barrier = 1;
+        }
         ok &= add(b.a, 1, 2, -1);
         ok &= add(b.b, 2, 1, b.down >= 0 ? 0 : 1);
     }
     if (!ok || net.param_floats >= (int64_t)1 << 31) return 1;
     const int per_utt = sz[0] + sz[1] + sz[2];
+    // Policy (scripts/fused_test.py, B = 4096, TCResNet8-1.0 / TCResNet14-1.5 at 49 and 98 frames): the largest group of
+    // up to 8 utterances whose activations fit the CU's 160 KB of LDS (more positions per layer = fuller MFMA tiles and
+    // more jobs per barrier phase), and as many waves per workgroup as keeps ~16 waves on the CU (the kernel needs
+    // ~90 VGPRs: 5 waves / SIMD at most).
+    auto lds_of = [&](int g) { return ((size_t)g * per_utt + 64) * sizeof(float); };      // + pad: operand prefetch reads one step past the end
     int group = tune_get(TCR_TUNE_FUSED_GROUP);
     if (group <= 0) {
-        // measured (scripts/fused_test.py, B = 4096): groups of 4 utterances win over the per-layer kernels while the
-        // group's activations stay below ~80 KB of LDS (TCResNet8-1.0 / TCResNet14-1.5 at 49 frames); the 98-frame
-        // front-end doubles every row and the per-layer kernels are as fast or faster there.
-        if (((size_t)4 * per_utt + 64) * sizeof(float) > 80 * 1024) return 1;
-        group = 4;
+        group = 8;
+        while (group > 1 && lds_of(group) > 160 * 1024) --group;
+        while (group > 1 && ceil_div(batch, group) < 512) --group;         // small batches: spread over the 256 CUs first
     }
     if (group > 16) group = 16;
     if (group > batch) group = batch;
     if (group < 1) group = 1;
-    const size_t lds = ((size_t)group * per_utt + 64) * sizeof(float);      // + pad: operand prefetch reads one step past the end
+    const size_t lds = lds_of(group);
     if (lds > 160 * 1024) return 1;
     // the head scratch (pooled + logits) lives in a buffer other than the feature buffer
     if ((int64_t)group * (net.feat_c + net.cfg.num_classes + 2) > (int64_t)group * sz[2] && (int64_t)group * (net.feat_c + net.cfg.num_classes + 2) > (int64_t)group * sz[0]) return 1;
@@ -332,12 +339,18 @@ static int forward_infer_fused(const tcr_net& net, const float* params, const fl
     a.buf_off[0] = 0; a.buf_off[1] = group * sz[0]; a.buf_off[2] = group * (sz[0] + sz[1]);
     a.buf_sz[0] = sz[0]; a.buf_sz[1] = sz[1]; a.buf_sz[2] = sz[2];
     a.in_c = net.cfg.in_channels; a.in_tp = tcr_padded_len(net.cfg.t_in);
+    a.in_global = in_global ? 1 : 0;
     a.feat_buf = 1; a.feat_c = net.feat_c; a.feat_t = net.feat_t; a.nc = net.cfg.num_classes;
     a.fc_off = (int)net.layers[net.fc].w_off; a.fc2_off = (int)net.layers[net.fc2].w_off;
-    const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
     int grid = 256 * per_cu;
     if (grid > a.n_groups) grid = a.n_groups;
-    return launch_net_fused(a, lds, grid, s);
+    // knob: waves + 100 * ring (0: default)
+    const int knob = tune_get(TCR_TUNE_FUSED_WAVES);
+    const int waves = knob % 100 ? knob % 100 : (per_cu >= 4 ? 4 : (per_cu >= 2 ? 8 : 16)), ring = knob / 100 ? knob / 100 : 4;
+    return launch_net_fused(a, lds, grid, waves, ring, s);
 }
 
 }  // namespace tcr
