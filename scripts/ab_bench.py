@@ -29,11 +29,11 @@ res = {}
 for tag, win, hop in (("4020", 640, 320), ("3010", 480, 160)):
     fe = T.Frontend(window_size_samples=win, window_stride_samples=hop, device=dev)
     feat = fe(wav)
-    for knob in (1, 2, 3, 4):
+    for knob in (1, 4, 5):
         lib.tcr_tune(1, knob)
         res[f"frontend_{tag}_var{knob}_us"] = timeit(lambda: fe(wav, out=feat))
     lib.tcr_tune(1, 0)
-    for name, ch in (("TCResNet8", [16, 24, 32, 48]),) if os.environ.get("AB_QUICK") else (("TCResNet8", [16, 24, 32, 48]), ("TCResNet14w15", [24, 36, 36, 48, 48, 72, 72])):
+    for name, ch in () if os.environ.get("AB_FE_ONLY") else (("TCResNet8", [16, 24, 32, 48]),) if os.environ.get("AB_QUICK") else (("TCResNet8", [16, 24, 32, 48]), ("TCResNet14w15", [24, 36, 36, 48, 48, 72, 72])):
         net = T.TCResNet("TCResNet8" if name == "TCResNet8" else "TCResNet14", ch, 40, fe.n_frames, 12, device=dev)
         net.init_xavier(0)
         for path in (0, 2):

@@ -18,24 +18,9 @@
 //   * DCT-II: after 64 frames of log-mel are in LDS, lane == frame and the DCT coefficients are
 //     wave-uniform (scalar loads feeding v_fmac), folded 64 -> 32 terms by the even/odd symmetry.
 #include "frontend_plan.h"
+#include "frontend_args.h"
 
 namespace tcr {
-
-struct FrontendArgs {
-    const float* wav;
-    float* out;
-    const float* window;
-    const float2* tw256;
-    const float2* tw_combine;
-    const float2* tw_real;
-    const int* seg_start;
-    const float2* wud;
-    const float* dcth;
-    int n_samples, win, hop, n_frames, n_coef, tp;
-    int total_frames;
-    int magnitude;      // 1: log-mel preprocessor (|S|, no DCT)
-    int aligned;        // frame starts are 8-byte aligned -> float2 loads
-};
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -364,7 +349,9 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     a.aligned = ((cfg->n_samples | cfg->hop) & 1) == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0;
     const int grid = ceil_div(a.total_frames, 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int var = tune_get(TCR_TUNE_FRONTEND) == 0 ? 3 : (tune_get(TCR_TUNE_FRONTEND) - 1) & 3;   // default: both on
+    const int knob = tune_get(TCR_TUNE_FRONTEND);
+    if (knob == 0 || knob == 5) return launch_frontend_pk(cfg->nfft / 2, a, grid, s);      // default: packed-FP32 kernel (frontend_pk.hip)
+    const int var = (knob - 1) & 3;
 #define TCR_FE(NC_)                                                                                     \
     switch (var) {                                                                                      \
         case 0: hipLaunchKernelGGL((frontend_kernel<NC_, 0>), dim3(grid), dim3(256), 0, s, a); break;   \

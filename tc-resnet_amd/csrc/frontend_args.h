@@ -1,0 +1,26 @@
+// Argument block of the fused front-end kernels (frontend.hip: scalar FP32; frontend_pk.hip: packed FP32).
+#pragma once
+#include "tcr_common.h"
+
+namespace tcr {
+
+struct FrontendArgs {
+    const float* wav;
+    float* out;
+    const float* window;
+    const float2* tw256;
+    const float2* tw_combine;
+    const float2* tw_real;
+    const int* seg_start;
+    const float2* wud;
+    const float* dcth;
+    int n_samples, win, hop, n_frames, n_coef, tp;
+    int total_frames;
+    int magnitude;      // 1: log-mel preprocessor (|S|, no DCT)
+    int aligned;        // frame starts are 8-byte aligned -> float2 loads
+};
+
+// packed-FP32 kernel; nc = nfft / 2 (256 or 512)
+int launch_frontend_pk(int nc, const FrontendArgs& a, int grid, hipStream_t s);
+
+}  // namespace tcr

@@ -180,16 +180,22 @@ def test_every_kernel_path_agrees(hip_lib):
     labels = Cm.to_dev(hip_lib, np.tile(fx["labels"], (40, 1)))
     net = Cm.make_net(hip_lib, "TCResNet8", 1.0, fe.n_frames, p, s)
     try:
-        feat0 = fe(wav).clone()
-        for v in (1, 2, 3, 4):
+        feat0 = fe(wav).clone()                                 # default: packed-FP32 kernel
+        hip_lib.tcr_tune(1, 1)
+        feat1 = fe(wav).clone()                                 # scalar-FP32 kernel
+        assert (feat1 - feat0).abs().max() < 2e-4               # (different rounding order in the real-FFT split)
+        for v in (2, 3, 4):                                     # its scheduling variants are bit-exact among themselves
             hip_lib.tcr_tune(1, v)
-            assert torch.equal(fe(wav), feat0), f"front-end variant {v}"
+            assert torch.equal(fe(wav), feat1), f"front-end variant {v}"
+        hip_lib.tcr_tune(1, 5)
+        assert torch.equal(fe(wav), feat0)
         hip_lib.tcr_tune(1, 0)
         base, _ = net.forward_infer(feat0)
         assert np.abs(base[:4].cpu().numpy() - fx["eval_logits"]).max() < Cm.LOGIT_TOL
         results = {}
         for name, knobs in (("per-layer mfma", {3: 1}), ("per-layer mfma, LDS image", {3: 1, 2: 1}), ("per-layer valu", {3: 1, 0: 1}),
-                            ("fused g=3", {4: 3}), ("fused g=8", {4: 8})):
+                            ("fused g=3", {4: 3}), ("fused g=4, 4 waves", {4: 4, 5: 404}), ("fused, features staged in LDS", {3: 2}),
+                            ("fused g=8, 16 waves, ring 8", {4: 8, 5: 816})):
             for k, v in knobs.items():
                 hip_lib.tcr_tune(k, v)
             results[name] = net.forward_infer(feat0)[0].clone()
@@ -210,5 +216,5 @@ def test_every_kernel_path_agrees(hip_lib):
         hip_lib.tcr_tune(0, 0)
         assert (grads[0] - grads[1]).abs().max() < 2e-4 * max(1.0, float(grads[0].abs().max()))
     finally:
-        for k in range(5):
+        for k in range(6):
             hip_lib.tcr_tune(k, 0)
