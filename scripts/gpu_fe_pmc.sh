@@ -14,6 +14,6 @@ import csv, glob, collections
 for f in sorted(glob.glob("$OUT/v*_p*/p_counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "frontend_kernel" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "frontend_" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f.split("/")[-2], {k: round(sum(v)/len(v)) for k, v in agg.items()})
 PY
