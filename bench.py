@@ -260,6 +260,31 @@ def main():
         out["train_3010"] = {"value": round(world * B * tsteps / tdt2, 1), "unit": "utterances/s", "ms_per_step": round(tdt2 / tsteps * 1e3, 4),
                              "steps": tsteps, "workload": "TCResNet8-1.0 train step, 98x40 MFCC (30/10 ms), batch 4096/GPU"}
 
+        # ---------------- input stage: PCM16 -> shift -> background mix -> clip, batch 4096 ----------------
+        lib = T._lib.get()
+        gen = torch.Generator(device=dev).manual_seed(7 + rank)
+        pcm = torch.randint(-32768, 32768, (B * 16000,), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
+        bgp = torch.randint(-32768, 32768, (6 * 60 * 16000,), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
+        clip_off = (torch.arange(B, device=dev, dtype=torch.int64) * 16000).contiguous()
+        clip_len = torch.full((B,), 16000, device=dev, dtype=torch.int32)
+        shift = torch.randint(-1600, 1600, (B,), generator=gen, device=dev, dtype=torch.int32)
+        bg_off = torch.randint(0, 6 * 60 * 16000 - 16000, (B,), generator=gen, device=dev, dtype=torch.int64)
+        mixed = torch.rand((B,), generator=gen, device=dev) < 0.8
+        bg_vol = (torch.rand((B,), generator=gen, device=dev) * 0.1 * mixed).contiguous()
+        aug_out = torch.empty((B, 16000), device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        def aug():
+            lib.check(lib.tcr_augment_fwd(pcm.data_ptr(), clip_off.data_ptr(), clip_len.data_ptr(), shift.data_ptr(), bgp.data_ptr(),
+                                          bg_off.data_ptr(), bg_vol.data_ptr(), B, 16000, aug_out.data_ptr(), stream), "tcr_augment_fwd")
+
+        dta = timed(aug, args.steps, args.warmup, dist_on)
+        aug_bytes = B * 16000 * (2 + 4) + int(mixed.sum().item()) * 16000 * 2
+        out["augment"] = {"value": round(world * B * args.steps / dta, 1), "unit": "utterances/s", "ms_per_step": round(dta / args.steps * 1e3, 4),
+                          "hbm_gbs": round(aug_bytes / (dta / args.steps) / 1e9, 1), "hbm_frac": round(aug_bytes / (dta / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                          "algorithmic_bytes_per_launch": aug_bytes,
+                          "workload": "tcr_augment_fwd: int16 PCM -> float, +-1600-sample shift, background mix (80 % of utterances), clip; batch 4096/GPU"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -235,6 +235,25 @@ int tcr_adam_step(float* params, const float* grads, float* m, float* v, int64_t
 int tcr_l2_loss(const float* params, int64_t n_decay, float weight_decay, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Input stage: PCM decode + crop/pad + time shift + background mix            */
+/* ------------------------------------------------------------------------------------------ */
+/* Batched device form of contrib_audio.decode_wav(desired_samples) + _shift_audio + _mix_background
+ * (datasets/augmentation_factory.py:30-211; mapped per element by AudioDataWrapper._parse_function,
+ * datasets/audio_data_wrapper.py:37-58).  The random draws of the reference's graph are inputs:
+ *   pcm        int16 pool holding every clip (mono, already at sample_rate);
+ *   clip_off   [batch] first sample of each utterance's clip in the pool;
+ *   clip_len   [batch] decoded samples of the clip (0 = the empty filename of a "silent" sample); longer clips are
+ *              cropped, shorter ones zero-padded to desired_samples (decode_wav).  NULL: every clip has desired_samples;
+ *   shift      [batch] time_shift_amount in samples, + delays the audio (zero fill, _shift_audio :104-141); NULL: 0;
+ *   background int16 pool of the background-noise recordings; bg_off [batch] first sample of the random crop;
+ *   bg_vol     [batch] background_volume (0 = not mixed: not read); NULL: no mixing at all;
+ *   out        [batch][desired_samples] float32 = clip(background / 32768 * bg_vol + foreground, -1, 1)  (:92-95).
+ * One IEEE multiply and one IEEE add per sample, like tf.multiply / tf.add: results are bit-exact. */
+int tcr_augment_fwd(const int16_t* pcm, const int64_t* clip_off, const int32_t* clip_len, const int32_t* shift,
+                    const int16_t* background, const int64_t* bg_off, const float* bg_vol, int batch,
+                    int desired_samples, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Instrumentation                                                                             */
 /* ------------------------------------------------------------------------------------------ */
 /* Name of the n-th kernel family in this library (NULL past the end); used by bench.py to match

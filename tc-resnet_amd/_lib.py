@@ -87,6 +87,7 @@ _PROTOTYPES = {
     "tcr_dscnn_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(TensorInfo)]),
     "tcr_dscnn_workspace_bytes": (C.c_size_t, [_P, C.c_int]),
     "tcr_dscnn_forward_infer": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P, _P, _P]),
+    "tcr_augment_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "tcr_dscnn_train_workspace_bytes": (C.c_size_t, [_P, C.c_int]),
     "tcr_dscnn_forward_train": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, C.c_size_t, _P, _P, _P, _P]),
     "tcr_dscnn_backward": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P, _P]),

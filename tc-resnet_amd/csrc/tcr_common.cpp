@@ -43,10 +43,11 @@ extern "C" const char* tcr_last_error(void) { return tcr::g_err; }
 
 extern "C" const char* tcr_kernel_name(int index) {
     static const char* names[] = {
-        "frontend_kernel", "conv_fwd_kernel", "conv_mfma_kernel", "conv1x1_mfma_kernel", "head_fwd_kernel",
+        "frontend_pk_kernel", "net_fused_kernel", "augment_kernel", "frontend_kernel", "conv_fwd_kernel", "conv_mfma_kernel", "conv1x1_mfma_kernel", "head_fwd_kernel",
         "bn_finalize_kernel", "bn_apply_kernel", "head_bwd_kernel", "bn_bwd_reduce_kernel",
         "bn_bwd_apply_kernel", "conv_dgrad_kernel", "conv_wgrad_mfma_kernel", "wgrad_reduce_kernel",
-        "sgd_momentum_kernel", "adam_kernel", "l2_loss_kernel",
+        "sgd_momentum_kernel", "adam_kernel", "l2_loss_kernel", "pw_wgrad_lds_kernel", "dscnn_conv1_kernel",
+        "dscnn_depthwise_kernel", "dscnn_dw_dgrad_kernel", "dscnn_dw_wgrad_kernel", "dscnn_conv1_wgrad_kernel",
     };
     const int n = (int)(sizeof(names) / sizeof(names[0]));
     return (index >= 0 && index < n) ? names[index] : nullptr;

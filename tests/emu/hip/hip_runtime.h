@@ -305,6 +305,9 @@ static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 static inline float min(float a, float b) { return fminf(a, b); }
 static inline float max(float a, float b) { return fmaxf(a, b); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+// round-to-nearest single operations that the compiler must not contract into an fma
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
