@@ -135,6 +135,8 @@ def main():
     value = world * B * args.steps / dt
     fe_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(args.warmup, args.warmup + args.steps)) / args.steps
     net_ms = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.warmup, args.warmup + args.steps)) / args.steps
+    per_step = sorted(ev[3 * i].elapsed_time(ev[3 * i + 2]) for i in range(args.warmup, args.warmup + args.steps))
+    pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4)
 
     w = WORK["4020"]
     # dominant kernel = the fused front-end (one launch per step): waveform read once, [40][49] tile written once
@@ -147,7 +149,8 @@ def main():
         roof = {"bound": "mfma", "achieved": round(fe_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fp_frac, 4)}
     else:
         roof = {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
-    roof.update({"traffic": None, "kernel": "frontend_pk_kernel<512>", "kernel_ms": round(fe_ms, 4),
+    traffic, traffic_src = pmc_traffic("frontend_pk_kernel<512>")
+    roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": "frontend_pk_kernel<512>", "kernel_ms": round(fe_ms, 4),
                  "note": "f32 VALU pipe; its 157.3 TFLOP/s peak equals the exact-f32 MFMA peak. HIP-event-bracketed launch on the "
                          "launch stream, inside the timed region",
                  "hbm_gbs": round(fe_gbs, 1), "hbm_frac": round(hbm_frac, 4), "fp32_tflops": round(fe_tf, 3), "fp32_frac": round(fp_frac, 4),
@@ -161,6 +164,7 @@ def main():
                    "global_batch": world * B, "parallelism": f"dp{world} (utterance shards, no collective)"},
         "roofline": roof,
         "phases_ms": {"frontend": round(fe_ms, 4), "net": round(net_ms, 4)},
+        "step_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
         "whole_path_fp32_frac": round(whole_tf / FP32_PEAK_TFLOPS, 4),
         "whole_path_hbm_frac": round(value / world * 64048 / 1e9 / HBM_PEAK_GBS, 4),
     }
@@ -291,6 +295,22 @@ def main():
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (scripts/gpu_prof.sh ->
+    profiles/*_pmc.csv): FETCH_SIZE x 2 (gfx950 counts 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE,
+    both in KiB.  None when no profile is committed."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.csv")), reverse=True):
+        vals = {}
+        for r in csv.DictReader(open(path)):
+            if r["kernel"] == kernel and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[r["counter"]] = float(r["mean_per_launch"])
+        if len(vals) == 2:
+            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.join("profiles", os.path.basename(path))
+    return None, None
 
 
 def cpu_baseline():

@@ -64,8 +64,11 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s);
 int launch_conv_mfma(int k, int stride, const ConvArgs& a, int epi, hipStream_t s);
 // dx = dgrad of a (k, stride) conv, computed as stride-1 MFMA convs over dy with re-arranged weights (scratch `wt`);
 // returns 1 when the shape is not covered
+// wt_ready: `wt` already holds the re-arranged weights (launch_dgrad_weights_multi)
 int launch_conv_dgrad_mfma(int k, int stride, int pad_lo, const float* w, float* wt, const float* dy, float* dx, const float* add,
-                           const float* add_mask, int add_bcast, int batch, int cin, int cout, int tin, int tout, hipStream_t s);
+                           const float* add_mask, int add_bcast, int batch, int cin, int cout, int tin, int tout, hipStream_t s,
+                           bool wt_ready = false);
+bool conv_dgrad_mfma_covers(int k, int stride, int cout);
 int launch_conv_mfma_with_down(const ConvArgs& a, const float* w_down, float* y_down, const float* scale_down,
                                const float* shift_down, int pad_lo, int epi, hipStream_t s);
 size_t wgrad_partial_floats(int k, int cin, int cout, int batch);
@@ -74,6 +77,34 @@ int launch_wgrad_reduce(const float* partial, float* dw, int nchunk, int k, int 
                         int cout_all, int co_base, hipStream_t s);
 int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
                       int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s);
+// Training engines that give every layer its own partial-slab scratch launch only the split-K kernel per layer
+// (launch_conv_wgrad_partial) and sum all layers' slabs in ONE launch at the end of backward (launch_wgrad_reduce_multi);
+// likewise the re-arranged data-gradient weights of every layer are produced by one launch up front.
+constexpr int kMultiMax = 64;        // >= 1 + 3 * TCR_MAX_BLOCKS conv layers
+struct WgradReduceEntry {
+    const float* partial;
+    float* dw;
+    int nchunk, k, cin, cout, cin_pad, cout_pad;
+};
+struct WgradReduceMulti {
+    int n;
+    WgradReduceEntry e[kMultiMax];
+};
+bool conv_wgrad_deferrable(int k, int cin, int cout);         // single slab (Cout <= 80), slab kernel
+int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, const float* dy, float* scratch, int batch, int cin, int cout,
+                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s);
+WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const float* scratch, float* dw);
+int launch_wgrad_reduce_multi(const WgradReduceMulti& m, hipStream_t s);
+struct DgradWeightsEntry {
+    const float* w;
+    float* wt;
+    int k, cin, cout, stride, pad_lo;
+};
+struct DgradWeightsMulti {
+    int n;
+    DgradWeightsEntry e[kMultiMax];
+};
+int launch_dgrad_weights_multi(const DgradWeightsMulti& m, hipStream_t s);
 
 // ---- fused.hip : whole-network eval forward, activations resident in LDS ---------------------
 constexpr int kFusedMaxLayers = 32;

@@ -332,11 +332,11 @@ int launch_conv_mfma(int k, int stride, const ConvArgs& a, int epi, hipStream_t 
 // For each output phase r = tin mod S this is a stride-1 convolution over dy:
 //   dx[ci][S*u + r] = sum_{i'} sum_co dy[co][u + i' + d_min] * Wr[i'][co][ci],   Wr[i'] = W[r + pad_lo - S*(i' + d_min)]^T
 // so the forward implicit-GEMM kernel is reused with re-arranged weights, an output stride of S and offset r.
-__global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int k, int cin, int cout,
-                                                            int stride, int pad_lo) {
+__device__ __forceinline__ void dgrad_weights_body(const float* __restrict__ w, float* __restrict__ wt, int k, int cin, int cout,
+                                                   int stride, int pad_lo, int first, int step) {
     // wt holds the phases back to back: phase r has taps j = j0_r, j0_r + S, ... ; entry [i'][co][ci]
     const int total = k * cin * cout;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    for (int idx = first; idx < total; idx += step) {
         const int ci = idx % cin;
         const int rest = idx / cin;
         const int co = rest % cout;
@@ -354,12 +354,37 @@ __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restr
     }
 }
 
+__global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int k, int cin, int cout,
+                                                            int stride, int pad_lo) {
+    dgrad_weights_body(w, wt, k, cin, cout, stride, pad_lo, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+// every layer of a network in one launch: blockIdx.y = layer
+__global__ __launch_bounds__(256) void dgrad_weights_multi_kernel(const DgradWeightsMulti m) {
+    const DgradWeightsEntry e = m.e[blockIdx.y];
+    dgrad_weights_body(e.w, e.wt, e.k, e.cin, e.cout, e.stride, e.pad_lo, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+int launch_dgrad_weights_multi(const DgradWeightsMulti& m, hipStream_t s) {
+    if (m.n <= 0) return TCR_OK;
+    int most = 0;
+    for (int i = 0; i < m.n; ++i) most = max(most, m.e[i].k * m.e[i].cin * m.e[i].cout);
+    hipLaunchKernelGGL(dgrad_weights_multi_kernel, dim3(min(ceil_div(most, 256), 64), m.n), dim3(256), 0, s, m);
+    return check_launch("dgrad_weights_multi_kernel");
+}
+
+bool conv_dgrad_mfma_covers(int k, int stride, int cout) {
+    return !(cout % 4 != 0 || stride < 1 || stride > 2 || k > 9) && tune_get(TCR_TUNE_CONV_PATH) != 1;
+}
+
 int launch_conv_dgrad_mfma(int k, int stride, int pad_lo, const float* w, float* wt, const float* dy, float* dx, const float* add,
-                           const float* add_mask, int add_bcast, int batch, int cin, int cout, int tin, int tout, hipStream_t s) {
-    if (cout % 4 != 0 || stride < 1 || stride > 2 || k > 9) return 1;
-    if (tune_get(TCR_TUNE_CONV_PATH) == 1) return 1;
-    hipLaunchKernelGGL(dgrad_weights_kernel, dim3(ceil_div(k * cin * cout, 256)), dim3(256), 0, s, w, wt, k, cin, cout, stride, pad_lo);
-    TCR_TRY(check_launch("dgrad_weights_kernel"));
+                           const float* add_mask, int add_bcast, int batch, int cin, int cout, int tin, int tout, hipStream_t s,
+                           bool wt_ready) {
+    if (!conv_dgrad_mfma_covers(k, stride, cout)) return 1;
+    if (!wt_ready) {
+        hipLaunchKernelGGL(dgrad_weights_kernel, dim3(ceil_div(k * cin * cout, 256)), dim3(256), 0, s, w, wt, k, cin, cout, stride, pad_lo);
+        TCR_TRY(check_launch("dgrad_weights_kernel"));
+    }
     int base = 0;
     for (int r = 0; r < stride; ++r) {
         const int res_mod = (r + pad_lo) % stride;
@@ -491,10 +516,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradArgs a)
 
 // dw[j][ci][co] = sum_chunk partial[chunk][j][ci][co].  Four lanes per output walk interleaved chunk subsets and are
 // combined with a fixed two-step shuffle tree, so the result is bitwise reproducible.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                           int nchunk, int k, int cin, int cout, int cin_pad, int cout_pad,
-                                                           int cout_all, int co_base) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, float* __restrict__ dw,
+                                                  int nchunk, int k, int cin, int cout, int cin_pad, int cout_pad,
+                                                  int cout_all, int co_base) {
     const int total = k * cin * cout;
+    if ((int)(blockIdx.x * 256) >= total * 4) return;
     const size_t slab = (size_t)k * cin_pad * cout_pad;
     const int part = threadIdx.x & 3;
     const int i = min((int)((blockIdx.x * 256 + threadIdx.x) >> 2), total - 1);
@@ -509,6 +535,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     if (live && part == 0) dw[((size_t)j * cin + ci) * cout_all + co_base + co] = s;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int nchunk, int k, int cin, int cout, int cin_pad, int cout_pad,
+                                                           int cout_all, int co_base) {
+    wgrad_reduce_body(partial, dw, nchunk, k, cin, cout, cin_pad, cout_pad, cout_all, co_base);
+}
+
+// the slabs of every layer of a network in one launch: blockIdx.y = layer
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradReduceMulti m) {
+    const WgradReduceEntry e = m.e[blockIdx.y];
+    wgrad_reduce_body(e.partial, e.dw, e.nchunk, e.k, e.cin, e.cout, e.cin_pad, e.cout_pad, e.cout, 0);
+}
+
+int launch_wgrad_reduce_multi(const WgradReduceMulti& m, hipStream_t s) {
+    if (m.n <= 0) return TCR_OK;
+    int most = 0;
+    for (int i = 0; i < m.n; ++i) most = max(most, m.e[i].k * m.e[i].cin * m.e[i].cout);
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(ceil_div(most * 4, 256), m.n), dim3(256), 0, s, m);
+    return check_launch("wgrad_reduce_multi_kernel");
 }
 
 int launch_wgrad_reduce(const float* partial, float* dw, int nchunk, int k, int cin, int cout, int cin_pad, int cout_pad,
@@ -677,6 +723,39 @@ static int launch_wgrad_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s)
         default: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<K, 5>), grid, dim3(256), 0, s, a); break;
     }
     return check_launch("conv_wgrad_mfma_kernel");
+}
+
+bool conv_wgrad_deferrable(int k, int cin, int cout) { return (k == 9 || k == 3 || k == 1) && cout <= 80 && !(k == 1 && cin > 80 && cout > 80); }
+
+WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const float* scratch, float* dw) {
+    WgradReduceEntry e;
+    e.partial = scratch; e.dw = dw; e.k = k; e.cin = cin; e.cout = cout;
+    e.cin_pad = ceil_div(cin, 16) * 16; e.cout_pad = ceil_div(cout, 16) * 16;
+    e.nchunk = ceil_div(batch, ceil_div(batch, wgrad_chunks(batch)));
+    return e;
+}
+
+int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, const float* dy, float* scratch, int batch, int cin, int cout,
+                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s) {
+    if (!conv_wgrad_deferrable(k, cin, cout)) { set_error("conv wgrad: shape %dx1 %d->%d cannot defer its reduction", k, cin, cout); return TCR_ERR_ARG; }
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.partial = scratch;
+    a.batch = batch; a.cin = cin; a.cout = cout; a.cout_all = cout; a.co_base = 0;
+    a.cin_pad = ceil_div(cin, 16) * 16;
+    a.cout_pad = ceil_div(cout, 16) * 16;
+    a.tpi = tpi; a.tout = tout; a.tpo = tpo; a.stride = stride;
+    a.xoff = kHalo - pad_lo;
+    const int nchunk = wgrad_chunks(batch);
+    a.utt_per_block = ceil_div(batch, nchunk);
+    const dim3 grid(ceil_div(batch, a.utt_per_block), a.cin_pad / 16);
+    const int nco = a.cout_pad / 16;
+    int rc;
+    if (k == 9) rc = launch_wgrad_k<9>(a, nco, grid, s);
+    else if (k == 3) rc = launch_wgrad_k<3>(a, nco, grid, s);
+    else rc = launch_wgrad_k<1>(a, nco, grid, s);
+    TCR_TRY(rc);
+    if (entry) *entry = conv_wgrad_entry(k, cin, cout, batch, scratch, nullptr);
+    return TCR_OK;
 }
 
 // dw: [K][Cin][Cout]; scratch: wgrad_partial_floats(...) floats.  Output channels are processed in

@@ -54,6 +54,7 @@ struct Workspace {
     std::vector<int64_t> dyb;               // grad wrt raw conv output (train)
     std::vector<int64_t> gact;              // grad wrt activation per conv layer (train)
     std::vector<int64_t> mean, invstd;      // saved batch statistics (train)
+    std::vector<int64_t> wg, wtl;           // per-layer wgrad partial slabs / re-arranged dgrad weights (train)
     int64_t partial = -1, sums = -1, kcoef = -1;
     int64_t dropped = -1, dscale = -1, dlogits = -1, loss_utt = -1, dpool = -1;
     int64_t wgrad_scratch = -1, wt = -1, fc_partial = -1;
@@ -66,7 +67,7 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
     auto take = [&](int64_t n) { int64_t at = o; o += align_up(n, 64); return at; };
     const size_t nl = net.layers.size();
     w.act.assign(nl, -1); w.raw.assign(nl, -1); w.dyb.assign(nl, -1); w.gact.assign(nl, -1);
-    w.mean.assign(nl, -1); w.invstd.assign(nl, -1);
+    w.mean.assign(nl, -1); w.invstd.assign(nl, -1); w.wg.assign(nl, -1); w.wtl.assign(nl, -1);
     int64_t ss = 0;
     for (const ConvLayer& l : net.layers) if (l.bn) ss += 2 * l.c_pad;
     w.ss = take(ss);
@@ -83,6 +84,8 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
             w.gact[i] = take(n);
             w.mean[i] = take(l.c_pad);
             w.invstd[i] = take(l.c_pad);
+            w.wg[i] = take((int64_t)wgrad_partial_floats(l.k, l.cin, l.cout, batch));
+            w.wtl[i] = take((int64_t)l.k * l.cin * l.cout);
         }
         cmax = l.cout > cmax ? l.cout : cmax;
         const int64_t wsz = (int64_t)l.k * l.cin * l.cout;
@@ -668,11 +671,15 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     TCR_TRY(launch_bn_bwd_apply(a, c.s));
     // weight gradient
     const float* x = layer_input(net, c.w, c.base, c.feat, l);
-    TCR_TRY(launch_conv_wgrad(l.k, l.stride, l.pad_lo, x, dy, grads + l.w_off, c.base + c.w.wgrad_scratch,
-                              c.batch, l.cin, l.cout, tpi, l.tout, tp, c.s));
+    if (conv_wgrad_deferrable(l.k, l.cin, l.cout))       // slabs summed for all layers at once at the end of backward
+        TCR_TRY(launch_conv_wgrad_partial(l.k, l.stride, l.pad_lo, x, dy, c.base + c.w.wg[u.li], c.batch, l.cin, l.cout, tpi, l.tout, tp,
+                                          nullptr, c.s));
+    else
+        TCR_TRY(launch_conv_wgrad(l.k, l.stride, l.pad_lo, x, dy, grads + l.w_off, c.base + c.w.wgrad_scratch,
+                                  c.batch, l.cin, l.cout, tpi, l.tout, tp, c.s));
     if (l.in_act < 0) return TCR_OK;        // no gradient flows into the features
     // data gradient into gact[in_act]; the shortcut branch of the block adds its contribution in the same pass
-    float* wt = c.base + c.w.wt;
+    float* wt = c.base + c.w.wtl[u.li];       // filled for every layer by the first backward stage
     float* dx = c.base + c.w.gact[l.in_act];
     const float* add = nullptr;
     const float* add_mask = nullptr;
@@ -689,9 +696,10 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     }
     {
         const int rc = launch_conv_dgrad_mfma(l.k, l.stride, l.pad_lo, c.params + l.w_off, wt, dy, dx, add, add_mask, add_bcast,
-                                              c.batch, l.cin, l.cout, l.tin, l.tout, c.s);
+                                              c.batch, l.cin, l.cout, l.tin, l.tout, c.s, true);
         if (rc != 1) return rc;
     }
+    wt = c.base + c.w.wt;
     TCR_TRY(launch_transpose_weights(c.params + l.w_off, wt, l.k, l.cin, l.cout, c.s));
     DgradArgs d;
     std::memset(&d, 0, sizeof(d));
@@ -747,9 +755,29 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
                                     grads + net->layers[net->fc].w_off, batch, net->feat_c, nc, c.s));
             TCR_TRY(launch_head_bwd(c.base + c.w.dlogits, params + net->layers[net->fc].w_off, c.base + c.w.dscale,
                                     c.base + c.w.dpool, batch, net->feat_c, nc, c.s));
+            // re-arranged (phase-major, transposed) weights of every data-gradient conv, one launch
+            DgradWeightsMulti dm;
+            dm.n = 0;
+            for (int li : order) {
+                const ConvLayer& l = net->layers[li];
+                if (l.in_act < 0 || !conv_dgrad_mfma_covers(l.k, l.stride, l.cout) || dm.n >= kMultiMax) continue;
+                dm.e[dm.n++] = {params + l.w_off, c.base + c.w.wtl[li], l.k, l.cin, l.cout, l.stride, l.pad_lo};
+            }
+            TCR_TRY(launch_dgrad_weights_multi(dm, c.s));
         }
         if (st > 0) TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, order[st - 1], dpool), grads, dpool));
         if (st < nu) TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, order[st], dpool)));
+        if (st == nu) {         // every layer's split-K slabs -> dW, one launch
+            WgradReduceMulti rm;
+            rm.n = 0;
+            for (int li : order) {
+                const ConvLayer& l = net->layers[li];
+                if (!conv_wgrad_deferrable(l.k, l.cin, l.cout)) continue;
+                if (rm.n == kMultiMax) { TCR_TRY(launch_wgrad_reduce_multi(rm, c.s)); rm.n = 0; }
+                rm.e[rm.n++] = conv_wgrad_entry(l.k, l.cin, l.cout, batch, c.base + c.w.wg[li], grads + l.w_off);
+            }
+            TCR_TRY(launch_wgrad_reduce_multi(rm, c.s));
+        }
     }
     return TCR_OK;
 }
