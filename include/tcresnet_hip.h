@@ -267,7 +267,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_NET_FUSED = 3,   /* eval forward: 0 one fused LDS-resident kernel for the whole net (default), 1 per-layer kernels, 2 fused with the features copied to LDS */
        TCR_TUNE_FUSED_GROUP = 4, /* utterances per workgroup group of the fused kernel (0: largest that fits 64 KB of LDS) */
        TCR_TUNE_FUSED_WAVES = 5, /* fused kernel: waves per workgroup (4, 8, 16) + 100 * weight-ring depth (4, 8, 16); 0: default */
-       TCR_TUNE_COUNT = 6 };
+       TCR_TUNE_CONV_KSPLIT = 6, /* train-mode conv / data-gradient: waves sharing one 32-position group's reduction (0 auto, 1, 2, 4) */
+       TCR_TUNE_COUNT = 7 };
 int tcr_tune(int knob, int value);
 
 #ifdef __cplusplus

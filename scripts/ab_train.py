@@ -28,14 +28,16 @@ def timeit(fn, n=20, warm=5):
     return ts[len(ts) // 2]
 
 for name, ch in () if os.environ.get("AB_DS_ONLY") else (("TCResNet8", [16, 24, 32, 48]), ("TCResNet14", [24, 36, 36, 48, 48, 72, 72])):
-    for cap in (0,):
+    for cap in (0, 1, 2, 4):
         for unroll in (0,):
+            lib.tcr_tune(6, cap)
             net = T.TCResNet(name, ch, 40, fe.n_frames, 12, device=dev)
             net.init_xavier(0)
             def train():
                 net.forward_train(feat, lab, keep_prob=0.5, seed=1); net.backward(); net.sgd_momentum_step(0.1, 0.9, 0.001)
-            print(f"{name} cap={cap} unroll={unroll}: {timeit(train):9.1f} us", flush=True)
+            print(f"{name} ksplit={cap}: {timeit(train):9.1f} us", flush=True)
             del net
+lib.tcr_tune(6, 0)
 fe3 = T.Frontend(window_size_samples=640, window_stride_samples=320, num_mfccs=10, device=dev)
 feat3 = fe3(wav)
 ds = T.DSCNN("L", fe3.n_frames, 10, 12, device=dev); ds.init_xavier(0)

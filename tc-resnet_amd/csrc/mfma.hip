@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
                 }
                 float* o = a.y + ((size_t)n * a.cout + co) * a.tpo + kHalo + t;
                 o[0] = v;
-                if (t == 0) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
-                if (t == a.tout - 1) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+                if (EPI == MF_AFFINE) {     // (raw outputs: see conv_mfma_store)
+                    if (t == 0) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
+                    if (t == a.tout - 1) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+                }
             }
     }
 }
@@ -148,7 +150,10 @@ __device__ __forceinline__ void conv_mfma_store(const f32x4 (&acc)[MT][2], float
                 }
                 float* dst = y + o;
                 dst[0] = v;
-                if (ex.ostride == 1) {      // (strided data-gradient phases leave the halo alone: nothing reads it)
+                // Only the eval-mode activations are read through their zero halo by the next conv.  Raw train-mode
+                // outputs and data gradients go through bn_apply / bn_bwd_apply, which rewrite whole rows (halo = 0)
+                // and read interiors only -- skipping the halo stores there also keeps the epilogue code short.
+                if (EPI == EPI_AFFINE) {
                     if (t == 0) { dst[-4] = 0.f; dst[-3] = 0.f; dst[-2] = 0.f; dst[-1] = 0.f; }
                     if (t == tout - 1) { dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f; dst[4] = 0.f; }
                 }
@@ -279,6 +284,143 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a, const 
     }
 }
 
+// K-split form for launches that cannot fill the chip (training at the late layers: a few hundred to a few thousand
+// 32-position waves on 1024 SIMDs, each walking K * Cin / 4 dependent-latency steps): a workgroup is ONE 32-position
+// group and KS waves that take every KS-th chunk of the reduction; the partial accumulators are added through LDS in a
+// fixed order (wave 0 + wave 1 + ...), so the result is reproducible -- though not bitwise the same sum as KS = 1.
+// Raw epilogue only (train-mode forward and the data gradient), activations straight from global memory.
+template <int K, int S, int MT, bool DOWN, int KS>
+__global__ __launch_bounds__(64 * KS) void conv_mfma_ksplit_kernel(const ConvArgs a, const ConvDownArgs d) {
+    constexpr int CH = 4;
+    float* red = reinterpret_cast<float*>(dyn_lds());       // [KS - 1][MT * 8][64]
+    const int lane = threadIdx.x & 63;
+    // (readfirstlane: tells the compiler the wave index is uniform, so the chunk bookkeeping below runs on the scalar unit)
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int p_base = blockIdx.x * 32;
+    const int wg_p1 = min(p_base + 32, a.npos);
+    const int n0 = p_base / a.tout;
+    const int row = a.cin * a.tpi;
+    const int C4 = a.cin >> 2;
+    // Per-lane operand pointers at (tap 0, channel quad 0); a K-step adds a wave-uniform offset.  Out-of-range output
+    // channels / channel quads are CLAMPED, not predicated: the products land in rows that are never stored or in steps
+    // that are never multiplied, and the loop stays free of per-load masks.
+    const float* xp[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int p = min(p_base + nt * 16 + r, wg_p1 - 1);
+        const int n = p / a.tout, t = p - n * a.tout;
+        xp[nt] = a.x + (size_t)n * row + t * S + a.xoff + q * a.tpi;
+    }
+    const int cot0 = blockIdx.y * MT;
+    const float* wp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wp[m] = a.w + q * a.cout + min((cot0 + m) * 16 + r, a.cout - 1);
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tap_stride = a.cin * a.cout;
+    const int step_stride = 4 * a.cout;
+    const int xq = 4 * a.tpi;
+    // chunk = CH consecutive channel quads of one tap; woff / xoff: uniform float offsets of its first K-step
+    auto load_chunk = [&](const float* const (&wq)[MT], int woff, int xoff, int c0, float (&af)[CH][MT + 2]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int ci = min(c0 + i, C4 - 1) - c0;                // (tail: re-read the last quad; not multiplied)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[i][m] = wq[m][woff + ci * step_stride];
+            af[i][MT] = xp[0][xoff + ci * xq];
+            af[i][MT + 1] = xp[1][xoff + ci * xq];
+        }
+    };
+    auto mma_chunk = [&](int c0, const float (&af)[CH][MT + 2], f32x4 (&ac)[MT][2]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (c0 + i < C4) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    ac[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][m], af[i][MT], ac[m][0], 0, 0, 0);
+                    ac[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][m], af[i][MT + 1], ac[m][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // partial accumulators of waves 1 .. KS-1 -> LDS -> added by wave 0 in wave order
+    auto reduce = [&](f32x4 (&ac)[MT][2]) {
+        if (KS == 1) return;
+        if (ks > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) red[(((ks - 1) * MT + m) * 8 + nt * 4 + reg) * 64 + lane] = ac[m][nt][reg];
+        }
+        __syncthreads();
+        if (ks == 0) {
+            for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) ac[m][nt][reg] += red[(((k2 - 1) * MT + m) * 8 + nt * 4 + reg) * 64 + lane];
+        }
+        __syncthreads();
+    };
+    const int cpj = (C4 + CH - 1) / CH;
+    const int nchunks = K * cpj;
+    // this wave's chunks: ks, ks + KS, ...; (tap j, chunk-in-tap cq) advance with scalar adds
+    int j = 0, cq = ks;
+    auto norm = [&]() { while (cq >= cpj) { cq -= cpj; ++j; } };
+    norm();
+    float afA[CH][MT + 2], afB[CH][MT + 2];
+    if (ks < nchunks) load_chunk(wp, j * tap_stride + cq * CH * step_stride, j + cq * CH * xq, cq * CH, afA);
+    for (int ch = ks; ch < nchunks; ch += 2 * KS) {
+        const int cqa = cq;
+        cq += KS; norm();
+        const int cqb = cq;
+        if (ch + KS < nchunks) load_chunk(wp, j * tap_stride + cq * CH * step_stride, j + cq * CH * xq, cq * CH, afB);
+        mma_chunk(cqa * CH, afA, acc);
+        cq += KS; norm();
+        if (ch + 2 * KS < nchunks) load_chunk(wp, j * tap_stride + cq * CH * step_stride, j + cq * CH * xq, cq * CH, afA);
+        if (ch + KS < nchunks) mma_chunk(cqb * CH, afB, acc);
+    }
+    reduce(acc);
+    if (ks == 0) {
+        const ConvStoreExtra ex = {a.ostride > 0 ? a.ostride : 1, a.ooff, a.add, a.add_mask, a.add_bcast};
+        conv_mfma_store<MT, EPI_RAW>(acc, a.y, a.scale, a.shift, a.res, a.relu, cot0, a.cout, a.tout, a.tpo, p_base, wg_p1, r, q, ex);
+    }
+    if (DOWN) {
+        f32x4 acc2[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc2[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* wd[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wd[m] = d.w + q * a.cout + min((cot0 + m) * 16 + r, a.cout - 1);
+        for (int cc = ks * CH; cc < C4; cc += KS * CH) {
+            load_chunk(wd, cc * step_stride, d.tap + cc * xq, cc, afA);
+            mma_chunk(cc, afA, acc2);
+        }
+        reduce(acc2);
+        if (ks == 0) {
+            const ConvStoreExtra ex2 = {1, 0, nullptr, nullptr, 0};
+            conv_mfma_store<MT, EPI_RAW>(acc2, d.y, d.scale, d.shift, nullptr, d.relu, cot0, a.cout, a.tout, a.tpo, p_base, wg_p1, r, q, ex2);
+        }
+    }
+}
+
+template <int K, int S, int MT, bool DOWN>
+static void launch_conv_ksplit(int ks, dim3 grid, const ConvArgs& a, const ConvDownArgs& d, hipStream_t s) {
+    const size_t lds = (size_t)(ks - 1) * MT * 8 * 64 * sizeof(float);
+    if (ks == 4) hipLaunchKernelGGL((conv_mfma_ksplit_kernel<K, S, MT, DOWN, 4>), grid, dim3(256), lds, s, a, d);
+    else hipLaunchKernelGGL((conv_mfma_ksplit_kernel<K, S, MT, DOWN, 2>), grid, dim3(128), lds, s, a, d);
+}
+
 // Returns TCR_OK after launching, or 1 when the shape does not fit this kernel (caller falls back).
 template <int K, int S>
 static int launch_conv_mfma_ks(const ConvArgs& a, const ConvDownArgs* down, int epi, hipStream_t s) {
@@ -299,10 +441,30 @@ static int launch_conv_mfma_ks(const ConvArgs& a, const ConvDownArgs* down, int 
     if (!ldsb) { ppw = 128; lds = 0; while (ppw > 32 && ceil_div(a.npos, ppw) < 1024) ppw /= 2; }
     const int tiles = ceil_div(a.cout, 16);
     const int mt = tiles <= 3 ? tiles : (tiles == 4 ? 2 : (tiles == 5 ? 5 : 3));
-    const dim3 grid(ceil_div(a.npos, ppw), ceil_div(tiles, mt));
-    const dim3 block(ppw * 2);
     ConvDownArgs d;
     if (down) d = *down; else { d.w = nullptr; d.y = nullptr; d.scale = d.shift = nullptr; d.tap = 0; d.relu = 0; }
+    // K-split (raw epilogue = training only; the eval path keeps the single-chain sum that is bitwise the fused kernel's)
+    if (epi == EPI_RAW && !ldsb) {
+        const int groups = ceil_div(a.npos, 32) * ceil_div(tiles, mt);          // 32-position waves of the plain form
+        const int nchunks = K * ceil_div(a.cin >> 2, 4);
+        int ks = tune_get(TCR_TUNE_CONV_KSPLIT);
+        if (ks == 0) ks = groups >= 8192 ? 1 : (groups >= 4096 ? 2 : 4);
+        while (ks > 1 && nchunks < 2 * ks) ks /= 2;
+        if (ks == 2 || ks == 4) {
+            const dim3 kgrid(ceil_div(a.npos, 32), ceil_div(tiles, mt));
+#define TCR_CK(MT_) if (down) launch_conv_ksplit<K, S, MT_, true>(ks, kgrid, a, d, s); else launch_conv_ksplit<K, S, MT_, false>(ks, kgrid, a, d, s)
+            switch (mt) {
+                case 1: TCR_CK(1); break;
+                case 2: TCR_CK(2); break;
+                case 3: TCR_CK(3); break;
+                default: TCR_CK(5); break;
+            }
+#undef TCR_CK
+            return check_launch("conv_mfma_ksplit_kernel");
+        }
+    }
+    const dim3 grid(ceil_div(a.npos, ppw), ceil_div(tiles, mt));
+    const dim3 block(ppw * 2);
 #define TCR_CM3(MT_, EPI_, LB_)                                                                                         \
     if (down) hipLaunchKernelGGL((conv_mfma_kernel<K, S, MT_, EPI_, true, LB_>), grid, block, lds, s, a, d, ppw);       \
     else hipLaunchKernelGGL((conv_mfma_kernel<K, S, MT_, EPI_, false, LB_>), grid, block, lds, s, a, d, ppw)

@@ -208,13 +208,16 @@ def test_every_kernel_path_agrees(hip_lib):
                 assert torch.equal(r, base), name
         # training: MFMA vs VALU conv/dgrad paths give the same gradients up to f32 re-association
         grads = []
-        for path in (0, 1):
+        for path, ksplit in ((0, 0), (1, 0), (0, 1), (0, 2), (0, 4)):
             hip_lib.tcr_tune(0, path)
+            hip_lib.tcr_tune(6, ksplit)
             sd = dict(p); sd.update(s); net.load_state_dict(sd)
             net.forward_train(feat0, labels, keep_prob=0.5, seed=7)
             grads.append(net.backward().clone())
         hip_lib.tcr_tune(0, 0)
-        assert (grads[0] - grads[1]).abs().max() < 2e-4 * max(1.0, float(grads[0].abs().max()))
+        hip_lib.tcr_tune(6, 0)
+        for g in grads[1:]:
+            assert (grads[0] - g).abs().max() < 2e-4 * max(1.0, float(grads[0].abs().max()))
     finally:
-        for k in range(6):
+        for k in range(7):
             hip_lib.tcr_tune(k, 0)
