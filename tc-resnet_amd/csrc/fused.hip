@@ -117,7 +117,8 @@ __global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
     constexpr int NT = NW * 64;
     float* lds = reinterpret_cast<float*>(dyn_lds());
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // uniform: job bookkeeping runs on the scalar unit
     const int r = lane & 15, q = lane >> 4;
 
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {

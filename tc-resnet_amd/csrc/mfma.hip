@@ -609,7 +609,8 @@ struct WgradArgs {
 template <int K, int NCO>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradArgs a) {
     __shared__ float s_acc[K * 16 * NCO * 16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int ci = blockIdx.y * 16 + r;
     const bool civ = ci < a.cin;
@@ -630,19 +631,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradArgs a)
 
     // The reduction index is (utterance, t): the MFMA k dimension holds 4 consecutive t of one utterance
     // (lane group q), so operand addresses advance by plain increments -- no per-step division.
+    // Lean addressing: the utterance base is wave-uniform (scalar registers), the per-lane part is a 32-bit offset that
+    // never changes; no per-load predicates -- steps past the row end multiply dy's ZERO halo (bn_bwd_apply writes it)
+    // with a clamped, finite x.
     const int n_begin = blockIdx.x * a.utt_per_block;
     const int n_end = min(n_begin + a.utt_per_block, a.batch);
+    int doff[NCO];
+#pragma unroll
+    for (int m = 0; m < NCO; ++m) doff[m] = coc[m] * a.tpo + kHalo + q;
+    const int xlane = cic * a.tpi + a.xoff;
+    const int tlast = a.tout - 1;
     for (int n = n_begin + wave; n < n_end; n += 4) {
-        const float* xr = a.x + ((size_t)n * a.cin + cic) * a.tpi + a.xoff + q * a.stride;
-        const float* dr = a.dy + (size_t)n * a.cout_all * a.tpo + kHalo + q;
+        const float* xr = a.x + (size_t)n * a.cin * a.tpi;
+        const float* dr = a.dy + (size_t)n * a.cout_all * a.tpo;
 #pragma unroll 2
         for (int t0 = 0; t0 < a.tout; t0 += 4) {
-            const bool pv = t0 + q < a.tout;
             float bf[NCO], af[K];
 #pragma unroll
-            for (int m = 0; m < NCO; ++m) bf[m] = (pv && cov[m]) ? dr[(size_t)coc[m] * a.tpo + t0] : 0.f;
+            for (int m = 0; m < NCO; ++m) bf[m] = dr[doff[m] + t0];
+            const float* xt = xr + xlane + min(t0 + q, tlast) * a.stride;
 #pragma unroll
-            for (int j = 0; j < K; ++j) af[j] = (pv && civ) ? xr[t0 * a.stride + j] : 0.f;
+            for (int j = 0; j < K; ++j) af[j] = xt[j];
 #pragma unroll
             for (int j = 0; j < K; ++j)
 #pragma unroll
