@@ -56,8 +56,11 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
     }
     const int blk0 = blockIdx.x * a.pos_per_block;
     const int blk1 = min(blk0 + a.pos_per_block, a.npos);
+    const float inv_t = 1.0f / (float)a.t;       // p / t: float multiply + one-step fix-up instead of an integer division
     for (int p = blk0 + threadIdx.x; p < blk1; p += 256) {
-        const int n = p / a.t, t = p - n * a.t;
+        int n = (int)(((float)p + 0.5f) * inv_t);
+        n += (n + 1) * a.t <= p ? 1 : (n * a.t > p ? -1 : 0);
+        const int t = p - n * a.t;
         const size_t base = ((size_t)n * a.c + c0) * a.tp + kHalo + t;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -200,24 +203,33 @@ int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
 
 // a = [relu](y * scale + shift)            (res == nullptr)
 // a = relu(y * scale + shift + res)        (block output, tc_resnet.py:40-41)
+// grid = (ceil(C * Tp / 256), B): one utterance per grid row, so the (channel, frame) split of an index is a 13-bit
+// quotient -- a float multiply with a one-step fix-up instead of the
+// 64-bit integer division a flat index needs (which made these HBM-streaming kernels instruction-bound).
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (int64_t)gridDim.x * 256) {
-        const int tt = (int)(i % a.tp) - kHalo;
-        const int c = (int)((i / a.tp) % a.c);
-        float v = 0.f;
-        if (tt >= 0 && tt < a.t) {
-            v = fmaf(a.y[i], a.scale[c], a.shift[c]);
-            if (a.res) v = fmaxf(v + a.res[i], 0.f);
-            else if (a.relu) v = fmaxf(v, 0.f);
-        }
-        a.out[i] = v;
+    const int per_utt = a.c * a.tp;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= per_utt) return;
+    int c = (int)(((float)j + 0.5f) * a.inv_tp);
+    c += (c + 1) * a.tp <= j ? 1 : (c * a.tp > j ? -1 : 0);
+    const int tt = j - c * a.tp - kHalo;
+    const size_t i = (size_t)blockIdx.y * per_utt + j;
+    float v = 0.f;
+    if (tt >= 0 && tt < a.t) {
+        v = fmaf(a.y[i], a.scale[c], a.shift[c]);
+        if (a.res) v = fmaxf(v + a.res[i], 0.f);
+        else if (a.relu) v = fmaxf(v, 0.f);
     }
+    a.out[i] = v;
 }
 
-int launch_bn_apply(const BnApplyArgs& a, hipStream_t s) {
-    int64_t blocks = ceil_div64(a.total, 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+int launch_bn_apply(const BnApplyArgs& a0, hipStream_t s) {
+    BnApplyArgs a = a0;
+    a.inv_tp = 1.0f / (float)a.tp;
+    const int per_utt = a.c * a.tp;
+    const int batch = (int)(a.total / per_utt);
+    if (per_utt >= (1 << 22) || batch > 65535) { set_error("bn_apply: %d x %d exceeds the launch geometry", batch, per_utt); return TCR_ERR_ARG; }
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ceil_div(per_utt, 256), batch), dim3(256), 0, s, a);
     return check_launch("bn_apply_kernel");
 }
 
@@ -244,26 +256,31 @@ int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
     return check_launch("bn_bwd_finalize_kernel");
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (int64_t)gridDim.x * 256) {
-        const int tt = (int)(i % a.tp) - kHalo;
-        const int64_t row = i / a.tp;           // b * C + c
-        const int c = (int)(row % a.c);
-        float v = 0.f;
-        if (tt >= 0 && tt < a.t) {
-            float dz = a.bcast ? a.da[row] : a.da[i];
-            if (a.m1 && !(a.m1[i] > 0.f)) dz = 0.f;
-            if (a.m2 && !(a.m2[i] > 0.f)) dz = 0.f;
-            v = a.k1[c] * (dz - a.k2[c] - (a.y[i] - a.mean[c]) * a.k3[c]);
-        }
-        a.dy[i] = v;
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {      // (geometry: see bn_apply_kernel)
+    const int per_utt = a.c * a.tp;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= per_utt) return;
+    int c = (int)(((float)j + 0.5f) * a.inv_tp);
+    c += (c + 1) * a.tp <= j ? 1 : (c * a.tp > j ? -1 : 0);
+    const int tt = j - c * a.tp - kHalo;
+    const size_t i = (size_t)blockIdx.y * per_utt + j;
+    float v = 0.f;
+    if (tt >= 0 && tt < a.t) {
+        float dz = a.bcast ? a.da[(size_t)blockIdx.y * a.c + c] : a.da[i];
+        if (a.m1 && !(a.m1[i] > 0.f)) dz = 0.f;
+        if (a.m2 && !(a.m2[i] > 0.f)) dz = 0.f;
+        v = a.k1[c] * (dz - a.k2[c] - (a.y[i] - a.mean[c]) * a.k3[c]);
     }
+    a.dy[i] = v;
 }
 
-int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s) {
-    int64_t blocks = ceil_div64(a.total, 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+int launch_bn_bwd_apply(const BnBwdApplyArgs& a0, hipStream_t s) {
+    BnBwdApplyArgs a = a0;
+    a.inv_tp = 1.0f / (float)a.tp;
+    const int per_utt = a.c * a.tp;
+    const int batch = (int)(a.total / per_utt);
+    if (per_utt >= (1 << 22) || batch > 65535) { set_error("bn_bwd_apply: %d x %d exceeds the launch geometry", batch, per_utt); return TCR_ERR_ARG; }
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(per_utt, 256), batch), dim3(256), 0, s, a);
     return check_launch("bn_bwd_apply_kernel");
 }
 

@@ -190,6 +190,7 @@ struct BnApplyArgs {
     float* out;
     int64_t total;      // B * C * Tp
     int c, t, tp, relu;
+    float inv_tp;       // (set by the launcher)
 };
 
 struct BnBwdFinalizeArgs {
@@ -221,6 +222,7 @@ struct BnBwdApplyArgs {
     float* dy;
     int64_t total;
     int c, t, tp, bcast;
+    float inv_tp;           // (set by the launcher)
 };
 
 int launch_bn_fold(const BnFoldArgs& a, hipStream_t s);
