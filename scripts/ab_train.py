@@ -46,3 +46,4 @@ def train_ds():
     st[0] += 1
     ds.forward_train(feat3, lab); ds.backward(); ds.adam_step(5e-4, st[0])
 print(f"DSCNN-L train: {timeit(train_ds, n=6, warm=2):9.1f} us")
+print(f"DSCNN-L eval forward: {timeit(lambda: ds.forward_infer(feat3), n=10, warm=3):9.1f} us")

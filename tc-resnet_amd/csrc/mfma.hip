@@ -35,6 +35,40 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
         const int n = p / a.tout, t = p - n * a.tout;
         xb[nt] = a.x + (size_t)n * a.cin * a.tpi + kHalo + t * a.stride;
     }
+    if ((a.cin & 3) == 0) {
+        // Lean loop (every shape in use: Cin % 4 == 0): per-lane operand pointers advanced by constant strides, no per-load
+        // predicates (output channels past Cout are clamped to a valid row that is never stored), next step's operands
+        // in flight while the current 4 * MT MFMAs issue.
+        const float* wp[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wp[m] = a.w + (size_t)q * a.cout + min((cot0 + m) * 16 + r, a.cout - 1);
+        const float* xq[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) xq[nt] = xb[nt] + (size_t)q * a.tpi;
+        const int wstep = 4 * a.cout, xstep = 4 * a.tpi;
+        const int nsteps = a.cin >> 2;
+        float af[MT], bf[4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = wp[m][0];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bf[nt] = xq[nt][0];
+        for (int st = 0; st < nsteps; ++st) {
+            const int nx = min(st + 1, nsteps - 1);         // (last step re-reads itself)
+            float an[MT], bn[4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) an[m] = wp[m][nx * wstep];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bn[nt] = xq[nt][nx * xstep];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = an[m];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bf[nt] = bn[nt];
+        }
+    } else
     for (int ci0 = 0; ci0 < a.cin; ci0 += 4) {
         const int ci = ci0 + q;
         const bool civ = ci < a.cin;
