@@ -350,8 +350,11 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     const int grid = ceil_div(a.total_frames, 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int knob = tune_get(TCR_TUNE_FRONTEND);
-    if (knob == 0 || knob == 5) return launch_frontend_pk(cfg->nfft / 2, a, grid, s);      // default: packed-FP32 kernel (frontend_pk.hip)
-    const int var = (knob - 1) & 3;
+    if (knob == 0 || knob == 5) {           // default: packed-FP32 kernel (frontend_pk.hip) where its window specialisation applies
+        const int rc = launch_frontend_pk(cfg->nfft / 2, a, grid, s);
+        if (rc != 1) return rc;
+    }
+    const int var = knob == 0 || knob == 5 ? 3 : (knob - 1) & 3;
 #define TCR_FE(NC_)                                                                                     \
     switch (var) {                                                                                      \
         case 0: hipLaunchKernelGGL((frontend_kernel<NC_, 0>), dim3(grid), dim3(256), 0, s, a); break;   \

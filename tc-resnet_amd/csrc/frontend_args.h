@@ -20,7 +20,7 @@ struct FrontendArgs {
     int aligned;        // frame starts are 8-byte aligned -> float2 loads
 };
 
-// packed-FP32 kernel; nc = nfft / 2 (256 or 512)
+// packed-FP32 kernel; nc = nfft / 2 (256 or 512); returns 1 when the general kernel must be used
 int launch_frontend_pk(int nc, const FrontendArgs& a, int grid, hipStream_t s);
 
 }  // namespace tcr

@@ -144,7 +144,10 @@ __device__ __forceinline__ void pk_real_pair_power(v2 zk, v2 zn, v2 wmi, float& 
     p_hi = fmaf(Y.x, Y.x, Y.y * Y.y);
 }
 
-template <int NC>
+// QV: number of leading radix-16 inputs per lane that fall inside the analysis window -- identical for every lane when
+// win / 2 is a multiple of 16 * SUB (640 -> 10 of 16, 480 -> 15 of 16).  The rest of the zero-padded FFT input is never
+// loaded, windowed or butterflied (the compiler folds the zeros through the first radix-16 pass), and no load is masked.
+template <int NC, int QV, bool MAG>
 __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs a) {
     constexpr int LPF = NC / 16;            // lanes per frame
     constexpr int FPR = 256 / LPF;          // frames per round
@@ -173,13 +176,14 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     const v2* tw_real = reinterpret_cast<const v2*>(a.tw_real);
     const v2* tw_combine = reinterpret_cast<const v2*>(a.tw_combine);
 
-    v2 wnd[16], tw[16];
+    v2 wnd[QV], tw[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < QV; ++q) {
         const int idx = 2 * (SUB * (l + 16 * q) + u);
-        wnd[q] = (idx < a.win) ? (v2){a.window[idx], a.window[idx + 1]} : (v2){0.f, 0.f};
-        tw[q] = tw256[l * 16 + q];
+        wnd[q] = (v2){a.window[idx], a.window[idx + 1]};
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tw[q] = tw256[l * 16 + q];
     v2 twr[8], twc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
         twc[i] = (SUB == 2) ? tw_combine[k] : (v2){1.f, 0.f};
     }
     {
-        const float fold = a.magnitude ? 0.5f : 0.25f;
+        const float fold = MAG ? 0.5f : 0.25f;
         const v2* wud = reinterpret_cast<const v2*>(a.wud);
         for (int i = threadIdx.x; i < NBINS; i += 256) s_wud[i] = wud[i] * fold;
         for (int i = threadIdx.x; i <= NSEG; i += 256) s_seg[i] = a.seg_start[i];
@@ -198,23 +202,17 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     const v2 twmid = (v2){wm.y, -wm.x};
     __syncthreads();
 
-    v2 xa[16];
-    auto load_frame = [&](int rr, v2 (&dst)[16]) {
+    const float inv_frames = 1.0f / (float)a.n_frames;
+    v2 xa[QV];
+    auto load_frame = [&](int rr, v2 (&dst)[QV]) {
         int g = blockIdx.x * 64 + rr * FPR + f;
         g = min(g, a.total_frames - 1);
-        const int n = g / a.n_frames;
+        int n = (int)(((float)g + 0.5f) * inv_frames);          // g / n_frames: float multiply + one-step fix-up
+        n += (n + 1) * a.n_frames <= g ? 1 : (n * a.n_frames > g ? -1 : 0);
         const int t = g - n * a.n_frames;
         const float* src = a.wav + (size_t)n * a.n_samples + (size_t)t * a.hop;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int idx = 2 * (SUB * (l + 16 * q) + u);
-            v2 x = (v2){0.f, 0.f};
-            if (idx < a.win) {
-                if (a.aligned) x = *reinterpret_cast<const v2*>(src + idx);
-                else x = (v2){src[idx], src[idx + 1]};
-            }
-            dst[q] = x;
-        }
+        for (int q = 0; q < QV; ++q) dst[q] = *reinterpret_cast<const v2*>(src + 2 * (SUB * (l + 16 * q) + u));     // (8-byte aligned: launcher)
     };
     // (A frame's lanes never straddle a wavefront: the phases of a round are ordered by wave-local sync points.)
     for (int r = 0; r < ROUNDS; ++r) {
@@ -222,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
         v2 v[16];
         if (r == 0) load_frame(r, xa);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = xa[q] * wnd[q];
+        for (int q = 0; q < 16; ++q) v[q] = q < QV ? xa[q] * wnd[q] : (v2){0.f, 0.f};
         if (r + 1 < ROUNDS) load_frame(r + 1, xa);
         pk_dft16(v);
 #pragma unroll
@@ -255,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
                 }
                 float plo, phi;
                 pk_real_pair_power(zk, zn, twr[i], plo, phi);
-                if (a.magnitude) { plo = sqrtf(plo); phi = sqrtf(phi); }
+                if (MAG) { plo = sqrtf(plo); phi = sqrtf(phi); }
                 P[k] = plo;
                 P[NC - k] = phi;
             }
@@ -265,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
                 else z = E[NC / 2];
                 float plo, phi;
                 pk_real_pair_power(z, z, twmid, plo, phi);
-                if (a.magnitude) plo = sqrtf(plo);
+                if (MAG) plo = sqrtf(plo);
                 P[NC / 2] = plo;
             }
         }
@@ -320,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     const int n = gg / a.n_frames;
     const int t = gg - n * a.n_frames;
     float* dst = a.out + (size_t)n * a.n_coef * a.tp + kHalo + t;
-    if (a.magnitude) {
+    if (MAG) {
         for (int m = w; m < a.n_coef; m += 4) {
             if (valid) {
                 float* row = dst + (size_t)m * a.tp;
@@ -349,10 +347,27 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     }
 }
 
+// returns 1 (nothing launched) when the configuration needs the general kernel: unaligned frames, or a window whose
+// valid radix-16 inputs differ from lane to lane
 int launch_frontend_pk(int nc, const FrontendArgs& a, int grid, hipStream_t s) {
-    if (nc == 256) hipLaunchKernelGGL((frontend_pk_kernel<256>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((frontend_pk_kernel<512>), dim3(grid), dim3(256), 0, s, a);
-    return check_launch("frontend_pk_kernel");
+    const int sub = nc / 256;
+    if (!a.aligned || (a.win & 1) || (a.win / 2) % (16 * sub) != 0) return 1;
+    if (a.total_frames >= (1 << 23)) return 1;              // (the frame -> utterance split uses a float reciprocal)
+    const int qv = a.win / (32 * sub);
+#define TCR_FPK(NC_, QV_)                                                                                           \
+    if (nc == NC_ && qv == QV_) {                                                                                   \
+        if (a.magnitude) hipLaunchKernelGGL((frontend_pk_kernel<NC_, QV_, true>), dim3(grid), dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((frontend_pk_kernel<NC_, QV_, false>), dim3(grid), dim3(256), 0, s, a);             \
+        return check_launch("frontend_pk_kernel");                                                                  \
+    }
+    TCR_FPK(512, 10)    // 40 ms window @ 16 kHz, FFT 1024
+    TCR_FPK(256, 15)    // 30 ms window, FFT 512
+    TCR_FPK(512, 16)
+    TCR_FPK(256, 16)
+    TCR_FPK(256, 10)    // 20 ms window, FFT 512
+    TCR_FPK(512, 15)
+#undef TCR_FPK
+    return 1;
 }
 
 }  // namespace tcr
