@@ -149,8 +149,8 @@ def main():
         roof = {"bound": "mfma", "achieved": round(fe_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fp_frac, 4)}
     else:
         roof = {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
-    traffic, traffic_src = pmc_traffic("frontend_pk_kernel<512>")
-    roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": "frontend_pk_kernel<512>", "kernel_ms": round(fe_ms, 4),
+    traffic, traffic_src = pmc_traffic("frontend_pk_kernel<512,")
+    roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": "frontend_pk_kernel<512, 10, false>", "kernel_ms": round(fe_ms, 4),
                  "note": "f32 VALU pipe; its 157.3 TFLOP/s peak equals the exact-f32 MFMA peak. HIP-event-bracketed launch on the "
                          "launch stream, inside the timed region",
                  "hbm_gbs": round(fe_gbs, 1), "hbm_frac": round(hbm_frac, 4), "fp32_tflops": round(fe_tf, 3), "fp32_frac": round(fp_frac, 4),
@@ -306,7 +306,7 @@ def pmc_traffic(kernel: str):
     for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.csv")), reverse=True):
         vals = {}
         for r in csv.DictReader(open(path)):
-            if r["kernel"] == kernel and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if r["kernel"].startswith(kernel) and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[r["counter"]] = float(r["mean_per_launch"])
         if len(vals) == 2:
             return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.join("profiles", os.path.basename(path))
