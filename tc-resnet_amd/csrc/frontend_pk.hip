@@ -157,11 +157,12 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     constexpr int NMEL = 64, NSEG = NMEL + 1;
     constexpr int XLD = 17;                 // padded row of the 16x16 transpose tile
     constexpr int UNIT = 16 * XLD;
-    constexpr int PLD = NBINS + 3;
+    constexpr int PLD = NBINS + 31;         // row stride = 32 (mod 64) banks: the two frames of a wave never collide
 
     __shared__ v2 s_x[16 * UNIT];                   // transpose tiles, then the FFT output of each unit
     __shared__ float s_p[FPR * PLD];                // 4 x power (or 2 x magnitude) spectrum
-    __shared__ v2 s_ud[FPR * (NSEG + 1)];           // per-segment (up, down) partial sums
+    constexpr int ULD = NSEG + 1;                   // (a bank-friendlier 80 pushes NC = 256 past 80 KB of LDS: 1 workgroup / CU)
+    __shared__ v2 s_ud[FPR * ULD];                  // per-segment (up, down) partial sums
     __shared__ float s_lm[NMEL * 65];               // log-mel [mel][frame], 64 frames
     __shared__ v2 s_wud[NBINS];                     // mel slopes per bin, pre-scaled by 1/4 (1/2)
     __shared__ int s_seg[NSEG + 1];
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
         // ---------------- sparse mel: per-segment (up, down) sums, one packed FMA per bin ----------------
         {
             const float* P = s_p + f * PLD;
-            v2* UD = s_ud + f * (NSEG + 1);
+            v2* UD = s_ud + f * ULD;
             for (int i = 0;; ++i) {
                 const int j = (i & 1) ? (i + 1) * LPF - 1 - lf : i * LPF + lf;
                 if (i * LPF >= NSEG) break;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
         wave_sync();
         // ---------------- log(mel + 1e-6) -> [mel][frame] ----------------
         {
-            const v2* UD = s_ud + f * (NSEG + 1);
+            const v2* UD = s_ud + f * ULD;
 #pragma unroll
             for (int i = 0; i < NMEL / LPF; ++i) {
                 const int m = lf + LPF * i;
