@@ -39,6 +39,16 @@ struct tcr_net {
     int64_t param_floats = 0, decay_floats = 0, stat_floats = 0;
     std::vector<tcr_tensor_info> tensors;
     int feat_c = 0, feat_t = 0;
+    // Backward runs the weight-gradient kernels on a second stream: they only consume (x, dy) of their own layer and write
+    // their own split-K slab, so they overlap the data-gradient / BN-backward chain of the layers below (each kernel of a
+    // training step is too short to fill the chip on its own).  Created on first use; joined before the slab reduction.
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~tcr_net() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 namespace tcr {
@@ -436,6 +446,7 @@ struct TrainCtx {
     const float* feat;
     int batch;
     double bn_batch;        // batch the BN statistics are taken over (global batch under sync BN)
+    hipStream_t side;       // backward: stream of the weight-gradient kernels (== s when overlap is off)
     hipStream_t s;
 };
 
@@ -671,10 +682,16 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     TCR_TRY(launch_bn_bwd_apply(a, c.s));
     // weight gradient
     const float* x = layer_input(net, c.w, c.base, c.feat, l);
-    if (conv_wgrad_deferrable(l.k, l.cin, l.cout))       // slabs summed for all layers at once at the end of backward
+    if (conv_wgrad_deferrable(l.k, l.cin, l.cout)) {     // slabs summed for all layers at once at the end of backward
+        if (c.side != c.s) {                            // fork: the side stream waits for dy, the main stream carries on
+            if (hipEventRecord(c.net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(c.side, c.net->ev_fork, 0) != hipSuccess) {
+                set_error("tcr_net_backward: stream fork failed");
+                return TCR_ERR_HIP;
+            }
+        }
         TCR_TRY(launch_conv_wgrad_partial(l.k, l.stride, l.pad_lo, x, dy, c.base + c.w.wg[u.li], c.batch, l.cin, l.cout, tpi, l.tout, tp,
-                                          nullptr, c.s));
-    else
+                                          nullptr, c.side));
+    } else
         TCR_TRY(launch_conv_wgrad(l.k, l.stride, l.pad_lo, x, dy, grads + l.w_off, c.base + c.w.wgrad_scratch,
                                   c.batch, l.cin, l.cout, tpi, l.tout, tp, c.s));
     if (l.in_act < 0) return TCR_OK;        // no gradient flows into the features
@@ -739,6 +756,18 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     c.bn_batch = sync_bn ? (double)global_batch : (double)batch;
     c.sync_bn = sync_bn != 0;
     c.s = static_cast<hipStream_t>(stream);
+    c.side = c.s;
+    if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) {
+        if (!net->side) {
+            if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) != hipSuccess) {
+                set_error("tcr_net_backward: cannot create the weight-gradient stream");
+                return TCR_ERR_HIP;
+            }
+        }
+        c.side = net->side;
+    }
     const std::vector<int> order = backward_order(*net);
     const int nu = (int)order.size();
     TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);
@@ -767,7 +796,11 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
         }
         if (st > 0) TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, order[st - 1], dpool), grads, dpool));
         if (st < nu) TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, order[st], dpool)));
-        if (st == nu) {         // every layer's split-K slabs -> dW, one launch
+        if (st == nu) {         // every layer's split-K slabs -> dW, one launch (after the side stream has drained)
+            if (c.side != c.s && (hipEventRecord(net->ev_join, c.side) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join, 0) != hipSuccess)) {
+                set_error("tcr_net_backward: stream join failed");
+                return TCR_ERR_HIP;
+            }
             WgradReduceMulti rm;
             rm.n = 0;
             for (int li : order) {
