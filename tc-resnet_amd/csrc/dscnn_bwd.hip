@@ -27,8 +27,9 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_kernel(const DsDwBwdArgs a
     const float* dz = a.dz + row * a.ppo + kHalo;
     float* dx = a.dx + row * a.ppi + kHalo;
     const int pin = a.h_in * a.w_in;
+    const float inv_w = 1.0f / (float)a.w_in;
     for (int pos = lane; pos < pin; pos += 64) {
-        const int h = pos / a.w_in, w = pos - h * a.w_in;
+        const int h = fast_div(pos, a.w_in, inv_w), w = pos - h * a.w_in;
         float s = 0.f;
 #pragma unroll
         for (int di = 0; di < 3; ++di) {
@@ -68,9 +69,10 @@ __global__ __launch_bounds__(256) void dscnn_dw_wgrad_kernel(const DsDwWgradArgs
     float acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    const float inv_p = 1.0f / (float)P, inv_ow = 1.0f / (float)a.ow;
     for (int idx = lane; idx < cnt * P; idx += 64) {
-        const int dn = idx / P, pos = idx - dn * P;
-        const int oh = pos / a.ow, ow = pos - oh * a.ow;
+        const int dn = fast_div(idx, P, inv_p), pos = idx - dn * P;
+        const int oh = fast_div(pos, a.ow, inv_ow), ow = pos - oh * a.ow;
         const size_t plane = (size_t)(n0 + dn) * a.c + c;
         const float g = a.dz[plane * a.ppo + kHalo + pos];
         const float* xr = a.x + plane * a.ppi + kHalo;

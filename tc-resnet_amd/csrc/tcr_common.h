@@ -80,6 +80,14 @@ __device__ __forceinline__ int opaque_zero() {
 #endif
 }
 
+// n / d for 0 <= n < 2^22, 1 <= d: float multiply + one-step fix-up (a 32-bit integer division by a run-time value is
+// ~25 dependent VALU instructions on this ISA).  inv_d = 1.0f / d.
+__device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
+    int qt = (int)(((float)n + 0.5f) * inv_d);
+    qt += (qt + 1) * d <= n ? 1 : (qt * d > n ? -1 : 0);
+    return qt;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
