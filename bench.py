@@ -171,12 +171,18 @@ def main():
 
     if not args.no_extras:
         # ---------------- training step (configs[2]) ----------------
+        # Every step computes the MFCC of its own batch; like the reference's tf.data prefetch, the front-end of step k+1 is
+        # issued on a second stream while step k's forward/backward/update occupy the main stream (FeaturePrefetcher).
+        from tcresnet_amd.pipeline import FeaturePrefetcher
         dp = DataParallel(net)
         step_no = [0]
+        pf = FeaturePrefetcher(fe, B)
+        pf.submit(wav)
 
         def train_step():
             step_no[0] += 1
-            f = fe(wav, out=feat)
+            f = pf.get()
+            pf.submit(wav)
             dp.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
             dp.backward()
             net.sgd_momentum_step(0.1, 0.9, 0.001)
@@ -184,7 +190,7 @@ def main():
         tsteps = max(5, args.steps // 2)
         tdt = timed(train_step, tsteps, max(2, args.warmup // 2), dist_on)
         out["train"] = {"value": round(world * B * tsteps / tdt, 1), "unit": "utterances/s", "ms_per_step": round(tdt / tsteps * 1e3, 4),
-                        "steps": tsteps, "workload": "TCResNet8-1.0 train step: MFCC + train-mode BN fwd + bwd + momentum (wd 1e-3, keep_prob 0.5), "
+                        "steps": tsteps, "workload": "TCResNet8-1.0 train step: MFCC (prefetched on a second stream) + train-mode BN fwd + bwd + momentum (wd 1e-3, keep_prob 0.5), "
                                                      "batch 4096/GPU" + (", RCCL all-reduce of the flat gradient arena" if dist_on else "")}
         # ---------------- TCResNet14-1.5 training (configs[3]: global batch 32768 = 8 x 4096 over RCCL) ----------------
         net14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, fe.n_frames, 12, device=dev)
@@ -193,7 +199,8 @@ def main():
 
         def train14_step():
             step_no[0] += 1
-            f = fe(wav, out=feat)
+            f = pf.get()
+            pf.submit(wav)
             dp14.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
             dp14.backward()
             net14.sgd_momentum_step(0.1, 0.9, 0.001)
@@ -252,10 +259,13 @@ def main():
                                             + (", RCCL all-reduce of the gradient arena" if dist_on else "")}
         # ---------------- TCResNet8 training with the 30/10 ms front-end (the reference's training scripts) ----------------
         dp2 = DataParallel(net2)
+        pf2 = FeaturePrefetcher(fe2, B)
+        pf2.submit(wav)
 
         def train2_step():
             step_no[0] += 1
-            f = fe2(wav, out=feat2)
+            f = pf2.get()
+            pf2.submit(wav)
             dp2.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
             dp2.backward()
             net2.sgd_momentum_step(0.1, 0.9, 0.001)

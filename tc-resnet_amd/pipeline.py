@@ -52,3 +52,52 @@ class InferencePipeline:
         cur = torch.cuda.current_stream(self.fe.device)
         cur.wait_stream(self.s_fe)
         cur.wait_stream(self.s_net)
+
+
+class FeaturePrefetcher:
+    """Training-side input prefetch: the front-end of batch k+1 runs on its own stream while the optimisation step of
+    batch k occupies the caller's stream (the device-side counterpart of the reference's tf.data `prefetch`,
+    datasets/data_wrapper_base.py:70-76).  The kernels of a training step are individually too short to fill the chip, so
+    the MFCC kernel slots in between them.
+
+        pf = FeaturePrefetcher(frontend, batch)
+        pf.submit(first_wavs)
+        for step in ...:
+            feat = pf.get()                 # features of this step (ready on the caller's stream)
+            pf.submit(next_wavs)            # next step's features, overlapped with the step below
+            net.forward_train(feat, ...); net.backward(); net.sgd_momentum_step(...)
+    """
+
+    def __init__(self, frontend, batch: int):
+        self.fe = frontend
+        dev = frontend.device
+        self.stream = torch.cuda.Stream(dev)
+        self.feat = [torch.empty((batch, frontend.n_coef, padded_len(frontend.n_frames)), device=dev) for _ in range(2)]
+        self._ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self._free = [None, None]           # event after which buffer i may be overwritten
+        self._k = 0                         # submits so far
+        self._pending = None
+
+    def submit(self, wav: torch.Tensor):
+        i = self._k % 2
+        cur = torch.cuda.current_stream(self.fe.device)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_stream(cur)                        # `wav` was produced on the caller's stream
+            if self._free[i] is not None:
+                self.stream.wait_event(self._free[i])           # the step that consumed buffer i has been issued and finished
+            self.fe(wav, out=self.feat[i])
+            self._ready[i].record(self.stream)
+        self._pending = i
+        self._k += 1
+
+    def get(self) -> torch.Tensor:
+        """Features of the most recent submit, ordered after their kernel on the caller's stream.  The buffer stays valid
+        until the submit after next."""
+        i = self._pending
+        cur = torch.cuda.current_stream(self.fe.device)
+        cur.wait_event(self._ready[i])
+        j = 1 - i                                               # the other buffer was consumed by the step just issued
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._free[j] = ev
+        return self.feat[i]
