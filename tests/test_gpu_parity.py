@@ -221,3 +221,32 @@ def test_every_kernel_path_agrees(hip_lib):
     finally:
         for k in range(7):
             hip_lib.tcr_tune(k, 0)
+
+
+def test_feature_prefetch_matches_sequential(hip_lib):
+    """FeaturePrefetcher (front-end of step k+1 on a second stream) leaves a training run bitwise unchanged."""
+    from tcresnet_amd.pipeline import FeaturePrefetcher
+    fx = Cm.load("tcresnet8_1.0_4020.npz")
+    arch, p, s = Cm.fixture_params(fx, "TCResNet8", 1.0)
+    fe = Cm.make_frontend(hip_lib, fx["win"], fx["hop"])
+    batches = [Cm.to_dev(hip_lib, np.tile(np.roll(fx["wav"], k, axis=0), (32, 1))) for k in range(4)]
+    labels = Cm.to_dev(hip_lib, np.tile(fx["labels"], (32, 1)))
+    finals = []
+    for prefetch in (False, True):
+        net = Cm.make_net(hip_lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+        pf = FeaturePrefetcher(fe, batches[0].shape[0]) if prefetch else None
+        if pf:
+            pf.submit(batches[0])
+        for k in range(4):
+            if pf:
+                feat = pf.get()
+                if k + 1 < 4:
+                    pf.submit(batches[k + 1])
+            else:
+                feat = fe(batches[k])
+            net.forward_train(feat, labels, keep_prob=0.5, seed=k)
+            net.backward()
+            net.sgd_momentum_step(0.1, 0.9, 0.001)
+        torch.cuda.synchronize()
+        finals.append((net.params.clone(), net.stats.clone()))
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
