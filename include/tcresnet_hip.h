@@ -57,7 +57,10 @@ typedef struct tcr_frontend_cfg {
     int32_t n_coef;             /* --num_mfccs for mfcc; ignored (== n_mel) for log-mel */
     float lower_hz;             /* --lower_edge_hertz 80 */
     float upper_hz;             /* --upper_edge_hertz 7600 */
-    int32_t method;             /* 0 = mfcc (power spectrum + DCT-II), 1 = log_mel_spectrogram (magnitude) */
+    int32_t method;             /* 0 = mfcc (power spectrum + DCT-II), 1 = log_mel_spectrogram (magnitude),
+                                 * 2 = deploy-path mfcc: contrib_audio.audio_spectrogram + contrib_audio.mfcc op semantics
+                                 *     (datasets/preprocessors.py:98-124,196-203): magnitude-weighted mel filterbank of the op,
+                                 *     log(max(x, 1e-12)), the same sqrt(2/N) DCT-II */
 } tcr_frontend_cfg;
 
 /* Fills nfft / n_frames and validates the configuration. */

@@ -146,6 +146,47 @@ def mfcc(wav: np.ndarray, cfg: FrontendCfg, dtype=np.float64) -> np.ndarray:
 # --------------------------------------------------------------------------- #
 # Network description: audio_nets/tc_resnet.py:6-70
 # --------------------------------------------------------------------------- #
+def mfcc_deploy(wav: np.ndarray, cfg: FrontendCfg, dtype=np.float64) -> np.ndarray:
+    """Deploy-path MFCC (datasets/preprocessors.py:98-124,196-203): contrib_audio.audio_spectrogram(magnitude_squared=True)
+    followed by contrib_audio.mfcc(spectrogram, sample_rate, upper/lower_frequency_limit, filterbank_channel_count,
+    dct_coefficient_count).  The two ops are TF C++ kernels (core/kernels/spectrogram.cc, mfcc.cc, mfcc_mel_filterbank.cc,
+    mfcc_dct.cc), restated here from their published algorithm (PARITY UNPINNED):
+      * spectrogram: periodic Hann 0.5 - 0.5 cos(2 pi i / L), zero-padded to the next power of two, |rfft|^2,
+        frames = 1 + (N - L) // stride;
+      * filterbank: C + 1 centre frequencies equally spaced in mel(f) = 1127 ln(1 + f / 700) between the two limits,
+        hz_per_bin = (sr / 2) / (bins - 1), bins int(1.5 + lower / hz_per_bin) .. int(upper / hz_per_bin); bin i in band b
+        (largest b with centre[b] < mel_i; -1 below the first centre) adds w_i sqrt(P_i) to channel b and (1 - w_i) sqrt(P_i)
+        to channel b + 1, w_i = (centre[b+1] - mel_i) / (centre[b+1] - centre[b]) (for b = -1: (centre[0] - mel_i) / (centre[0] - mel_low));
+      * log(max(x, 1e-12)); DCT-II with sqrt(2 / C) cos(pi k (n + 0.5) / C), first dct_coefficient_count outputs."""
+    wav = np.asarray(wav, dtype=dtype)
+    frames = frame_signal(wav, cfg.win, cfg.hop) * hann_periodic(cfg.win, dtype)
+    spec = np.fft.rfft(frames, n=cfg.nfft, axis=-1)
+    power = spec.real ** 2 + spec.imag ** 2
+    nbins, nch = cfg.n_bins, cfg.num_mel_bins
+    mel = lambda f: 1127.0 * np.log1p(np.asarray(f, dtype=np.float64) / 700.0)
+    mel_low, mel_hi = mel(cfg.lower_edge_hertz), mel(cfg.upper_edge_hertz)
+    center = mel_low + (mel_hi - mel_low) / (nch + 1) * (np.arange(nch + 1) + 1)
+    hz_per_sbin = 0.5 * cfg.sample_rate / (nbins - 1)
+    start, end = int(1.5 + cfg.lower_edge_hertz / hz_per_sbin), int(cfg.upper_edge_hertz / hz_per_sbin)
+    out = np.zeros(power.shape[:-1] + (nch,), dtype=dtype)
+    channel = 0
+    for i in range(start, min(end, nbins - 1) + 1):
+        melf = mel(i * hz_per_sbin)
+        while channel < nch and center[channel] < melf:
+            channel += 1
+        b = channel - 1
+        w = (center[b + 1] - melf) / (center[b + 1] - center[b]) if b >= 0 else (center[0] - melf) / (center[0] - mel_low)
+        v = np.sqrt(power[..., i])
+        if b >= 0:
+            out[..., b] += w * v
+        if b + 1 < nch:
+            out[..., b + 1] += v - w * v
+    logmel = np.log(np.maximum(out, 1e-12))
+    n = np.arange(nch)
+    dct = np.sqrt(2.0 / nch) * np.cos(np.pi / nch * np.outer(np.arange(cfg.num_mfccs), n + 0.5))
+    return logmel @ dct.T
+
+
 @dataclass
 class ConvSpec:
     name: str            # TF variable scope under the model scope, e.g. "block0/conv0_0"

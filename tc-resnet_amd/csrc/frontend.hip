@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
             for (int i = 0; i < NMEL / LPF; ++i) {
                 const int m = lf + LPF * i;
                 const float mel = UD[m] + UD[NSEG + 1 + m + 1];     // up-slope of segment m + down-slope of segment m+1
-                s_lm[m * 65 + r * FPR + f] = logf(mel + 1e-6f);
+                s_lm[m * 65 + r * FPR + f] = a.log_floor ? logf(fmaxf(mel, 1e-12f)) : logf(mel + 1e-6f);
             }
         }
     }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
     const int n = gg / a.n_frames;
     const int t = gg - n * a.n_frames;
     float* dst = a.out + (size_t)n * a.n_coef * a.tp + kHalo + t;
-    if (a.magnitude) {
+    if (a.no_dct) {
         for (int m = w; m < a.n_coef; m += 4) {
             if (valid) {
                 float* row = dst + (size_t)m * a.tp;
@@ -345,7 +345,9 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     a.n_coef = cfg->n_coef;
     a.tp = tcr_padded_len(cfg->n_frames);
     a.total_frames = batch * cfg->n_frames;
-    a.magnitude = cfg->method == 1;
+    a.magnitude = cfg->method != 0;
+    a.no_dct = cfg->method == 1;
+    a.log_floor = cfg->method == 2;
     a.aligned = ((cfg->n_samples | cfg->hop) & 1) == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0;
     const int grid = ceil_div(a.total_frames, 64);
     hipStream_t s = static_cast<hipStream_t>(stream);

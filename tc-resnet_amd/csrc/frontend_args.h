@@ -16,7 +16,9 @@ struct FrontendArgs {
     const float* dcth;
     int n_samples, win, hop, n_frames, n_coef, tp;
     int total_frames;
-    int magnitude;      // 1: log-mel preprocessor (|S|, no DCT)
+    int magnitude;      // 1: the mel filterbank takes |S| instead of |S|^2
+    int no_dct;         // 1: log-mel preprocessor (output = log-mel, no DCT)
+    int log_floor;      // 0: log(x + 1e-6) (tf.contrib.signal path); 1: log(max(x, 1e-12)) (contrib_audio.mfcc op)
     int aligned;        // frame starts are 8-byte aligned -> float2 loads
 };
 

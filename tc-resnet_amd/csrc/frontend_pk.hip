@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
             for (int i = 0; i < NMEL / LPF; ++i) {
                 const int m = lf + LPF * i;
                 const float mel = UD[m].x + UD[m + 1].y;    // up-slope of segment m + down-slope of segment m+1
-                s_lm[m * 65 + r * FPR + f] = logf(mel + 1e-6f);
+                s_lm[m * 65 + r * FPR + f] = a.log_floor ? logf(fmaxf(mel, 1e-12f)) : logf(mel + 1e-6f);
             }
         }
     }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     const int n = gg / a.n_frames;
     const int t = gg - n * a.n_frames;
     float* dst = a.out + (size_t)n * a.n_coef * a.tp + kHalo + t;
-    if (MAG) {
+    if (a.no_dct) {
         for (int m = w; m < a.n_coef; m += 4) {
             if (valid) {
                 float* row = dst + (size_t)m * a.tp;

@@ -62,7 +62,7 @@ extern "C" int tcr_frontend_resolve(tcr_frontend_cfg* cfg) {
                 "front-end: fft_length %d (window %d samples) unsupported; this build has the 512- and 1024-point kernels", nfft, cfg->win);
     TCR_REQUIRE((cfg->win & 1) == 0, "front-end: window_size_samples must be even (got %d)", cfg->win);
     TCR_REQUIRE(cfg->n_mel == 64, "front-end: num_mel_bins must be 64 (got %d)", cfg->n_mel);
-    TCR_REQUIRE(cfg->method == 0 || cfg->method == 1, "front-end: method must be 0 (mfcc) or 1 (log_mel_spectrogram)");
+    TCR_REQUIRE(cfg->method >= 0 && cfg->method <= 2, "front-end: method must be 0 (mfcc), 1 (log_mel_spectrogram) or 2 (deploy-path mfcc)");
     if (cfg->method == 1) cfg->n_coef = cfg->n_mel;
     TCR_REQUIRE(cfg->n_coef >= 1 && cfg->n_coef <= cfg->n_mel, "front-end: num_mfccs must be in [1, %d] (got %d)", cfg->n_mel, cfg->n_coef);
     TCR_REQUIRE(cfg->lower_hz >= 0.f && cfg->lower_hz < cfg->upper_hz && cfg->upper_hz <= cfg->sample_rate / 2.0f,
@@ -102,8 +102,44 @@ extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_pl
         w[L.tw_real + 2 * k + 1] = (float)std::sin(a);
     }
 
-    // Sparse mel: segment boundaries in bins + two slopes per bin, extracted from the dense matrix.
     const int nm = cfg->n_mel;
+    if (cfg->method == 2) {
+        // Deploy path: the filterbank of the contrib_audio.mfcc op (TF core/kernels/mfcc_mel_filterbank.cc, restated):
+        // centre frequencies equally spaced on the mel scale, bins [start_index, end_index], bin i with band b = band_mapper[i]
+        // adds weight[i] * |X| to channel b and (1 - weight[i]) * |X| to channel b + 1.  In the kernel's segment form bin i
+        // lies in segment b + 1 with up-slope (-> filter b + 1) 1 - weight and down-slope (-> filter b) weight.
+        const int nbins = L.nbins;
+        const double mel_low = hertz_to_mel(cfg->lower_hz), mel_hi = hertz_to_mel(cfg->upper_hz);
+        const double mel_spacing = (mel_hi - mel_low) / (double)(nm + 1);
+        std::vector<double> center(nm + 1);
+        for (int i = 0; i < nm + 1; ++i) center[i] = mel_low + mel_spacing * (i + 1);
+        const double hz_per_sbin = 0.5 * cfg->sample_rate / (double)(nbins - 1);
+        const int start_index = (int)(1.5 + cfg->lower_hz / hz_per_sbin);
+        const int end_index = (int)(cfg->upper_hz / hz_per_sbin);
+        int32_t* segd = reinterpret_cast<int32_t*>(w + L.seg_start);
+        std::vector<int> band(nbins, -2);
+        int channel = 0;
+        for (int i = 0; i < nbins; ++i) {
+            const double melf = hertz_to_mel(i * hz_per_sbin);
+            if (i < start_index || i > end_index) continue;
+            while (center[channel] < melf && channel < nm) ++channel;
+            band[i] = channel - 1;
+        }
+        for (int j = 0; j <= L.nseg; ++j) {
+            int first = end_index + 1;
+            for (int i = end_index; i >= start_index; --i)
+                if (band[i] + 1 >= j) first = i;
+            segd[j] = j == 0 ? start_index : first;
+        }
+        for (int i = start_index; i <= end_index && i < nbins; ++i) {
+            const double melf = hertz_to_mel(i * hz_per_sbin);
+            const int b = band[i];
+            const double wgt = b >= 0 ? (center[b + 1] - melf) / (center[b + 1] - center[b]) : (center[0] - melf) / (center[0] - mel_low);
+            w[L.wud + 2 * i] = (float)(1.0 - wgt);
+            w[L.wud + 2 * i + 1] = (float)wgt;
+        }
+    } else {
+    // Sparse mel: segment boundaries in bins + two slopes per bin, extracted from the dense matrix.
     const std::vector<double> M = dense_mel(*cfg, L.nbins);
     const double nyquist = cfg->sample_rate / 2.0;
     const double mlo = hertz_to_mel(cfg->lower_hz), mhi = hertz_to_mel(cfg->upper_hz);
@@ -139,6 +175,7 @@ extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_pl
                 return TCR_ERR_ARG;
             }
         }
+    }
     }
 
     // DCT-II rows, folded: dcth[c][n] = 2 cos(pi c (2n+1) / (2 N)) / sqrt(2 N), n < N/2

@@ -55,20 +55,24 @@ class AudioPreprocessorBase(PreprocessorBase):
     def preprocess(self, inputs, window_size_samples, window_stride_samples, for_deploy, **kwargs):
         """kwargs read (as in the reference, :80-86,192): num_mel_bins, sample_rate, lower_edge_hertz,
         upper_edge_hertz, num_mfccs."""
+        method = self.method
         if for_deploy:
-            # the contrib_audio.audio_spectrogram/mfcc deploy variant (:98-124,196-203) is a different MFCC
-            # definition (SURVEY F7) and is listed under "next" (SURVEY 8(f) #3)
-            raise NotImplementedError("for_deploy=True (audio_spectrogram/mfcc op semantics) is not built yet")
+            # the contrib_audio.audio_spectrogram + mfcc deploy variant (:98-124,196-203) is a different MFCC definition
+            # (SURVEY F7); the reference only takes batch 1 there, this kernel takes any batch.  The log-mel deploy path of
+            # the reference cannot run (undefined const.MEL_WEIGHT_..., SURVEY F8).
+            if method != "mfcc":
+                raise NotImplementedError("for_deploy=True exists for the mfcc preprocessor only (the reference's log-mel deploy path is broken)")
+            method = "mfcc_deploy"
         self._input_node = inputs
         sr = int(kwargs.get("sample_rate", 16000))
         n = inputs.shape[1]
         key = (sr, n, int(window_size_samples), int(window_stride_samples), int(kwargs.get("num_mel_bins", 64)),
                int(kwargs.get("num_mfccs", 40)), float(kwargs.get("lower_edge_hertz", 80.0)),
-               float(kwargs.get("upper_edge_hertz", 7600.0)))
+               float(kwargs.get("upper_edge_hertz", 7600.0)), method)
         if self._frontend is None or key != self._key:
             self._frontend = Frontend(sample_rate=sr, clip_duration_ms=n * 1000 // sr, window_size_samples=key[2],
                                       window_stride_samples=key[3], num_mel_bins=key[4], num_mfccs=key[5],
-                                      lower_edge_hertz=key[6], upper_edge_hertz=key[7], method=self.method,
+                                      lower_edge_hertz=key[6], upper_edge_hertz=key[7], method=method,
                                       lib=runtime.default_lib(), device=runtime.default_device() or inputs.device)
             self._key = key
         wav = inputs if inputs.is_contiguous() else inputs.contiguous()

@@ -50,7 +50,7 @@ class _Base:
 class Frontend(_Base):
     """MFCC / log-mel front-end (datasets/preprocessors.py:54-96,183-194 of the reference)."""
 
-    METHODS = {"mfcc": 0, "log_mel_spectrogram": 1}
+    METHODS = {"mfcc": 0, "log_mel_spectrogram": 1, "mfcc_deploy": 2}
 
     def __init__(self, sample_rate: int = 16000, clip_duration_ms: int = 1000, window_size_samples: int = 480,
                  window_stride_samples: int = 160, num_mel_bins: int = 64, num_mfccs: int = 40,

@@ -72,6 +72,27 @@ def check_frontend(lib, tag):
     return err
 
 
+def check_frontend_deploy(lib, tag):
+    """Deploy-path MFCC (audio_spectrogram + mfcc op semantics, method "mfcc_deploy") against oracle.mfcc_deploy."""
+    fx = load(f"frontend_{tag}.npz")
+    cfg = R.FRONTEND_4020 if tag == "4020" else R.FRONTEND_3010
+    fe = make_frontend(lib, cfg.win, cfg.hop, method="mfcc_deploy")
+    got = fe.reference_view(fe(to_dev(lib, fx["wav"])))[..., 0].cpu().numpy()
+    ref = R.mfcc_deploy(fx["wav"], cfg)
+    err = np.abs(got - ref).max()
+    assert err < MFCC_TOL, f"deploy MFCC {tag}: max abs err {err}"
+    # the op's filterbank, read back from the plan: every in-range bin's two weights sum to 1, bins outside are weightless
+    m = fe.mel_matrix()
+    rs = m.sum(axis=1)
+    hz = 0.5 * cfg.sample_rate / (cfg.n_bins - 1)
+    start, end = int(1.5 + cfg.lower_edge_hertz / hz), int(cfg.upper_edge_hertz / hz)
+    assert np.all(rs[:start] == 0) and np.all(rs[end + 1:] == 0)
+    inner = rs[start:end + 1]
+    # (the bins below the first / above the last centre frequency feed one channel only)
+    assert np.all(inner <= 1.0 + 1e-6) and np.mean(np.abs(inner - 1.0) < 1e-6) > 0.8 and np.all(inner > 0)
+    return err
+
+
 def check_eval(lib, fname, name, width):
     fx = load(fname)
     arch, p, s = fixture_params(fx, name, width)

@@ -97,6 +97,14 @@ def test_model_build_matches_oracle(emu_runtime):
     assert np.isfinite(float(tot)) and abs(float(mdl) - float(ds_s.model_loss)) < 1e-6 and not torch.equal(before, ds_s.engine.params)
     with pytest.raises(NotImplementedError):
         model.build_deployable_model()
+    # deploy-path MFCC through the reference's preprocessor call (for_deploy=True; the reference feeds batch 1 there)
+    from tcresnet_amd.datasets import preprocessor_factory
+    pre = preprocessor_factory.factory("mfcc", "input/audio/preprocessing", "input/audio/preprocessed")
+    dep = pre.preprocess(wavs[:1], window_size_samples=640, window_stride_samples=320, for_deploy=True, **vars(args))
+    assert tuple(dep.shape) == (1, 49, 40, 1)
+    assert np.abs(dep[0, :, :, 0].numpy() - R.mfcc_deploy(fx["wav"][:1], R.FRONTEND_4020)[0]).max() < Cm.MFCC_TOL
+    with pytest.raises(NotImplementedError):
+        preprocessor_factory.factory("log_mel_spectrogram", "s", "n").preprocess(wavs[:1], 640, 320, True, **vars(args))
 
 
 def test_lr_schedule():

@@ -92,6 +92,11 @@ def test_engine_argument_errors(emu_lib):
     assert net.total_params() == 65264
 
 
+@pytest.mark.parametrize("tag", ["3010", "4020"])
+def test_frontend_deploy_path(emu_lib, tag):
+    Cm.check_frontend_deploy(emu_lib, tag)
+
+
 @pytest.mark.parametrize("size", ["S", "M", "L"])
 def test_dscnn_eval_forward(emu_lib, size):
     Cm.check_dscnn(emu_lib, size)

@@ -22,6 +22,16 @@ def test_frontend(hip_lib, tag):
     Cm.check_frontend(hip_lib, tag)
 
 
+@pytest.mark.parametrize("tag", ["3010", "4020"])
+def test_frontend_deploy_path(hip_lib, tag):
+    Cm.check_frontend_deploy(hip_lib, tag)
+    try:                                    # the general (scalar-FP32) kernel implements the same method
+        hip_lib.tcr_tune(1, 4)
+        Cm.check_frontend_deploy(hip_lib, tag)
+    finally:
+        hip_lib.tcr_tune(1, 0)
+
+
 def test_frontend_variants(hip_lib):
     fx = Cm.load("frontend_4020.npz")
     wav = Cm.to_dev(hip_lib, fx["wav"])
