@@ -174,9 +174,11 @@ def main():
         # Every step computes the MFCC of its own batch; like the reference's tf.data prefetch, the front-end of step k+1 is
         # issued on a second stream while step k's forward/backward/update occupy the main stream (FeaturePrefetcher).
         from tcresnet_amd.pipeline import FeaturePrefetcher
+        from tcresnet_amd.parallel import ranks_share_gpu
+        overlap = not ranks_share_gpu()
         dp = DataParallel(net)
         step_no = [0]
-        pf = FeaturePrefetcher(fe, B)
+        pf = FeaturePrefetcher(fe, B, overlap=overlap)
         pf.submit(wav)
 
         def train_step():
@@ -259,7 +261,7 @@ def main():
                                             + (", RCCL all-reduce of the gradient arena" if dist_on else "")}
         # ---------------- TCResNet8 training with the 30/10 ms front-end (the reference's training scripts) ----------------
         dp2 = DataParallel(net2)
-        pf2 = FeaturePrefetcher(fe2, B)
+        pf2 = FeaturePrefetcher(fe2, B, overlap=overlap)
         pf2.submit(wav)
 
         def train2_step():

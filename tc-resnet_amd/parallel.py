@@ -16,6 +16,14 @@ import torch
 import torch.distributed as dist
 
 
+def ranks_share_gpu() -> bool:
+    """True when more local ranks than GPUs are running (several processes time-sharing one device: a CPU-side rehearsal
+    of the multi-GPU path, never a production layout).  Cross-stream event waits of one process can then sit out whole
+    scheduler time slices of the other (measured: seconds per step), so the stream-level overlaps are switched off."""
+    import os
+    return torch.cuda.is_available() and int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > torch.cuda.device_count()
+
+
 class DataParallel:
     def __init__(self, net, sync_bn: bool = False, group: Optional[dist.ProcessGroup] = None):
         self.net = net
@@ -24,6 +32,8 @@ class DataParallel:
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
+        if self.enabled and ranks_share_gpu() and hasattr(net, "lib"):
+            net.lib.tcr_tune(7, 1)          # TCR_TUNE_WGRAD_STREAM: everything on the caller's stream (see ranks_share_gpu)
 
     def _sum(self, t: torch.Tensor):
         if self.enabled:

@@ -68,10 +68,11 @@ class FeaturePrefetcher:
             net.forward_train(feat, ...); net.backward(); net.sgd_momentum_step(...)
     """
 
-    def __init__(self, frontend, batch: int):
+    def __init__(self, frontend, batch: int, overlap: bool = True):
+        """overlap=False degrades to the caller's stream (same results, no second stream)."""
         self.fe = frontend
         dev = frontend.device
-        self.stream = torch.cuda.Stream(dev)
+        self.stream = torch.cuda.Stream(dev) if overlap else None
         self.feat = [torch.empty((batch, frontend.n_coef, padded_len(frontend.n_frames)), device=dev) for _ in range(2)]
         self._ready = [torch.cuda.Event(), torch.cuda.Event()]
         self._free = [None, None]           # event after which buffer i may be overwritten
@@ -80,6 +81,11 @@ class FeaturePrefetcher:
 
     def submit(self, wav: torch.Tensor):
         i = self._k % 2
+        if self.stream is None:
+            self.fe(wav, out=self.feat[i])
+            self._pending = i
+            self._k += 1
+            return
         cur = torch.cuda.current_stream(self.fe.device)
         with torch.cuda.stream(self.stream):
             self.stream.wait_stream(cur)                        # `wav` was produced on the caller's stream
@@ -94,6 +100,8 @@ class FeaturePrefetcher:
         """Features of the most recent submit, ordered after their kernel on the caller's stream.  The buffer stays valid
         until the submit after next."""
         i = self._pending
+        if self.stream is None:
+            return self.feat[i]
         cur = torch.cuda.current_stream(self.fe.device)
         cur.wait_event(self._ready[i])
         j = 1 - i                                               # the other buffer was consumed by the step just issued
