@@ -110,3 +110,29 @@ def test_net_layout_matches_reference_variables(lib, name, width):
     # unsupported topologies are refused with a message
     cfg.num_classes = 100
     assert lib.tcr_tcresnet_create(C.byref(cfg), C.byref(h)) == -1 and b"num_classes" in lib.tcr_last_error()
+
+
+def test_deploy_frontend_plan_and_dscnn_layout(lib):
+    """Host-only entry points of the later additions: the deploy-path filterbank (method 2) and the DS-CNN training ABI."""
+    cfg = T._lib.FrontendCfg(16000, 16000, 640, 320, 0, 0, 64, 40, 80.0, 7600.0, 2)
+    assert lib.tcr_frontend_resolve(C.byref(cfg)) == 0 and cfg.nfft == 1024 and cfg.n_frames == 49
+    plan = np.zeros(lib.tcr_frontend_plan_bytes(C.byref(cfg)) // 4, np.float32)
+    assert lib.tcr_frontend_plan_init(C.byref(cfg), plan.ctypes.data) == 0
+    mel = np.zeros((513, 64), np.float32)
+    assert lib.tcr_frontend_plan_mel_matrix(C.byref(cfg), plan.ctypes.data, mel.ctypes.data) == 0
+    hz = 8000.0 / 512
+    start, end = int(1.5 + 80.0 / hz), int(7600.0 / hz)
+    assert np.all(mel[:start] == 0) and np.all(mel[end + 1:] == 0) and np.all(mel[start:end + 1].sum(1) > 0)
+    assert np.all((mel > 0).sum(1) <= 2)                         # every bin feeds at most two adjacent channels
+    bad = T._lib.FrontendCfg(16000, 16000, 640, 320, 0, 0, 64, 40, 80.0, 7600.0, 3)
+    assert lib.tcr_frontend_resolve(C.byref(bad)) == -1 and b"method" in lib.tcr_last_error()
+    dcfg = T._lib.DSCNNCfg(49, 10, 12, 276, 5, 10, 4, 2, 1, 2, 2, 0.96, 0.001)
+    h = C.c_void_p()
+    assert lib.tcr_dscnn_create(C.byref(dcfg), C.byref(h)) == 0
+    assert 0 < lib.tcr_dscnn_workspace_bytes(h, 4) < lib.tcr_dscnn_train_workspace_bytes(h, 4) < lib.tcr_dscnn_train_workspace_bytes(h, 8)
+    assert lib.tcr_dscnn_forward_train(h, None, None, None, None, 4, 4, 0.0, None, 0, None, None, None, None) == -1
+    assert lib.tcr_dscnn_backward(h, None, None, 4, None, 0, None, None) == -1
+    lib.tcr_dscnn_destroy(h)
+    # input stage: argument checks happen before any launch
+    assert lib.tcr_augment_fwd(None, None, None, None, None, None, None, 4, 16000, None, None) == -1
+    assert b"tcr_augment_fwd" in lib.tcr_last_error()
