@@ -232,3 +232,45 @@ def check_dscnn_train(lib, size, steps=3, grad_rtol=2e-4):
             d = np.abs(net._view(k[len("param3:"):]).cpu().numpy().reshape(ref.shape) - ref)
             assert d.max() < 4 * lr and np.mean(d > 1e-4) < 0.03, (k, d.max(), np.mean(d > 1e-4))
     return worst
+
+
+def check_dscnn_train_live(lib, size, grad_rtol=2e-4):
+    """DS-CNN train-mode forward + backward against the oracle evaluated on the spot (sizes without a committed fixture).
+    The waveform seed is the one of 12 candidates whose BN pre-activations stay farthest from the ReLU kink."""
+    import dataclasses
+    from oracle import dscnn_ref as D
+    blocks = D.net_def(size)
+    cfg = dataclasses.replace(R.FRONTEND_4020, num_mfccs=10)
+    labels = R.synth_labels(3).astype(np.float64)
+    best = None
+    for seed in range(2468, 2480):
+        p, s = D.init_params(blocks, seed=0)
+        wav = R.synth_waveforms(3, seed=seed)
+        f = D.forward(blocks, p, s, R.mfcc(wav, cfg), True)
+        margin = min(np.abs(c["xhat"] + p[k + "/beta"]).min() for k, c in f["cache"].items() if isinstance(c, dict))
+        if best is None or margin > best[0]:
+            best = (margin, wav, f, p, s)
+    margin, wav, f, p, s = best
+    assert margin > 2e-6, margin
+    g = D.backward(blocks, p, f, labels)
+    fe = make_frontend(lib, cfg.win, cfg.hop, num_mfccs=10)
+    net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
+    sd = dict(p)
+    sd.update(s)
+    net.load_state_dict(sd)
+    logits, probs, loss_sum = net.forward_train(fe(to_dev(lib, wav)), to_dev(lib, labels))
+    net.backward()
+    assert np.abs(logits.cpu().numpy() - f["logits"]).max() < LOGIT_TOL
+    assert abs(float(loss_sum) / 3 - D.loss(f["logits"], labels)) < 1e-4
+    worst = 0.0
+    for n, ref in g.items():
+        got = net.grad_view(n).cpu().numpy().reshape(ref.shape).astype(np.float64)
+        if n.endswith("/biases") and "fc1" not in n:
+            assert np.all(got == 0.0), n
+            continue
+        e = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3)
+        worst = max(worst, e)
+        assert e < grad_rtol, f"{n}: grad rel err {e}"
+    for k, ref in f["new_stats"].items():
+        assert np.abs(net._view(k).cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), k
+    return worst

@@ -144,6 +144,11 @@ def test_dscnn_train_steps(hip_lib, size):
     Cm.check_dscnn_train(hip_lib, size, steps=3)
 
 
+def test_dscnn_m_train_against_live_oracle(hip_lib):
+    """DS-CNN-M (172 channels: the 96-row blocks of the LDS-tiled pointwise wgrad end in a partial block)."""
+    Cm.check_dscnn_train_live(hip_lib, "M")
+
+
 def test_dscnn_train_full_batch(hip_lib):
     """DSCNN-L training step at batch 4096: 64 distinct utterances tiled 64x have the batch statistics of the 64, so
     logits / loss equal the oracle's on the 64, every tile gets identical rows, gradients agree, and the step is
