@@ -224,6 +224,15 @@ struct tcr_dscnn {
     int64_t param_floats, stat_floats, ss_floats;
     int c_pad;
     std::vector<tcr_tensor_info> tensors;
+    // backward: filter-gradient kernels on a second stream (see tcr_net in net.cpp); dz is double-buffered for it
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done[2] = {nullptr, nullptr};
+    ~tcr_dscnn() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        for (hipEvent_t e : ev_done) if (e) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 namespace tcr {
@@ -424,7 +433,7 @@ static std::vector<DsUnit> ds_units(const tcr_dscnn& net) {
 }
 
 struct DsTrainWs {
-    int64_t ss, kcoef, partial, pooled, dropped, dscale, dlogits, loss_utt, dpool, fc_partial, scratch, wt, ga, dz, total;
+    int64_t ss, kcoef, partial, pooled, dropped, dscale, dlogits, loss_utt, dpool, fc_partial, scratch, wt, ga, dz, dz2, total;
     std::vector<int64_t> raw, act, mean, invstd;
 };
 
@@ -466,6 +475,7 @@ static DsTrainWs ds_carve(const tcr_dscnn& net, int batch) {
     w.wt = take((int64_t)net.cfg.depth * net.cfg.depth);
     w.ga = take(max_act);
     w.dz = take(max_act);
+    w.dz2 = take(max_act);
     w.total = o;
     return w;
 }
@@ -579,12 +589,31 @@ extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, con
     TCR_TRY(launch_bias_grad(base + w.dlogits, batch, nc, grads + net->fcb_off, s));
     TCR_TRY(launch_head_bwd(base + w.dlogits, params + net->fcw_off, base + w.dscale, base + w.dpool, batch, cl, nc, s));
 
+    // Filter gradients run on a second stream, overlapped with the (HBM-bound) BN-backward / data-gradient chain of the units
+    // below.  They read dz, so dz alternates between two buffers and a buffer is rewritten only after the filter-gradient
+    // kernel that read it has finished (ev_done).
+    hipStream_t side = s;
+    if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) {
+        if (!net->side) {
+            bool ok = hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&net->ev_done[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) { set_error("tcr_dscnn_backward: cannot create the filter-gradient stream"); return TCR_ERR_HIP; }
+        }
+        side = net->side;
+    }
     const float* da = base + w.dpool;       // gradient wrt the current unit's activation
     int bcast = 1;                          // ([B][C] broadcast over the map for the last unit: average-pool backward)
     float* ga = base + w.ga;
-    float* dz = base + w.dz;
     float* kc = base + w.kcoef;
-    for (int ui = (int)units.size() - 1; ui >= 0; --ui) {
+    int flip = 0, used[2] = {0, 0};
+    for (int ui = (int)units.size() - 1; ui >= 0; --ui, flip ^= 1) {
+        float* dz = base + (flip ? w.dz2 : w.dz);
+        if (side != s && used[flip] && hipStreamWaitEvent(s, net->ev_done[flip], 0) != hipSuccess) {
+            set_error("tcr_dscnn_backward: stream wait failed");
+            return TCR_ERR_HIP;
+        }
         const DsUnit& u = units[ui];
         const DsLayer& l = net->layers[u.layer];
         const int pp = tcr_padded_len(u.P);
@@ -607,9 +636,13 @@ extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, con
         ap.k1 = f.k1; ap.k2 = f.k2; ap.k3 = f.k3; ap.dy = dz;
         ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.bcast = bcast;
         TCR_TRY(launch_bn_bwd_apply(ap, s));
+        if (side != s && (hipEventRecord(net->ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, net->ev_fork, 0) != hipSuccess)) {
+            set_error("tcr_dscnn_backward: stream fork failed");
+            return TCR_ERR_HIP;
+        }
         const float* xin = ui > 0 ? base + w.act[ui - 1] : nullptr;
         if (u.kind == DS_PW) {
-            TCR_TRY(launch_conv_wgrad(1, 1, 0, xin, dz, grads + u.w_off, base + w.scratch, batch, l.cin, l.cout, pp, u.P, pp, s));
+            TCR_TRY(launch_conv_wgrad(1, 1, 0, xin, dz, grads + u.w_off, base + w.scratch, batch, l.cin, l.cout, pp, u.P, pp, side));
             TCR_TRY(launch_transpose_weights(params + u.w_off, base + w.wt, 1, l.cin, l.cout, s));
             Conv1x1Args c1;
             c1.x = dz; c1.w = base + w.wt; c1.y = ga; c1.scale = nullptr; c1.shift = nullptr;
@@ -620,7 +653,7 @@ extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, con
             DsDwWgradArgs g;
             g.x = xin; g.dz = dz; g.partial = base + w.scratch; g.batch = batch; g.c = u.c; g.h_in = l.h_in; g.w_in = l.w_in; g.ppi = ppi;
             g.oh = l.oh; g.ow = l.ow; g.ppo = pp; g.sh = l.sh; g.sw = l.sw; g.pad_t = l.pad_t; g.pad_l = l.pad_l; g.utt_per_block = 0;
-            TCR_TRY(launch_dscnn_dw_wgrad(g, grads + u.w_off, s));
+            TCR_TRY(launch_dscnn_dw_wgrad(g, grads + u.w_off, side));
             DsDwBwdArgs d;
             d.dz = dz; d.w = params + u.w_off; d.dx = ga; d.planes = (int64_t)batch * u.c; d.c = u.c; d.h_in = l.h_in; d.w_in = l.w_in;
             d.ppi = ppi; d.oh = l.oh; d.ow = l.ow; d.ppo = pp; d.sh = l.sh; d.sw = l.sw; d.pad_t = l.pad_t; d.pad_l = l.pad_l;
@@ -631,10 +664,18 @@ extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, con
             g.feat = feat; g.dz = dz; g.partial = base + w.scratch; g.batch = batch; g.cout = l.cout;
             g.h_in = l.h_in; g.w_in = l.w_in; g.tp_in = tcr_padded_len(l.h_in); g.oh = l.oh; g.ow = l.ow; g.pp = pp;
             g.kh = l.kh; g.sh = l.sh; g.sw = l.sw; g.pad_t = l.pad_t; g.pad_l = l.pad_l;
-            TCR_TRY(launch_dscnn_conv1_wgrad(g, grads + u.w_off, s));
+            TCR_TRY(launch_dscnn_conv1_wgrad(g, grads + u.w_off, side));
+        }
+        if (side != s) {
+            if (hipEventRecord(net->ev_done[flip], side) != hipSuccess) { set_error("tcr_dscnn_backward: event record failed"); return TCR_ERR_HIP; }
+            used[flip] = 1;
         }
         da = ga;
         bcast = 0;
+    }
+    if (side != s && (hipEventRecord(net->ev_join, side) != hipSuccess || hipStreamWaitEvent(s, net->ev_join, 0) != hipSuccess)) {
+        set_error("tcr_dscnn_backward: stream join failed");
+        return TCR_ERR_HIP;
     }
     return TCR_OK;
 }
