@@ -43,10 +43,11 @@ struct tcr_net {
     // their own split-K slab, so they overlap the data-gradient / BN-backward chain of the layers below (each kernel of a
     // training step is too short to fill the chip on its own).  Created on first use; joined before the slab reduction.
     mutable hipStream_t side = nullptr;
-    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_down = nullptr;
     ~tcr_net() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_down) (void)hipEventDestroy(ev_down);
         if (side) (void)hipStreamDestroy(side);
     }
 };
@@ -66,6 +67,7 @@ struct Workspace {
     std::vector<int64_t> mean, invstd;      // saved batch statistics (train)
     std::vector<int64_t> wg, wtl;           // per-layer wgrad partial slabs / re-arranged dgrad weights (train)
     int64_t partial = -1, sums = -1, kcoef = -1;
+    int64_t partial2 = -1, kcoef2 = -1;     // second set: the shortcut branch's BN backward runs concurrently on the side stream
     int64_t dropped = -1, dscale = -1, dlogits = -1, loss_utt = -1, dpool = -1;
     int64_t wgrad_scratch = -1, wt = -1, fc_partial = -1;
     int64_t total = 0;
@@ -107,6 +109,8 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
         w.partial = take((int64_t)512 * 2 * cmax);
         w.sums = take(2 * cmax);
         w.kcoef = take(3 * (int64_t)align_up(cmax, 64));
+        w.partial2 = take((int64_t)512 * 2 * cmax);
+        w.kcoef2 = take(3 * (int64_t)align_up(cmax, 64));
         const int c = net.feat_c, nc = net.cfg.num_classes;
         w.dropped = take((int64_t)batch * c);
         w.dscale = take((int64_t)batch * c);
@@ -645,45 +649,53 @@ static BwdUnit bwd_unit_of(const TrainCtx& c, int li, const float* dpool) {
     return u;
 }
 
-static int bwd_unit_pre(const TrainCtx& c, const BwdUnit& u) {
+static int bwd_unit_pre(const TrainCtx& c, const BwdUnit& u, hipStream_t st, float* partial) {
     const ConvLayer& l = c.net->layers[u.li];
     ChanReduceArgs r;
     std::memset(&r, 0, sizeof(r));
     r.y = c.base + c.w.raw[u.li]; r.da = u.da; r.m1 = u.m1; r.m2 = u.m2;
     r.mean = c.base + c.w.mean[u.li]; r.invstd = c.base + c.w.invstd[u.li];
-    r.partial = c.base + c.w.partial;
+    r.partial = partial;
     r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout); r.bcast = u.da_bcast;
     int nchunk = 0;
-    TCR_TRY(launch_chan_reduce(1, r, &nchunk, c.s));
+    TCR_TRY(launch_chan_reduce(1, r, &nchunk, st));
     if (!c.sync_bn) return TCR_OK;
-    return launch_chan_sums(c.base + c.w.partial, nchunk, l.cout, c.base + c.w.sums, c.s);
+    return launch_chan_sums(partial, nchunk, l.cout, c.base + c.w.sums, st);
 }
 
-static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, const float* dpool) {
+// parts: 1 = BN backward (finalize + apply -> dy), 2 = weight gradient, 4 = data gradient.  bn_stream / partial / kc: where the
+// BN part runs (the shortcut branch's may run early on the side stream with the second scratch set).
+enum { BWD_BN = 1, BWD_WGRAD = 2, BWD_DGRAD = 4, BWD_ALL = 7 };
+
+static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, const float* dpool, int parts, hipStream_t bn_stream,
+                         float* partial, float* kc) {
     const tcr_net& net = *c.net;
     const ConvLayer& l = net.layers[u.li];
     const int tp = tcr_padded_len(l.tout), tpi = tcr_padded_len(l.tin);
-    float* kc = c.base + c.w.kcoef;
     const int64_t kstride = align_up(l.cout, 64);
-    BnBwdFinalizeArgs f;
-    f.partial = c.base + c.w.partial;
-    f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout);
-    f.sums = c.base + c.w.sums; f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[u.li];
-    f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
-    f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
-    f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
-    f.grad_scale = (float)((double)c.batch / c.bn_batch);
-    TCR_TRY(launch_bn_bwd_finalize(f, c.s));
     float* dy = c.base + c.w.dyb[u.li];
-    BnBwdApplyArgs a;
-    a.y = c.base + c.w.raw[u.li]; a.da = u.da; a.m1 = u.m1; a.m2 = u.m2; a.mean = c.base + c.w.mean[u.li];
-    a.k1 = f.k1; a.k2 = f.k2; a.k3 = f.k3; a.dy = dy;
-    a.total = (int64_t)c.batch * l.cout * tp; a.c = l.cout; a.t = l.tout; a.tp = tp; a.bcast = u.da_bcast;
-    TCR_TRY(launch_bn_bwd_apply(a, c.s));
+    if (parts & BWD_BN) {
+        BnBwdFinalizeArgs f;
+        f.partial = partial;
+        f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout);
+        f.sums = c.base + c.w.sums; f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[u.li];
+        f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
+        f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
+        f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
+        f.grad_scale = (float)((double)c.batch / c.bn_batch);
+        TCR_TRY(launch_bn_bwd_finalize(f, bn_stream));
+        BnBwdApplyArgs a;
+        a.y = c.base + c.w.raw[u.li]; a.da = u.da; a.m1 = u.m1; a.m2 = u.m2; a.mean = c.base + c.w.mean[u.li];
+        a.k1 = f.k1; a.k2 = f.k2; a.k3 = f.k3; a.dy = dy;
+        a.total = (int64_t)c.batch * l.cout * tp; a.c = l.cout; a.t = l.tout; a.tp = tp; a.bcast = u.da_bcast;
+        TCR_TRY(launch_bn_bwd_apply(a, bn_stream));
+    }
     // weight gradient
     const float* x = layer_input(net, c.w, c.base, c.feat, l);
-    if (conv_wgrad_deferrable(l.k, l.cin, l.cout)) {     // slabs summed for all layers at once at the end of backward
-        if (c.side != c.s) {                            // fork: the side stream waits for dy, the main stream carries on
+    if (!(parts & BWD_WGRAD)) {
+        // (not this call)
+    } else if (conv_wgrad_deferrable(l.k, l.cin, l.cout)) {     // slabs summed for all layers at once at the end of backward
+        if (c.side != c.s && bn_stream != c.side) {     // fork: the side stream waits for dy, the main stream carries on
             if (hipEventRecord(c.net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(c.side, c.net->ev_fork, 0) != hipSuccess) {
                 set_error("tcr_net_backward: stream fork failed");
                 return TCR_ERR_HIP;
@@ -694,7 +706,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     } else
         TCR_TRY(launch_conv_wgrad(l.k, l.stride, l.pad_lo, x, dy, grads + l.w_off, c.base + c.w.wgrad_scratch,
                                   c.batch, l.cin, l.cout, tpi, l.tout, tp, c.s));
-    if (l.in_act < 0) return TCR_OK;        // no gradient flows into the features
+    if (l.in_act < 0 || !(parts & BWD_DGRAD)) return TCR_OK;        // (no gradient flows into the features)
     // data gradient into gact[in_act]; the shortcut branch of the block adds its contribution in the same pass
     float* wt = c.base + c.w.wtl[u.li];       // filled for every layer by the first backward stage
     float* dx = c.base + c.w.gact[l.in_act];
@@ -761,7 +773,8 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
         if (!net->side) {
             if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) != hipSuccess) {
+                hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&net->ev_down, hipEventDisableTiming) != hipSuccess) {
                 set_error("tcr_net_backward: cannot create the weight-gradient stream");
                 return TCR_ERR_HIP;
             }
@@ -794,8 +807,39 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
             }
             TCR_TRY(launch_dgrad_weights_multi(dm, c.s));
         }
-        if (st > 0) TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, order[st - 1], dpool), grads, dpool));
-        if (st < nu) TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, order[st], dpool)));
+        // Without cross-replica statistics the shortcut ("down") unit of a block is started EARLY on the side stream: its BN
+        // backward and weight gradient depend only on the block-output gradient, which is ready when the block begins; only
+        // its data gradient (accumulated onto conv_a's) stays in the main chain.
+        const bool early = !c.sync_bn && c.side != c.s;
+        auto down_of_block_starting_at = [&](int li) { for (const Block& b : net->blocks) if (b.b == li && b.down >= 0) return b.down; return -1; };
+        auto is_down = [&](int li) { for (const Block& b : net->blocks) if (b.down == li) return true; return false; };
+        float* partial = c.base + c.w.partial;
+        float* kc = c.base + c.w.kcoef;
+        if (st > 0) {
+            const int li = order[st - 1];
+            if (early && is_down(li)) {
+                if (hipStreamWaitEvent(c.s, net->ev_down, 0) != hipSuccess) { set_error("tcr_net_backward: stream wait failed"); return TCR_ERR_HIP; }
+                TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, li, dpool), grads, dpool, BWD_DGRAD, c.s, partial, kc));
+            } else {
+                TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, li, dpool), grads, dpool, BWD_ALL, c.s, partial, kc));
+            }
+        }
+        if (st < nu) {
+            const int li = order[st];
+            const int dn = early ? down_of_block_starting_at(li) : -1;
+            if (dn >= 0) {
+                if (hipEventRecord(net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(c.side, net->ev_fork, 0) != hipSuccess) {
+                    set_error("tcr_net_backward: stream fork failed");
+                    return TCR_ERR_HIP;
+                }
+                const BwdUnit ud = bwd_unit_of(c, dn, dpool);
+                TCR_TRY(bwd_unit_pre(c, ud, c.side, c.base + c.w.partial2));
+                TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_BN, c.side, c.base + c.w.partial2, c.base + c.w.kcoef2));
+                if (hipEventRecord(net->ev_down, c.side) != hipSuccess) { set_error("tcr_net_backward: event record failed"); return TCR_ERR_HIP; }
+                TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_WGRAD, c.side, c.base + c.w.partial2, c.base + c.w.kcoef2));
+            }
+            if (!(early && is_down(li))) TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, li, dpool), c.s, partial));
+        }
         if (st == nu) {         // every layer's split-K slabs -> dW, one launch (after the side stream has drained)
             if (c.side != c.s && (hipEventRecord(net->ev_join, c.side) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join, 0) != hipSuccess)) {
                 set_error("tcr_net_backward: stream join failed");
