@@ -441,6 +441,21 @@ extern "C" int tcr_net_forward_infer(const tcr_net* net, const float* params, co
 // ---- train-mode forward -----------------------------------------------------------------------
 namespace tcr {
 
+// the net's internal second stream + events, created on first use
+static int side_stream(const tcr_net& net, hipStream_t* out) {
+    if (!net.side) {
+        if (hipStreamCreateWithFlags(&net.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&net.ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&net.ev_join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&net.ev_down, hipEventDisableTiming) != hipSuccess) {
+            set_error("cannot create the internal side stream");
+            return TCR_ERR_HIP;
+        }
+    }
+    *out = net.side;
+    return TCR_OK;
+}
+
 struct TrainCtx {
     bool sync_bn;           // cross-replica statistics: partial rows are pre-reduced into `sums` for the host all-reduce
     const tcr_net* net;
@@ -468,7 +483,7 @@ static bool fused_with_down(const tcr_net& net, int li, int* down_of_a, int* a_o
     return false;
 }
 
-static int fwd_unit_pre(const TrainCtx& c, int li) {
+static int fwd_unit_pre(const TrainCtx& c, int li, hipStream_t rs, float* partial) {     // rs / partial: stream and scratch of the statistics
     const ConvLayer& l = c.net->layers[li];
     const float* x = layer_input(*c.net, c.w, c.base, c.feat, l);
     float* raw = c.base + c.w.raw[li];
@@ -489,20 +504,24 @@ static int fwd_unit_pre(const TrainCtx& c, int li) {
     if (!conv_done) TCR_TRY(conv_forward(*c.net, l, x, c.params, raw, nullptr, nullptr, nullptr, false, EPI_RAW, c.batch, c.s));
     ChanReduceArgs r;
     std::memset(&r, 0, sizeof(r));
-    r.y = raw; r.partial = c.base + c.w.partial;
+    r.y = raw; r.partial = partial;
     r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout);
+    if (rs != c.s && (hipEventRecord(c.net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(rs, c.net->ev_fork, 0) != hipSuccess)) {
+        set_error("tcr_net_forward_train: stream fork failed");     // (the conv above ran on the main stream)
+        return TCR_ERR_HIP;
+    }
     int nchunk = 0;
-    TCR_TRY(launch_chan_reduce(0, r, &nchunk, c.s));
+    TCR_TRY(launch_chan_reduce(0, r, &nchunk, rs));
     if (!c.sync_bn) return TCR_OK;          // the finalize kernel sums the partial rows itself
-    return launch_chan_sums(c.base + c.w.partial, nchunk, l.cout, c.base + c.w.sums, c.s);
+    return launch_chan_sums(partial, nchunk, l.cout, c.base + c.w.sums, rs);
 }
 
 // statistics -> scale/shift, moving-stat update, normalise (+ReLU / +residual)
-static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* res) {
+static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* res, hipStream_t rs, float* partial) {
     const ConvLayer& l = c.net->layers[li];
     float* ss = c.base + c.w.ss + l.ss_off;
     BnFinalizeArgs f;
-    f.partial = c.base + c.w.partial;
+    f.partial = partial;
     f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout);
     f.sums = c.base + c.w.sums;
     f.gamma = c.params + l.gamma_off; f.beta = c.params + l.beta_off;
@@ -511,12 +530,12 @@ static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* r
     f.mean = c.base + c.w.mean[li]; f.invstd = c.base + c.w.invstd[li];
     f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
     f.decay = c.net->cfg.bn_decay; f.eps = c.net->cfg.bn_eps;
-    TCR_TRY(launch_bn_finalize(f, c.s));
+    TCR_TRY(launch_bn_finalize(f, rs));
     BnApplyArgs a;
     a.y = c.base + c.w.raw[li]; a.scale = ss; a.shift = ss + l.c_pad; a.res = res; a.out = c.base + c.w.act[li];
     a.total = (int64_t)c.batch * l.cout * tcr_padded_len(l.tout);
     a.c = l.cout; a.t = l.tout; a.tp = tcr_padded_len(l.tout); a.relu = l.relu;
-    return launch_bn_apply(a, c.s);
+    return launch_bn_apply(a, rs);
 }
 
 // residual source of a unit: conv_b of a block adds the block's shortcut
@@ -549,15 +568,35 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
     c.bn_batch = sync_bn ? (double)global_batch : (double)batch;
     c.sync_bn = sync_bn != 0;
     c.s = static_cast<hipStream_t>(stream);
+    c.side = c.s;
+    if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1 && !sync_bn) TCR_TRY(side_stream(*net, &c.side));
     const int nu = (int)net->units.size();
     TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_forward_train: bad stage range [%d, %d)", stage_begin, stage_end);
     for (int st = stage_begin; st < stage_end; ++st) {
+        // Without cross-replica statistics the BN chain (statistics -> finalize -> normalise) of a block's shortcut conv runs
+        // on the side stream next to conv_a's: the two raw outputs come from ONE fused launch and nothing reads the shortcut
+        // activation before conv_b's residual add.
+        const bool early = !c.sync_bn && c.side != c.s;
+        auto is_down = [&](int li) { for (const Block& b : net->blocks) if (b.down == li) return true; return false; };
+        auto is_block_out_with_down = [&](int li) { for (const Block& b : net->blocks) if (b.b == li && b.down >= 0) return true; return false; };
+        float* partial = c.base + c.w.partial;
         if (st > 0) {
             const int li = net->units[st - 1];
-            TCR_TRY(fwd_unit_post(c, li, stats, unit_residual(c, li)));
+            if (early && is_down(li)) {
+                TCR_TRY(fwd_unit_post(c, li, stats, unit_residual(c, li), c.side, c.base + c.w.partial2));
+                if (hipEventRecord(net->ev_down, c.side) != hipSuccess) { set_error("tcr_net_forward_train: event record failed"); return TCR_ERR_HIP; }
+            } else {
+                if (early && is_block_out_with_down(li) && hipStreamWaitEvent(c.s, net->ev_down, 0) != hipSuccess) {
+                    set_error("tcr_net_forward_train: stream wait failed");
+                    return TCR_ERR_HIP;
+                }
+                TCR_TRY(fwd_unit_post(c, li, stats, unit_residual(c, li), c.s, partial));
+            }
         }
         if (st < nu) {
-            TCR_TRY(fwd_unit_pre(c, net->units[st]));
+            const int li = net->units[st];
+            if (early && is_down(li)) TCR_TRY(fwd_unit_pre(c, li, c.side, c.base + c.w.partial2));
+            else TCR_TRY(fwd_unit_pre(c, li, c.s, partial));
         } else {
             HeadArgs h;
             std::memset(&h, 0, sizeof(h));
@@ -769,18 +808,7 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     c.sync_bn = sync_bn != 0;
     c.s = static_cast<hipStream_t>(stream);
     c.side = c.s;
-    if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) {
-        if (!net->side) {
-            if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&net->ev_down, hipEventDisableTiming) != hipSuccess) {
-                set_error("tcr_net_backward: cannot create the weight-gradient stream");
-                return TCR_ERR_HIP;
-            }
-        }
-        c.side = net->side;
-    }
+    if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) TCR_TRY(side_stream(*net, &c.side));
     const std::vector<int> order = backward_order(*net);
     const int nu = (int)order.size();
     TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);
