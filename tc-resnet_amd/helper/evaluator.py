@@ -36,6 +36,7 @@ class SingleLabelAudioEvaluator:
         iters = self.args.evaluation_iterations or max(self.dataset.num_samples // self.dataset.batch_size, 1)
         correct = total = 0
         losses, times = [], []
+        all_probs, all_labels = [], []
         for _ in range(int(iters)):
             wavs, labels = self.dataset.next_batch()
             t0 = time.perf_counter()
@@ -45,8 +46,13 @@ class SingleLabelAudioEvaluator:
             correct += int((pred == truth).sum())
             total += int(labels.shape[0])
             losses.append(float(self.model.total_loss))
+            all_probs.append(self.model.outputs.detach().cpu().numpy())         # np.vstack of the fetched batches (helper/base.py:86-104)
+            all_labels.append(labels.detach().cpu().numpy())
             times.append(time.perf_counter() - t0)
         out = {"accuracy": correct / max(total, 1), "total_loss": float(np.mean(losses)), "batch_infer_time": float(np.mean(times)),
                "unit_infer_time": float(np.mean(times)) / self.dataset.batch_size, "num_evaluated": total}
-        self.log.info("%s", out)
+        from ..metrics import audio_metrics
+        names = getattr(self.dataset, "label_names", None) or [str(i) for i in range(all_probs[0].shape[1])]
+        out.update(audio_metrics(np.vstack(all_probs), np.vstack(all_labels), names, self.dataset_name))
+        self.log.info("%s", {k: v for k, v in out.items() if not k.startswith(("precision/", "recall/", "f1score/", "ap/", "classification_report/"))})
         return out

@@ -60,6 +60,9 @@ def test_reference_command_lines_train_then_evaluate(emu_runtime, tmp_path):
     eargs = evaluate_audio.parse_arguments(REF_EVAL_CMD.format(d=tmp_path).split())
     out = evaluate_audio.main(eargs)
     assert out["num_evaluated"] == 6 and 0.0 <= out["accuracy"] <= 1.0 and np.isfinite(out["total_loss"])
+    split = [k for k in out if k.startswith("accuracy/")][0].split("/", 1)[1]
+    assert out[f"accuracy/{split}"] == out["accuracy"] and 0.0 <= out[f"top5_accuracy/{split}"] <= 1.0
+    assert {f"mAP/{split}/{a}" for a in ("macro", "micro", "weighted", "samples")} <= set(out) and f"classification_report/{split}" in out
 
 
 def test_model_build_matches_oracle(emu_runtime):
@@ -110,3 +113,26 @@ def test_model_build_matches_oracle(emu_runtime):
 def test_lr_schedule():
     from tcresnet_amd.helper.trainer import piecewise_constant
     assert [piecewise_constant(s, [10000, 20000], [0.1, 0.01, 0.001]) for s in (0, 10000, 10001, 20000, 20001)] == [0.1, 0.1, 0.01, 0.01, 0.001]
+
+
+def test_audio_metrics_match_reference_formulas():
+    """Keys and values of the reference's non-tensor metric ops (metrics/ops/non_tensor_ops.py, metrics/funcs.py)."""
+    from tcresnet_amd.metrics import audio_metrics, top_n_accuracy
+    rng = np.random.RandomState(0)
+    names = ["__null__", "yes", "no", "up", "down", "left"]
+    labels = rng.randint(0, 6, 64)
+    onehot = np.eye(6)[labels]
+    logits = rng.randn(64, 6) + 2.0 * onehot
+    probs = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+    m = audio_metrics(probs, onehot, names, "valid")
+    pred = probs.argmax(1)
+    assert m["accuracy/valid"] == np.mean(pred == labels)
+    assert m["top5_accuracy/valid"] == np.mean([labels[i] in np.argsort(-probs[i])[:5] for i in range(64)]) == top_n_accuracy(labels, probs, 5)
+    tp = np.sum((pred == 1) & (labels == 1))
+    assert abs(m["precision/valid/yes"] - tp / max(np.sum(pred == 1), 1)) < 1e-12 and abs(m["recall/valid/yes"] - tp / np.sum(labels == 1)) < 1e-12
+    order = np.argsort(-probs[:, 2])                            # average precision of class "no" by its definition
+    hits = (labels[order] == 2)
+    ap = np.sum(np.cumsum(hits)[hits] / (np.nonzero(hits)[0] + 1)) / hits.sum()
+    assert abs(m["ap/valid/no"] - ap) < 1e-12
+    assert abs(m["mAP/valid/macro"] - np.mean([m[f"ap/valid/{n}"] for n in names])) < 1e-12
+    assert m["classification_report/valid"].startswith("[ClassificationReport]")
