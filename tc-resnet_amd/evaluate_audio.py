@@ -6,6 +6,7 @@ import argparse
 import logging
 from typing import List
 
+from .datasets.audio_data_wrapper import SingleLabelAudioDataWrapper
 from .datasets.synthetic import SyntheticAudioDataWrapper
 from .factory import audio_nets
 from .factory.base import TFModel
@@ -29,7 +30,8 @@ def parse_arguments(arguments: List[str] = None):
 
 def main(args):
     logging.basicConfig(level=logging.INFO)
-    dataset = SyntheticAudioDataWrapper(args, None, args.dataset_split_name[0], False)
+    wrapper = SyntheticAudioDataWrapper if args.dataset_path == "synthetic" else SingleLabelAudioDataWrapper
+    dataset = wrapper(args, None, args.dataset_split_name[0], False)
     wavs, labels = dataset.get_input_and_output_op()
     model = getattr(audio_nets, args.model)(args, dataset)
     model.build(wavs=wavs, labels=labels, is_training=False)

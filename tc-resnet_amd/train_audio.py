@@ -1,5 +1,5 @@
 """`python -m tcresnet_amd.train_audio <global flags> <ModelName> <model flags>` -- same command-line shape as
-the reference's train_audio.py (:19-77).  Data: --dataset_path synthetic (the tf.data input pipeline is outside
+the reference's train_audio.py (:19-77).  Data: --dataset_path <dir of WAVs> or `synthetic` (the tf.data file handling is outside
 the hot path).  Multi-GPU: launch with torch.distributed.run, one process per GPU."""
 from __future__ import annotations
 
@@ -11,6 +11,7 @@ from typing import List
 import torch
 import torch.distributed as dist
 
+from .datasets.audio_data_wrapper import SingleLabelAudioDataWrapper
 from .datasets.synthetic import SyntheticAudioDataWrapper
 from .factory import audio_nets
 from .factory.base import TFModel
@@ -38,6 +39,9 @@ def add_data_arguments(parser):
     g.add_argument("--shuffle", dest="shuffle", action="store_true")
     g.add_argument("--no-shuffle", dest="shuffle", action="store_false")
     g.set_defaults(shuffle=True)
+    g.add_argument("--add_null_class", dest="add_null_class", action="store_true")
+    g.add_argument("--no-add_null_class", dest="add_null_class", action="store_false")
+    g.set_defaults(add_null_class=True)
     g.add_argument("--buffer_size", default=1000, type=int)
     g.add_argument("--prefetch_factor", default=100, type=int)
 
@@ -61,9 +65,8 @@ def train(args):
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl")
-    if args.dataset_path != "synthetic":
-        raise NotImplementedError("only --dataset_path synthetic: WAV decode/augmentation is outside the hot path (SURVEY 8(f) #1)")
-    dataset = SyntheticAudioDataWrapper(args, None, args.dataset_split_name[0], True)
+    wrapper = SyntheticAudioDataWrapper if args.dataset_path == "synthetic" else SingleLabelAudioDataWrapper
+    dataset = wrapper(args, None, args.dataset_split_name[0], True)
     wavs, labels = dataset.get_input_and_output_op()
     model = getattr(audio_nets, args.model)(args, dataset)
     model.build(wavs=wavs, labels=labels, is_training=True)

@@ -136,3 +136,49 @@ def test_audio_metrics_match_reference_formulas():
     assert abs(m["ap/valid/no"] - ap) < 1e-12
     assert abs(m["mAP/valid/macro"] - np.mean([m[f"ap/valid/{n}"] for n in names])) < 1e-12
     assert m["classification_report/valid"].startswith("[ClassificationReport]")
+
+
+def _write_wav(path, pcm, rate=16000):
+    import struct
+    pcm = np.asarray(pcm, dtype="<i2")
+    body = b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, rate, rate * 2, 2, 16) + b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes()
+    path.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def test_wav_directory_dataset_train_and_evaluate(emu_runtime, tmp_path):
+    """The reference's on-disk layout (<path>/<split>/<label>/*.wav, _background_noise_, silent samples) through the
+    reference command lines: decode + crop/pad + shift + background mix on the device input stage, then train / evaluate."""
+    from tcresnet_amd import train_audio, evaluate_audio
+    from tcresnet_amd.datasets.audio_data_wrapper import SingleLabelAudioDataWrapper
+    rng = np.random.RandomState(0)
+    words = ["down", "go", "left", "no", "off", "on", "right", "stop", "unknown", "up", "yes"]      # + __null__ = 12 classes
+    for split, per in (("train", 2), ("valid", 1)):
+        for w in words:
+            d = tmp_path / "data" / split / w
+            d.mkdir(parents=True)
+            for k in range(per):
+                _write_wav(d / f"{k}.wav", rng.randint(-8000, 8000, rng.randint(12000, 18000)))
+        bg = tmp_path / "data" / split / "_background_noise_"
+        bg.mkdir()
+        _write_wav(bg / "noise.wav", rng.randint(-3000, 3000, 40000))
+        _write_wav(bg / "short.wav", rng.randint(-3000, 3000, 100))             # shorter than a clip: cannot be cropped, skipped
+    cmd = REF_TRAIN_CMD.replace("--dataset_path synthetic", f"--dataset_path {tmp_path / 'data'}").replace("--num_silent 1854", "--num_silent 2")
+    args = train_audio.parse_arguments(cmd.format(d=tmp_path / "ckpt").split())
+    ds = SingleLabelAudioDataWrapper(args, None, "train", True)
+    assert ds.label_names == ["__null__"] + words and ds.num_samples == 24 and len(ds.background) == 1
+    wavs, labels = ds.next_batch()
+    assert tuple(wavs.shape) == (6, 16000, 1) and tuple(labels.shape) == (6, 12) and float(wavs.abs().max()) <= 1.0
+    assert torch.all(labels.sum(1) == 1)
+    # a silent sample without background is all zeros; with the mix it is the scaled background crop
+    sil = [i for i, f in enumerate(ds.filenames) if f == ""]
+    from tcresnet_amd.datasets import augmentation_factory as F
+    z = F.anchored_slice_or_pad(ds.pool, sil[:1], 16000, background_data=ds.background, is_training=False)
+    assert float(z.abs().max()) == 0.0
+    trainer = train_audio.train(args)
+    assert trainer.global_step == 3 and np.isfinite(float(trainer.model.total_loss))
+    ecmd = REF_EVAL_CMD.replace("--dataset_path synthetic", f"--dataset_path {tmp_path / 'data'}").replace("--num_silent 258", "--num_silent 1")
+    out = evaluate_audio.main(evaluate_audio.parse_arguments(ecmd.format(d=tmp_path / "ckpt").split()))
+    assert out["num_evaluated"] == 6 and "accuracy/valid" in out and np.isfinite(out["total_loss"])
+    with pytest.raises(ValueError):
+        bad = train_audio.parse_arguments(cmd.replace("--num_classes 12", "--num_classes 10").format(d=tmp_path / "c2").split())
+        SingleLabelAudioDataWrapper(bad, None, "train", True)
