@@ -113,13 +113,14 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
 
 int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
     const int tiles = ceil_div(a.cout, 16);
-    const int mt = tiles >= 3 ? 3 : tiles;
+    const int mt = tiles >= 12 ? 6 : (tiles >= 3 ? 3 : tiles);       // (9 tiles per wave spill: 1.5x slower)       // wide layers: 96 channels per wave halve the re-reads of x
     const dim3 grid(ceil_div(a.npos, 256), ceil_div(tiles, mt));
 #define TCR_L1(MT_)                                                                                         \
     if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_mfma_kernel<MT_, MF_RAW>), grid, dim3(256), 0, s, a);    \
     else hipLaunchKernelGGL((conv1x1_mfma_kernel<MT_, MF_AFFINE>), grid, dim3(256), 0, s, a)
     if (mt == 1) { TCR_L1(1); }
     else if (mt == 2) { TCR_L1(2); }
+    else if (mt == 6) { TCR_L1(6); }
     else { TCR_L1(3); }
 #undef TCR_L1
     return check_launch("conv1x1_mfma_kernel");
