@@ -191,17 +191,19 @@ static int launch_dscnn_depthwise(const DsDwArgs& d, int batch, hipStream_t s) {
     return check_launch("dscnn_depthwise_kernel");
 }
 
-// pooled[b][c][HALO] = mean over the P positions of plane (b, c): one wavefront per plane (coalesced row read +
-// 64-lane shuffle reduction); feeds head_fwd_kernel with T = 1 when the map is large (DS-CNN: 13 x 5 = 65).
+// pooled[b][c][HALO] = mean over the P positions of plane (b, c); feeds head_fwd_kernel with T = 1 when the map is large
+// (DS-CNN: 13 x 5 = 65).
 __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ pooled, int64_t rows, int p, int pp) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + row * pp + kHalo;
+    // 16 lanes per plane (16 planes per workgroup: more rows in flight than one wavefront per 65-element plane); the 16
+    // partial sums are combined with a fixed xor tree
+    const int t16 = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const float* xr = x + (row < rows ? row : rows - 1) * pp + kHalo;
     float s = 0.f;
-    for (int i = lane; i < p; i += 64) s += xr[i];
-    s = wave_sum(s);
-    if (lane == 0) pooled[row * (1 + 2 * kHalo) + kHalo] = s / (float)p;
+    for (int i = t16; i < p; i += 16) s += xr[i];
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (t16 == 0 && row < rows) pooled[row * (1 + 2 * kHalo) + kHalo] = s / (float)p;
 }
 
 struct DsLayer {
@@ -387,7 +389,7 @@ extern "C" int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params
     const DsLayer& last = net->layers.back();
     const int P = last.oh * last.ow;
     const int64_t rows = (int64_t)batch * last.cout;
-    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, s, (const float*)buf[cur], buf[cur ^ 1], rows, P,
+    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, (const float*)buf[cur], buf[cur ^ 1], rows, P,
                        tcr_padded_len(P));
     TCR_TRY(check_launch("plane_mean_kernel"));
     HeadArgs h;
@@ -551,7 +553,7 @@ extern "C" int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params
     const DsLayer& last = net->layers.back();
     const int P = last.oh * last.ow;
     const int64_t rows = (int64_t)batch * last.cout;
-    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, s, x, base + w.pooled, rows, P, tcr_padded_len(P));
+    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, x, base + w.pooled, rows, P, tcr_padded_len(P));
     TCR_TRY(check_launch("plane_mean_kernel"));
     HeadArgs h;
     std::memset(&h, 0, sizeof(h));
