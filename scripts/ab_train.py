@@ -27,15 +27,19 @@ def timeit(fn, n=20, warm=5):
     ts.sort()
     return ts[len(ts) // 2]
 
-for name, ch in () if os.environ.get("AB_DS_ONLY") else (("TCResNet8", [16, 24, 32, 48]), ("TCResNet14", [24, 36, 36, 48, 48, 72, 72])):
+for name, ch in () if os.environ.get("AB_DS_ONLY") else (("TCResNet8", [16, 24, 32, 48]), ("TCResNet14", [24, 36, 36, 48, 48, 72, 72]), ("TCResNet8", [24, 36, 48, 72])):
+    ref = None
     for cap in (0, 1, 2, 4):
         for unroll in (0,):
             lib.tcr_tune(6, cap)
             net = T.TCResNet(name, ch, 40, fe.n_frames, 12, device=dev)
             net.init_xavier(0)
+            net.forward_train(feat, lab, keep_prob=0.5, seed=1); g = net.backward().clone()
+            if cap == 0: ref = g
+            same = bool(torch.equal(g, ref)) if cap == 0 else None
             def train():
                 net.forward_train(feat, lab, keep_prob=0.5, seed=1); net.backward(); net.sgd_momentum_step(0.1, 0.9, 0.001)
-            print(f"{name} ksplit={cap}: {timeit(train):9.1f} us", flush=True)
+            print(f"{name} ksplit={cap}: {timeit(train):9.1f} us  bitwise_vs_auto={same} maxdiff={float((g - ref).abs().max()):.3e}", flush=True)
             del net
 lib.tcr_tune(6, 0)
 fe3 = T.Frontend(window_size_samples=640, window_stride_samples=320, num_mfccs=10, device=dev)
