@@ -348,15 +348,16 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     a.magnitude = cfg->method != 0;
     a.no_dct = cfg->method == 1;
     a.log_floor = cfg->method == 2;
+    a.rounds = 0;
     a.aligned = ((cfg->n_samples | cfg->hop) & 1) == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0;
     const int grid = ceil_div(a.total_frames, 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int knob = tune_get(TCR_TUNE_FRONTEND);
-    if (knob == 0 || knob == 5) {           // default: packed-FP32 kernel (frontend_pk.hip) where its window specialisation applies
-        const int rc = launch_frontend_pk(cfg->nfft / 2, a, grid, s);
+    if (knob == 0 || knob == 5 || knob >= 10) {           // default: packed-FP32 kernel (frontend_pk.hip) where its window specialisation applies
+        const int rc = launch_frontend_pk(cfg->nfft / 2, a, s);
         if (rc != 1) return rc;
     }
-    const int var = knob == 0 || knob == 5 ? 3 : (knob - 1) & 3;
+    const int var = knob == 0 || knob == 5 || knob >= 10 ? 3 : (knob - 1) & 3;
 #define TCR_FE(NC_)                                                                                     \
     switch (var) {                                                                                      \
         case 0: hipLaunchKernelGGL((frontend_kernel<NC_, 0>), dim3(grid), dim3(256), 0, s, a); break;   \

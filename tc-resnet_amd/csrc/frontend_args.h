@@ -20,9 +20,10 @@ struct FrontendArgs {
     int no_dct;         // 1: log-mel preprocessor (output = log-mel, no DCT)
     int log_floor;      // 0: log(x + 1e-6) (tf.contrib.signal path); 1: log(max(x, 1e-12)) (contrib_audio.mfcc op)
     int aligned;        // frame starts are 8-byte aligned -> float2 loads
+    int rounds;         // packed kernel: rounds of (4096 / nc) frames per workgroup (set by launch_frontend_pk)
 };
 
 // packed-FP32 kernel; nc = nfft / 2 (256 or 512); returns 1 when the general kernel must be used
-int launch_frontend_pk(int nc, const FrontendArgs& a, int grid, hipStream_t s);
+int launch_frontend_pk(int nc, const FrontendArgs& a, hipStream_t s);
 
 }  // namespace tcr

@@ -204,9 +204,11 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     __syncthreads();
 
     const float inv_frames = 1.0f / (float)a.n_frames;
+    const int rounds = a.rounds;            // <= ROUNDS; chosen by the launcher so that the grid fills whole dispatch waves
+    const int fpw = rounds * FPR;           // frames per workgroup
     v2 xa[QV];
     auto load_frame = [&](int rr, v2 (&dst)[QV]) {
-        int g = blockIdx.x * 64 + rr * FPR + f;
+        int g = blockIdx.x * fpw + rr * FPR + f;
         g = min(g, a.total_frames - 1);
         int n = (int)(((float)g + 0.5f) * inv_frames);          // g / n_frames: float multiply + one-step fix-up
         n += (n + 1) * a.n_frames <= g ? 1 : (n * a.n_frames > g ? -1 : 0);
@@ -216,13 +218,13 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
         for (int q = 0; q < QV; ++q) dst[q] = *reinterpret_cast<const v2*>(src + 2 * (SUB * (l + 16 * q) + u));     // (8-byte aligned: launcher)
     };
     // (A frame's lanes never straddle a wavefront: the phases of a round are ordered by wave-local sync points.)
-    for (int r = 0; r < ROUNDS; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         // ---------------- load (+ prefetch of the next round) + window + first radix-16 pass ----------------
         v2 v[16];
         if (r == 0) load_frame(r, xa);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = q < QV ? xa[q] * wnd[q] : (v2){0.f, 0.f};
-        if (r + 1 < ROUNDS) load_frame(r + 1, xa);
+        if (r + 1 < rounds) load_frame(r + 1, xa);
         pk_dft16(v);
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) s_x[unit * UNIT + k2 * XLD + l] = c_mul(v[k2], tw[k2]);
@@ -313,8 +315,8 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     // ---------------- DCT-II (lane == frame, wave-uniform coefficients) + store ----------------
     const int fr = tid & 63;
     const int w = tid >> 6;
-    const int g = blockIdx.x * 64 + fr;
-    const bool valid = g < a.total_frames;
+    const int g = blockIdx.x * fpw + fr;
+    const bool valid = fr < fpw && g < a.total_frames;
     const int gg = valid ? g : a.total_frames - 1;
     const int n = gg / a.n_frames;
     const int t = gg - n * a.n_frames;
@@ -350,11 +352,34 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
 
 // returns 1 (nothing launched) when the configuration needs the general kernel: unaligned frames, or a window whose
 // valid radix-16 inputs differ from lane to lane
-int launch_frontend_pk(int nc, const FrontendArgs& a, int grid, hipStream_t s) {
+int launch_frontend_pk(int nc, const FrontendArgs& a0, hipStream_t s) {
+    const FrontendArgs& a_in = a0;
+    int grid = 0;
     const int sub = nc / 256;
-    if (!a.aligned || (a.win & 1) || (a.win / 2) % (16 * sub) != 0) return 1;
-    if (a.total_frames >= (1 << 23)) return 1;              // (the frame -> utterance split uses a float reciprocal)
-    const int qv = a.win / (32 * sub);
+    if (!a_in.aligned || (a_in.win & 1) || (a_in.win / 2) % (16 * sub) != 0) return 1;
+    if (a_in.total_frames >= (1 << 23)) return 1;              // (the frame -> utterance split uses a float reciprocal)
+    const int qv = a_in.win / (32 * sub);
+    // Frames per workgroup: rounds x (4096 / nc) frames, at most 64.  All workgroups cost the same (rounds + ~0.85 of a
+    // round for setup and the DCT), so the grid drains in dispatch waves of (2 workgroups x CUs); a last wave that leaves
+    // every CU with one workgroup runs ~1.6x faster.  Model fitted on MI355X at B = 1024 .. 16384 (scripts/fe_rounds.py,
+    // within 4 %); the round count that minimises it wins 4 % at B = 4096 and 8 % at B = 1024 over always using 64 frames.
+    FrontendArgs a = a0;
+    {
+        const int fpr = 4096 / nc, max_rounds = 64 / fpr, slots = 2 * device_cus();
+        int best = max_rounds;
+        float best_cost = 3.4e38f;
+        for (int r = max_rounds; r >= (max_rounds + 1) / 2; --r) {
+            const int wgs = ceil_div(a.total_frames, r * fpr);
+            const int full = wgs / slots, rest = wgs % slots;
+            const float waves = (float)full + (rest == 0 ? 0.f : (2 * rest <= slots ? 0.6f : 1.f));
+            const float cost = waves * ((float)r + 0.85f);
+            if (cost < best_cost * 0.995f) { best_cost = cost; best = r; }
+        }
+        const int knob = tune_get(TCR_TUNE_FRONTEND);
+        if (knob >= 10) best = min(max(knob - 10, 1), max_rounds);
+        a.rounds = best;
+        grid = ceil_div(a.total_frames, best * fpr);
+    }
 #define TCR_FPK(NC_, QV_)                                                                                           \
     if (nc == NC_ && qv == QV_) {                                                                                   \
         if (a.magnitude) hipLaunchKernelGGL((frontend_pk_kernel<NC_, QV_, true>), dim3(grid), dim3(256), 0, s, a);  \

@@ -27,6 +27,17 @@ static int g_tune[TCR_TUNE_COUNT] = {0};
 
 int tune_get(int knob) { return (knob >= 0 && knob < TCR_TUNE_COUNT) ? g_tune[knob] : 0; }
 
+int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 }  // namespace tcr
 
 extern "C" int tcr_tune(int knob, int value) {

@@ -18,6 +18,7 @@ constexpr int kWave = 64;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);      // hipGetLastError -> TCR_OK / TCR_ERR_HIP
 int tune_get(int knob);                  // process-wide tuning knobs (tcr_tune)
+int device_cus();                        // compute units of the current device (cached per device; 256 on MI355X)
 
 #define TCR_REQUIRE(cond, ...)                 \
     do {                                       \
