@@ -111,8 +111,154 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-tiled 1x1 convolution for the wide pointwise layers (DS-CNN: 276 -> 276 over B x 65 positions, 88 % of that
+// network's flops; audio_nets/ds_cnn.py:49-57).  The register-fed kernel above issues 10 gather loads (4 x 64 B
+// segments each) per 24 MFMAs and re-reads the activations once per 96-channel tile from HBM; here a workgroup of
+// FOUR waves (one per SIMD: the matrix pipes stay balanced) owns 32 NT flat positions x ALL output channels, stages
+// 12 input channels of x (coalesced dwords) and of W (float4) per chunk through double-buffered LDS with one barrier
+// per chunk, and wave (wm, wn) keeps an (16 MT) x (16 NT) accumulator block: MT + NT conflict-free ds_read_b32 per
+// MT x NT MFMAs, x read once.  LDS rows are padded so that the four k-rows of a fragment read land in disjoint bank
+// quarters.  NT (positions per workgroup) is picked by the launcher so that the grid fills whole dispatch waves.
+template <int MT, int NT, int EPI>
+__global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
+    constexpr int KC = 12;                  // input channels per chunk = 3 MFMA k-steps
+    constexpr int MW = 32 * MT;             // output channels covered (2 wave rows)
+    constexpr int XN = 32 * NT;             // positions per workgroup (2 wave columns)
+    constexpr int WLD = MW + 16;            // (32 MT + 16) % 64 in {16, 48} for MT = 6, 9
+    constexpr int XLD = XN + 16;            // (32 NT + 16) % 64 in {16, 48}
+    constexpr int RS = 256 / XN;            // x rows staged per pass (threads >= RS * XN idle in the x stage)
+    constexpr int XPT = KC / RS;            // x dwords per thread and chunk
+    constexpr int W4 = MW / 4;              // float4 per weight row
+    constexpr int WPT = (KC * W4 + 255) / 256;
+    static_assert(KC % RS == 0, "x staging");
+    __shared__ float s_w[2][KC * WLD];
+    __shared__ float s_x[2][KC * XLD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int pos0 = blockIdx.x * XN;
+
+    // ---- staging roles ----
+    const bool xuse = tid < RS * XN;
+    const int xpos = tid % XN, xrow0 = min(tid / XN, RS - 1);   // rows xrow0 + RS * j
+    const float* xsrc;
+    {
+        const int p = min(pos0 + xpos, a.npos - 1);
+        const int n = p / a.tout, t = p - n * a.tout;
+        xsrc = a.x + (size_t)n * a.cin * a.tpi + kHalo + t * a.stride;
+    }
+    int wrow[WPT], wcol[WPT];
+    bool wuse[WPT], wval[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int idx = tid + 256 * j;
+        wuse[j] = idx < KC * W4;
+        wrow[j] = min(idx / W4, KC - 1);
+        wcol[j] = 4 * (idx % W4);
+        wval[j] = wcol[j] < a.cout;                         // (Cout % 4 == 0: launcher)
+    }
+    float xr[XPT];
+    f32x4 wr[WPT];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) xr[j] = xsrc[(size_t)min(c0 + xrow0 + RS * j, a.cin - 1) * a.tpi];
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const float* src = a.w + (size_t)min(c0 + wrow[j], a.cin - 1) * a.cout + min(wcol[j], a.cout - 4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+            wr[j] = wval[j] ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        if (xuse) {
+#pragma unroll
+            for (int j = 0; j < XPT; ++j) s_x[buf][(xrow0 + RS * j) * XLD + xpos] = xr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; ++j)
+            if (wuse[j]) *reinterpret_cast<f32x4*>(&s_w[buf][wrow[j] * WLD + wcol[j]]) = wr[j];
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (a.cin + KC - 1) / KC;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int aoff = q * WLD + wm * (16 * MT) + r, boff = q * XLD + wn * (16 * NT) + r;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nchunks;
+        if (more) load_chunk((ch + 1) * KC);
+        const int steps = min(KC / 4, (a.cin - ch * KC) >> 2);      // (last chunk of a Cin that is not a multiple of 12)
+        const float* sw = s_w[buf] + aoff;
+        const float* sx = s_x[buf] + boff;
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            if (ks < steps) {
+                float af[MT], bf[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = sw[ks * 4 * WLD + m * 16];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[nt] = sx[ks * 4 * XLD + nt * 16];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+            }
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = pos0 + (wn * NT + nt) * 16 + r;
+        if (p >= a.npos) continue;
+        const int n = p / a.tout, t = p - n * a.tout;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = (wm * MT + m) * 16 + q * 4 + reg;
+                if (co >= a.cout) continue;
+                float v = acc[m][nt][reg];
+                if (EPI == MF_AFFINE) {
+                    v = fmaf(v, a.scale ? a.scale[co] : 1.0f, a.shift[co]);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                }
+                float* o = a.y + ((size_t)n * a.cout + co) * a.tpo + kHalo + t;
+                o[0] = v;
+                if (EPI == MF_AFFINE) {
+                    if (t == 0) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
+                    if (t == a.tout - 1) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+                }
+            }
+    }
+}
+
 int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
     const int tiles = ceil_div(a.cout, 16);
+    const int knob = tune_get(TCR_TUNE_CONV_B);
+    if (tiles >= 7 && tiles <= 18 && (a.cin & 3) == 0 && (a.cout & 3) == 0 && knob != 3) {
+        const int mt = tiles > 12 ? 9 : 6;
+        int nt = knob >= 12 && knob <= 14 ? knob - 10 : 2;
+        const dim3 lgrid(ceil_div(a.npos, 32 * nt));
+#define TCR_LL(MT_, NT_)                                                                                                \
+    if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, NT_, MF_RAW>), lgrid, dim3(256), 0, s, a);          \
+    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, NT_, MF_AFFINE>), lgrid, dim3(256), 0, s, a)
+        if (mt == 9) { if (nt == 2) { TCR_LL(9, 2); } else if (nt == 3) { TCR_LL(9, 3); } else { TCR_LL(9, 4); } }
+        else { if (nt == 2) { TCR_LL(6, 2); } else if (nt == 3) { TCR_LL(6, 3); } else { TCR_LL(6, 4); } }
+#undef TCR_LL
+        return check_launch("conv1x1_lds_kernel");
+    }
     const int mt = tiles >= 12 ? 6 : (tiles >= 3 ? 3 : tiles);       // (9 tiles per wave spill: 1.5x slower)       // wide layers: 96 channels per wave halve the re-reads of x
     const dim3 grid(ceil_div(a.npos, 256), ceil_div(tiles, mt));
 #define TCR_L1(MT_)                                                                                         \
