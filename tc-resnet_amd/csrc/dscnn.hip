@@ -59,22 +59,43 @@ __global__ __launch_bounds__(256) void dscnn_conv1_kernel(const DsConv1Args a) {
         xb[nt] = a.feat + ((size_t)n * a.w_in + (wok[nt] ? wc : 0)) * a.tp_in + kHalo;
         h0[nt] = oh * a.sh - a.pad_t;
     }
-    for (int i = 0; i < a.kh; ++i) {
-        float af[MT], bf[4];
+    // operands of kernel row i + 1 are in flight while the 4 * MT MFMAs of row i issue (clamped, unconditional loads;
+    // out-of-image taps are zeroed by a select)
+    const float* wp[MT];
+    bool cok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co = (cot0 + m) * 16 + r;
+        cok[m] = co < a.cout;
+        wp[m] = a.w + (size_t)q * a.cout + (cok[m] ? co : 0);
+    }
+    auto load_row = [&](int i, float (&af)[MT], float (&bf)[4]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int co = (cot0 + m) * 16 + r;
-            af[m] = co < a.cout ? a.w[((size_t)i * 4 + q) * a.cout + co] : 0.f;
+            const float v = wp[m][(size_t)i * 4 * a.cout];
+            af[m] = cok[m] ? v : 0.f;
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int h = h0[nt] + i;
-            bf[nt] = (wok[nt] && h >= 0 && h < a.h_in) ? xb[nt][h] : 0.f;
+            const bool in = wok[nt] && h >= 0 && h < a.h_in;
+            const float v = xb[nt][in ? h : 0];
+            bf[nt] = in ? v : 0.f;
         }
+    };
+    float af[MT], bf[4];
+    load_row(0, af, bf);
+    for (int i = 0; i < a.kh; ++i) {
+        float an[MT], bn[4];
+        load_row(min(i + 1, a.kh - 1), an, bn);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = an[m];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bf[nt] = bn[nt];
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -152,10 +173,22 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds_kernel(const DsDwArgs
     const float* xr = a.x + (size_t)row * a.ppi + kHalo;
     float* im = img + plane * isz;
     const float inv_c = 1.0f / (float)img_c;
-    for (int j = t16; j < isz; j += 16) {
-        const int rr = fast_div(j, img_c, inv_c), cc = j - rr * img_c;
-        const int h = rr - a.pad_t, w = cc - a.pad_l;
-        im[j] = (h >= 0 && h < a.h_in && w >= 0 && w < a.w_in) ? xr[h * a.w_in + w] : 0.f;
+    // batches of 8 independent (clamped, unconditional) loads per lane: a rolled loop waits out one global round trip
+    // per 16 image elements
+    for (int j0 = t16; j0 < isz; j0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = min(j0 + 16 * i, isz - 1);
+            const int rr = fast_div(j, img_c, inv_c), cc = j - rr * img_c;
+            const int h = rr - a.pad_t, w = cc - a.pad_l;
+            const bool in = h >= 0 && h < a.h_in && w >= 0 && w < a.w_in;
+            const float xv = xr[in ? h * a.w_in + w : 0];
+            v[i] = in ? xv : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (j0 + 16 * i < isz) im[j0 + 16 * i] = v[i];
     }
     float wt[9];
 #pragma unroll
@@ -166,16 +199,24 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds_kernel(const DsDwArgs
     const int P = a.oh * a.ow;
     const float inv_ow = 1.0f / (float)a.ow;
     float* yr = a.y + (size_t)row * a.ppo + kHalo;
-    for (int pos = t16; pos < P; pos += 16) {
-        const int oh = fast_div(pos, a.ow, inv_ow), ow = pos - oh * a.ow;
-        const float* p0 = im + oh * a.sh * img_c + ow * a.sw;
-        float s = 0.f;
+    for (int pos0 = t16; pos0 < P; pos0 += 16 * 5) {        // (13 x 5 maps: one trip, the 45 LDS reads of a lane in flight together)
+        float s[5];
 #pragma unroll
-        for (int di = 0; di < 3; ++di)
+        for (int i = 0; i < 5; ++i) {
+            const int pos = min(pos0 + 16 * i, P - 1);
+            const int oh = fast_div(pos, a.ow, inv_ow), ow = pos - oh * a.ow;
+            const float* p0 = im + oh * a.sh * img_c + ow * a.sw;
+            s[i] = 0.f;
 #pragma unroll
-            for (int dj = 0; dj < 3; ++dj) s = fmaf(wt[di * 3 + dj], p0[di * img_c + dj], s);
-        const float v = fmaf(s, sc, sh);
-        yr[pos] = a.relu ? fmaxf(v, 0.f) : v;
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) s[i] = fmaf(wt[di * 3 + dj], p0[di * img_c + dj], s[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float v = fmaf(s[i], sc, sh);
+            if (pos0 + 16 * i < P) yr[pos0 + 16 * i] = a.relu ? fmaxf(v, 0.f) : v;
+        }
     }
 }
 
