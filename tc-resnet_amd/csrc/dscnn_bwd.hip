@@ -49,7 +49,76 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_kernel(const DsDwBwdArgs a
     }
 }
 
+// LDS-staged form (as dscnn_depthwise_lds_kernel): a workgroup owns 16 consecutive planes and builds, per plane, the
+// zero-UPSAMPLED, zero-padded image U[(h_in + 2) x (w_in + 2)] of dz -- U[a][b] = dz[hh / sh][ww / sw] for hh = a - (2 - pad_t),
+// ww = b - (2 - pad_l) when both divide evenly and land inside the output map, else 0 -- with batches of independent clamped
+// loads; then dx[h][w] = sum_{di,dj} W[di][dj] * U[h + 2 - di][w + 2 - dj] with no predicates.  (The wave-per-plane kernel
+// above issues nine predicated global loads per lane: 1.1 TB/s at DS-CNN-L sizes.)
+template <int SH, int SW>
+__global__ __launch_bounds__(256) void dscnn_dw_dgrad_lds_kernel(const DsDwBwdArgs a) {
+    float* img = reinterpret_cast<float*>(dyn_lds());               // [16][h_in + 2][w_in + 2]
+    const int sh = SH ? SH : a.sh, sw = SW ? SW : a.sw;
+    const int plane = threadIdx.x >> 4, t16 = threadIdx.x & 15;
+    const int64_t row_raw = (int64_t)blockIdx.x * 16 + plane;
+    const int64_t row = row_raw < a.planes ? row_raw : a.planes - 1;
+    const bool live = row_raw < a.planes;
+    const int c = (int)(row % a.c);
+    const int ir = a.h_in + 2, ic = a.w_in + 2, isz = ir * ic;
+    const float* dz = a.dz + row * a.ppo + kHalo;
+    float* im = img + plane * isz;
+    const float inv_c = 1.0f / (float)ic;
+    for (int j0 = t16; j0 < isz; j0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = min(j0 + 16 * i, isz - 1);
+            const int rr = fast_div(j, ic, inv_c), cc = j - rr * ic;
+            const int hh = rr - (2 - a.pad_t), ww = cc - (2 - a.pad_l);
+            const int oh = hh / sh, ow = ww / sw;
+            const bool in = hh >= 0 && ww >= 0 && oh * sh == hh && ow * sw == ww && oh < a.oh && ow < a.ow;
+            const float g = dz[in ? oh * a.ow + ow : 0];
+            v[i] = in ? g : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (j0 + 16 * i < isz) im[j0 + 16 * i] = v[i];
+    }
+    float wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = a.w[(size_t)k * a.c + c];
+    __syncthreads();
+    if (!live) return;
+    const int pin = a.h_in * a.w_in;
+    const float inv_w = 1.0f / (float)a.w_in;
+    float* dx = a.dx + row * a.ppi + kHalo;
+    for (int pos0 = t16; pos0 < pin; pos0 += 16 * 5) {
+        float s[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int pos = min(pos0 + 16 * i, pin - 1);
+            const int h = fast_div(pos, a.w_in, inv_w), w = pos - h * a.w_in;
+            const float* p0 = im + (h + 2) * ic + (w + 2);
+            s[i] = 0.f;
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) s[i] = fmaf(wt[di * 3 + dj], p0[-di * ic - dj], s[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (pos0 + 16 * i < pin) dx[pos0 + 16 * i] = s[i];
+    }
+}
+
 int launch_dscnn_dw_dgrad(const DsDwBwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)16 * (a.h_in + 2) * (a.w_in + 2) * sizeof(float);
+    if (lds <= 64 * 1024 && a.pad_t <= 2 && a.pad_l <= 2) {
+        const dim3 lgrid((unsigned)ceil_div64(a.planes, 16));
+        if (a.sh == 1 && a.sw == 1) hipLaunchKernelGGL((dscnn_dw_dgrad_lds_kernel<1, 1>), lgrid, dim3(256), lds, s, a);
+        else if (a.sh == 2 && a.sw == 2) hipLaunchKernelGGL((dscnn_dw_dgrad_lds_kernel<2, 2>), lgrid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((dscnn_dw_dgrad_lds_kernel<0, 0>), lgrid, dim3(256), lds, s, a);
+        return check_launch("dscnn_dw_dgrad_lds_kernel");
+    }
     const dim3 grid((unsigned)ceil_div64(a.planes, 4));
     if (a.sh == 1 && a.sw == 1) hipLaunchKernelGGL((dscnn_dw_dgrad_kernel<1, 1>), grid, dim3(256), 0, s, a);
     else if (a.sh == 2 && a.sw == 2) hipLaunchKernelGGL((dscnn_dw_dgrad_kernel<2, 2>), grid, dim3(256), 0, s, a);
