@@ -33,6 +33,43 @@ struct DsConv1Args {
     int relu;               // scale == nullptr: y = acc + shift (conv bias, train-mode raw output)
 };
 
+// Epilogue of both conv_1 kernels.  One 64-bit row pointer per position tile and one 32-bit channel offset per
+// accumulator row: the per-store address is a single add (48 stores with their own 64-bit multiply chains, plus the
+// integer divisions of the position split, were most of this kernel's instructions).
+template <int MT>
+__device__ __forceinline__ void conv1_store(const DsConv1Args& a, const f32x4 (&acc)[MT][4], int pos0, int cot0, int r, int q) {
+    const int P = a.oh * a.ow;
+    const float inv_p = 1.0f / (float)P;
+    float sc[MT][4], sf[MT][4];
+    int off[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int co = (cot0 + m) * 16 + q * 4 + reg;
+            const int cc = min(co, a.cout - 1);
+            sc[m][reg] = a.scale ? a.scale[cc] : 1.0f;
+            sf[m][reg] = a.shift[cc];
+            off[m][reg] = co < a.cout ? cc * a.pp : -1;
+        }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int p = pos0 + nt * 16 + r;
+        if (p >= a.npos) continue;
+        const int n = a.npos < (1 << 23) ? fast_div(p, P, inv_p) : p / P, rem = p - n * P;    // (float reciprocal: exact below 2^23)
+        float* yb = a.y + (size_t)n * a.cout * a.pp + kHalo + rem;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if (off[m][reg] < 0) continue;
+                float v = fmaf(acc[m][nt][reg], sc[m][reg], sf[m][reg]);
+                if (a.relu) v = fmaxf(v, 0.f);
+                yb[off[m][reg]] = v;
+            }
+    }
+}
+
 // D[row = co][col = (b, oh, ow)] = sum_{i < kh, j < 4} W[i][j][co] * x[oh*sh + i - pad_t][ow*sw + j - pad_l]
 template <int MT>
 __global__ __launch_bounds__(256) void dscnn_conv1_kernel(const DsConv1Args a) {
@@ -97,22 +134,14 @@ __global__ __launch_bounds__(256) void dscnn_conv1_kernel(const DsConv1Args a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) bf[nt] = bn[nt];
     }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int p = pos0 + nt * 16 + r;
-        if (p >= a.npos) continue;
-        const int n = p / P, rem = p - n * P;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int co = (cot0 + m) * 16 + q * 4 + reg;
-                if (co >= a.cout) continue;
-                float v = fmaf(acc[m][nt][reg], a.scale ? a.scale[co] : 1.0f, a.shift[co]);
-                if (a.relu) v = fmaxf(v, 0.f);
-                a.y[((size_t)n * a.cout + co) * a.pp + kHalo + rem] = v;
-            }
-    }
+    conv1_store<MT>(a, acc, pos0, cot0, r, q);
+}
+
+static int launch_dscnn_conv1(const DsConv1Args& a, hipStream_t s) {
+    const int tiles = ceil_div(a.cout, 16);
+    const dim3 grid(ceil_div(a.npos, 256), ceil_div(tiles, 3));
+    hipLaunchKernelGGL((dscnn_conv1_kernel<3>), grid, dim3(256), 0, s, a);
+    return check_launch("dscnn_conv1_kernel");
 }
 
 struct DsDwArgs {
@@ -410,10 +439,7 @@ extern "C" int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params
             a.feat = feat; a.w = params + l.w_off; a.scale = ss + l.ss_off; a.shift = ss + l.ss_off + cp; a.y = buf[cur];
             a.npos = batch * P; a.cout = l.cout; a.h_in = l.h_in; a.w_in = l.w_in; a.tp_in = tcr_padded_len(l.h_in);
             a.oh = l.oh; a.ow = l.ow; a.pp = pp; a.kh = l.kh; a.sh = l.sh; a.sw = l.sw; a.pad_t = l.pad_t; a.pad_l = l.pad_l; a.relu = 1;
-            const int tiles = ceil_div(l.cout, 16);
-            const dim3 grid(ceil_div(a.npos, 256), ceil_div(tiles, 3));
-            hipLaunchKernelGGL((dscnn_conv1_kernel<3>), grid, dim3(256), 0, s, a);
-            TCR_TRY(check_launch("dscnn_conv1_kernel"));
+            TCR_TRY(launch_dscnn_conv1(a, s));
         } else {
             DsDwArgs d;
             d.x = buf[cur]; d.w = params + l.w_off; d.scale = ss + l.ss_off; d.shift = ss + l.ss_off + cp; d.y = buf[cur ^ 1];
@@ -555,9 +581,7 @@ extern "C" int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params
             a.feat = feat; a.w = params + u.w_off; a.scale = nullptr; a.shift = params + u.b_off; a.y = raw;
             a.npos = batch * u.P; a.cout = l.cout; a.h_in = l.h_in; a.w_in = l.w_in; a.tp_in = tcr_padded_len(l.h_in);
             a.oh = l.oh; a.ow = l.ow; a.pp = pp; a.kh = l.kh; a.sh = l.sh; a.sw = l.sw; a.pad_t = l.pad_t; a.pad_l = l.pad_l; a.relu = 0;
-            const int tiles = ceil_div(l.cout, 16);
-            hipLaunchKernelGGL((dscnn_conv1_kernel<3>), dim3(ceil_div(a.npos, 256), ceil_div(tiles, 3)), dim3(256), 0, s, a);
-            TCR_TRY(check_launch("dscnn_conv1_kernel"));
+            TCR_TRY(launch_dscnn_conv1(a, s));
         } else if (u.kind == DS_DW) {
             DsDwArgs d;
             d.x = x; d.w = params + u.w_off; d.scale = nullptr; d.shift = params + u.b_off; d.y = raw;

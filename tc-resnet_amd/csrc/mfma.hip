@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
         const int p = pos0 + nt * 16 + r;
         if (p >= a.npos) continue;
         const int n = p / a.tout, t = p - n * a.tout;
+        float* yb = a.y + (size_t)n * a.cout * a.tpo + kHalo + t;       // (lean addressing: see conv_mfma_store)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
                     v = fmaf(v, a.scale ? a.scale[co] : 1.0f, a.shift[co]);    // (scale == nullptr: conv bias only)
                     if (a.relu) v = fmaxf(v, 0.f);
                 }
-                float* o = a.y + ((size_t)n * a.cout + co) * a.tpo + kHalo + t;
+                float* o = yb + co * a.tpo;
                 o[0] = v;
                 if (EPI == MF_AFFINE) {     // (raw outputs: see conv_mfma_store)
                     if (t == 0) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
@@ -218,29 +219,36 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
         __syncthreads();
     }
 
+    // (lean addressing: see conv_mfma_store)
+    const float inv_tout = 1.0f / (float)a.tout;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = pos0 + (wn * NT + nt) * 16 + r;
         if (p >= a.npos) continue;
-        const int n = p / a.tout, t = p - n * a.tout;
+        const int n = a.npos < (1 << 23) ? fast_div(p, a.tout, inv_tout) : p / a.tout, t = p - n * a.tout;
+        float* yb = a.y + (size_t)n * a.cout * a.tpo + kHalo + t;
+        const bool first = t == 0, last = t == a.tout - 1;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            const int co0 = (wm * MT + m) * 16;
+            if (co0 >= a.cout) break;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int co = (wm * MT + m) * 16 + q * 4 + reg;
+                const int co = co0 + q * 4 + reg;
                 if (co >= a.cout) continue;
                 float v = acc[m][nt][reg];
                 if (EPI == MF_AFFINE) {
                     v = fmaf(v, a.scale ? a.scale[co] : 1.0f, a.shift[co]);
                     if (a.relu) v = fmaxf(v, 0.f);
                 }
-                float* o = a.y + ((size_t)n * a.cout + co) * a.tpo + kHalo + t;
+                float* o = yb + co * a.tpo;
                 o[0] = v;
                 if (EPI == MF_AFFINE) {
-                    if (t == 0) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
-                    if (t == a.tout - 1) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+                    if (first) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
+                    if (last) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
                 }
             }
+        }
     }
 }
 
@@ -307,11 +315,16 @@ template <int MT, int EPI>
 __device__ __forceinline__ void conv_mfma_store(const f32x4 (&acc)[MT][2], float* y, const float* scale, const float* shift,
                                                 const float* res, int relu, int cot0, int cout, int tout, int tpo,
                                                 int p_base, int wg_p1, int r, int q, const ConvStoreExtra ex) {
+    // One 64-bit row offset per position tile and one 32-bit channel offset per accumulator row: the per-store address is
+    // a single add (own 64-bit multiply chains per store and the integer division of the position split were a large part
+    // of the short train-mode launches' instruction count).
+    const float inv_tout = 1.0f / (float)tout;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int p = p_base + nt * 16 + r;
         if (p >= wg_p1) continue;
-        const int n = p / tout, t = p - n * tout;
+        const int n = wg_p1 < (1 << 23) ? fast_div(p, tout, inv_tout) : p / tout, t = p - n * tout;
+        const size_t ob = (size_t)n * cout * tpo + kHalo + t * ex.ostride + ex.ooff;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -319,7 +332,7 @@ __device__ __forceinline__ void conv_mfma_store(const f32x4 (&acc)[MT][2], float
                 const int co = (cot0 + m) * 16 + q * 4 + reg;
                 if (co >= cout) continue;
                 float v = acc[m][nt][reg];
-                const size_t o = ((size_t)n * cout + co) * tpo + kHalo + t * ex.ostride + ex.ooff;
+                const size_t o = ob + (size_t)(co * tpo);
                 if (EPI == EPI_AFFINE) {
                     v = fmaf(v, scale[co], shift[co]);
                     if (res) v = fmaxf(v + res[o], 0.f);            // net += layer_in; relu  (tc_resnet.py:40-41)
