@@ -257,13 +257,12 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
     const int knob = tune_get(TCR_TUNE_CONV_B);
     if (tiles >= 7 && tiles <= 18 && (a.cin & 3) == 0 && (a.cout & 3) == 0 && knob != 3) {
         const int mt = tiles > 12 ? 9 : 6;
-        int nt = knob >= 12 && knob <= 14 ? knob - 10 : 2;
-        const dim3 lgrid(ceil_div(a.npos, 32 * nt));
-#define TCR_LL(MT_, NT_)                                                                                                \
-    if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, NT_, MF_RAW>), lgrid, dim3(256), 0, s, a);          \
-    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, NT_, MF_AFFINE>), lgrid, dim3(256), 0, s, a)
-        if (mt == 9) { if (nt == 2) { TCR_LL(9, 2); } else if (nt == 3) { TCR_LL(9, 3); } else { TCR_LL(9, 4); } }
-        else { if (nt == 2) { TCR_LL(6, 2); } else if (nt == 3) { TCR_LL(6, 3); } else { TCR_LL(6, 4); } }
+        // 2 column tiles per wave = 64 positions per workgroup (3 tiles: 236 VGPRs, 2 waves per SIMD, slower; 4: slower still)
+        const dim3 lgrid(ceil_div(a.npos, 64));
+#define TCR_LL(MT_)                                                                                                     \
+    if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW>), lgrid, dim3(256), 0, s, a);            \
+    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE>), lgrid, dim3(256), 0, s, a)
+        if (mt == 9) { TCR_LL(9); } else { TCR_LL(6); }
 #undef TCR_LL
         return check_launch("conv1x1_lds_kernel");
     }
