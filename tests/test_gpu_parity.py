@@ -138,6 +138,27 @@ def test_dscnn_full_batch_independence(hip_lib):
     assert np.abs(l[0].cpu().numpy() - ref["logits"]).max() < Cm.LOGIT_TOL
 
 
+@pytest.mark.parametrize("size", ["M", "L"])
+def test_dscnn_pointwise_kernel_paths_agree(hip_lib, size):
+    """The LDS-tiled pointwise kernel (default for 97..288 output channels) and the register-fed 1x1 kernel
+    (TCR_TUNE_CONV_B = 3) accumulate over the input channels in the same order: bit-identical logits, eval mode, at a
+    batch whose last workgroup is partial (97 utterances x 65 positions = 98.5 workgroups of 64 positions)."""
+    from oracle import dscnn_ref as D
+    p, s = D.init_params(D.net_def(size), seed=3)
+    fe = Cm.make_frontend(hip_lib, 640, 320, num_mfccs=10)
+    net = T.DSCNN(size, fe.n_frames, 10, 12, device="cuda")
+    sd = dict(p); sd.update(s); net.load_state_dict(sd)
+    feat = fe(torch.from_numpy(R.synth_waveforms(97, seed=5)).cuda())
+    try:
+        base = net.forward_infer(feat)[0].clone()
+        hip_lib.tcr_tune(2, 3)
+        alt = net.forward_infer(feat)[0].clone()
+    finally:
+        hip_lib.tcr_tune(2, 0)
+    assert torch.isfinite(base).all()
+    assert torch.equal(base, alt)
+
+
 @pytest.mark.parametrize("size", ["S", "L"])
 def test_dscnn_train_steps(hip_lib, size):
     """DS-CNN train-mode forward + backward + Adam against the oracle fixture (BASELINE.json configs[4], training half)."""
