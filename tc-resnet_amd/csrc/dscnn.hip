@@ -249,6 +249,129 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds_kernel(const DsDwArgs
     }
 }
 
+// Eval-mode fusion of conv_1 (+ folded BN + ReLU) with the first depthwise layer (+ folded BN + ReLU).  conv_1 writes
+// B x 276 x 250 activations (1.17 GB at B = 4096) that the stride-2 depthwise layer immediately reduces 4x; here a workgroup
+// owns (one utterance, 48 channels): the conv_1 tile goes from the MFMA accumulators straight into zero-padded LDS planes
+// [48][(oh-1)*sh + 3][(ow-1)*sw + 3], and the 3x3 stencil reads them back -- conv_1's output never reaches HBM.
+// (Requires conv_1's map to fit 256 positions: 25 x 10 for every DS-CNN size.)
+template <int MT>
+__global__ __launch_bounds__(256) void dscnn_conv1_dw_kernel(const DsConv1Args a, const DsDwArgs d, const int ir, const int ic) {
+    constexpr int CH = 16 * MT;
+    float* planes = reinterpret_cast<float*>(dyn_lds());        // [CH][ir][ic]
+    float* s_dw = planes + CH * ir * ic;                        // [9][CH] depthwise taps
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int n = blockIdx.x;
+    const int cot0 = blockIdx.y * MT;
+    const int P1 = a.oh * a.ow, P2 = d.oh * d.ow;
+    const int isz = ir * ic;
+    for (int j = threadIdx.x; j < CH * isz; j += 256) planes[j] = 0.f;
+    for (int j = threadIdx.x; j < 9 * CH; j += 256) {
+        const int k = j / CH, cl = j - k * CH;
+        s_dw[j] = d.w[(size_t)k * d.c + min(cot0 * 16 + cl, d.c - 1)];
+    }
+
+    // ---- conv_1 tile: positions wave * 64 + nt * 16 + r of utterance n (as dscnn_conv1_kernel) ----
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float inv_ow1 = 1.0f / (float)a.ow;
+    const float* xb[4];
+    int h0[4], pdst[4];
+    bool wok[4], pv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int rem_raw = wave * 64 + nt * 16 + r;
+        pv[nt] = rem_raw < P1;
+        const int rem = min(rem_raw, P1 - 1);
+        const int oh = fast_div(rem, a.ow, inv_ow1), ow = rem - oh * a.ow;
+        const int wc = ow * a.sw + q - a.pad_l;
+        wok[nt] = wc >= 0 && wc < a.w_in;
+        xb[nt] = a.feat + ((size_t)n * a.w_in + (wok[nt] ? wc : 0)) * a.tp_in + kHalo;
+        h0[nt] = oh * a.sh - a.pad_t;
+        pdst[nt] = (oh + d.pad_t) * ic + ow + d.pad_l;          // this position inside a padded plane
+    }
+    const float* wp[MT];
+    bool cok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co = (cot0 + m) * 16 + r;
+        cok[m] = co < a.cout;
+        wp[m] = a.w + (size_t)q * a.cout + (cok[m] ? co : 0);
+    }
+    auto load_row = [&](int i, float (&af)[MT], float (&bf)[4]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float v = wp[m][(size_t)i * 4 * a.cout];
+            af[m] = cok[m] ? v : 0.f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int h = h0[nt] + i;
+            const bool in = wok[nt] && h >= 0 && h < a.h_in;
+            const float v = xb[nt][in ? h : 0];
+            bf[nt] = in ? v : 0.f;
+        }
+    };
+    float af[MT], bf[4];
+    load_row(0, af, bf);
+    for (int i = 0; i < a.kh; ++i) {
+        float an[MT], bn[4];
+        load_row(min(i + 1, a.kh - 1), an, bn);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = an[m];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bf[nt] = bn[nt];
+    }
+    __syncthreads();                                            // planes zeroed, taps staged
+    // ---- conv_1 epilogue (folded BN + ReLU) into the padded planes ----
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cl = m * 16 + q * 4 + reg;
+            const int cc = min(cot0 * 16 + cl, a.cout - 1);
+            const float sc = a.scale[cc], sf = a.shift[cc];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (pv[nt]) planes[cl * isz + pdst[nt]] = fmaxf(fmaf(acc[m][nt][reg], sc, sf), 0.f);
+        }
+    __syncthreads();
+    // ---- depthwise 3x3 (+ folded BN + ReLU) ----
+    const float inv_p2 = 1.0f / (float)P2, inv_ow2 = 1.0f / (float)d.ow;
+    for (int idx = threadIdx.x; idx < CH * P2; idx += 256) {
+        const int cl = fast_div(idx, P2, inv_p2), pos = idx - cl * P2;
+        const int c = cot0 * 16 + cl;
+        if (c >= d.c) break;                                    // (channels ascend with idx)
+        const int oh = fast_div(pos, d.ow, inv_ow2), ow = pos - oh * d.ow;
+        const float* p0 = planes + cl * isz + oh * d.sh * ic + ow * d.sw;
+        float sacc = 0.f;
+#pragma unroll
+        for (int di = 0; di < 3; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) sacc = fmaf(s_dw[(di * 3 + dj) * CH + cl], p0[di * ic + dj], sacc);
+        const float v = fmaf(sacc, d.scale[c], d.shift[c]);
+        d.y[((size_t)n * d.c + c) * d.ppo + kHalo + pos] = fmaxf(v, 0.f);
+    }
+}
+
+// returns 1 (nothing launched) when the shapes do not fit the fused kernel
+static int launch_dscnn_conv1_dw(const DsConv1Args& a, const DsDwArgs& d, int batch, hipStream_t s) {
+    const int ir = (d.oh - 1) * d.sh + 3, ic = (d.ow - 1) * d.sw + 3;
+    const size_t lds = ((size_t)48 * ir * ic + 9 * 48) * sizeof(float);
+    if (a.oh * a.ow > 256 || lds > 64 * 1024 || d.c != a.cout || d.h_in != a.oh || d.w_in != a.ow || !a.scale || !d.scale || !a.relu || !d.relu ||
+        d.pad_t + a.oh > ir || d.pad_l + a.ow > ic || batch > 65535 * 16) return 1;
+    const dim3 grid(batch, ceil_div(ceil_div(a.cout, 16), 3));
+    hipLaunchKernelGGL((dscnn_conv1_dw_kernel<3>), grid, dim3(256), lds, s, a, d, ir, ic);
+    return check_launch("dscnn_conv1_dw_kernel");
+}
+
 static int launch_dscnn_depthwise(const DsDwArgs& d, int batch, hipStream_t s) {
     const int rows = batch * d.c;
     const int img_r = (d.oh - 1) * d.sh + 3, img_c = (d.ow - 1) * d.sw + 3;
@@ -432,21 +555,33 @@ extern "C" int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params
     TCR_TRY(launch_bn_fold(f, s));
 
     int cur = 0;
-    for (const DsLayer& l : net->layers) {
+    bool dw_done = false;                   // the first depthwise layer ran inside the fused conv_1 kernel
+    for (size_t li = 0; li < net->layers.size(); ++li) {
+        const DsLayer& l = net->layers[li];
         const int P = l.oh * l.ow, pp = tcr_padded_len(P);
+        auto dw_args = [&](const DsLayer& dl, const float* x, float* y) {
+            DsDwArgs d;
+            d.x = x; d.w = params + dl.w_off; d.scale = ss + dl.ss_off; d.shift = ss + dl.ss_off + cp; d.y = y;
+            d.total = (int64_t)batch * dl.cin * dl.oh * dl.ow; d.c = dl.cin; d.h_in = dl.h_in; d.w_in = dl.w_in;
+            d.ppi = tcr_padded_len(dl.h_in * dl.w_in); d.oh = dl.oh; d.ow = dl.ow; d.ppo = tcr_padded_len(dl.oh * dl.ow);
+            d.sh = dl.sh; d.sw = dl.sw; d.pad_t = dl.pad_t; d.pad_l = dl.pad_l; d.relu = 1;
+            return d;
+        };
         if (!l.separable) {
             DsConv1Args a;
             a.feat = feat; a.w = params + l.w_off; a.scale = ss + l.ss_off; a.shift = ss + l.ss_off + cp; a.y = buf[cur];
             a.npos = batch * P; a.cout = l.cout; a.h_in = l.h_in; a.w_in = l.w_in; a.tp_in = tcr_padded_len(l.h_in);
             a.oh = l.oh; a.ow = l.ow; a.pp = pp; a.kh = l.kh; a.sh = l.sh; a.sw = l.sw; a.pad_t = l.pad_t; a.pad_l = l.pad_l; a.relu = 1;
-            TCR_TRY(launch_dscnn_conv1(a, s));
+            int fused = 1;
+            if (li + 1 < net->layers.size() && net->layers[li + 1].separable && tune_get(TCR_TUNE_CONV_B) != 3) {
+                fused = launch_dscnn_conv1_dw(a, dw_args(net->layers[li + 1], nullptr, buf[cur ^ 1]), batch, s);
+                if (fused < 0) return fused;
+            }
+            if (fused == 1) TCR_TRY(launch_dscnn_conv1(a, s));
+            else dw_done = true;
         } else {
-            DsDwArgs d;
-            d.x = buf[cur]; d.w = params + l.w_off; d.scale = ss + l.ss_off; d.shift = ss + l.ss_off + cp; d.y = buf[cur ^ 1];
-            d.total = (int64_t)batch * l.cin * P; d.c = l.cin; d.h_in = l.h_in; d.w_in = l.w_in;
-            d.ppi = tcr_padded_len(l.h_in * l.w_in); d.oh = l.oh; d.ow = l.ow; d.ppo = pp;
-            d.sh = l.sh; d.sw = l.sw; d.pad_t = l.pad_t; d.pad_l = l.pad_l; d.relu = 1;
-            TCR_TRY(launch_dscnn_depthwise(d, batch, s));
+            if (!dw_done) TCR_TRY(launch_dscnn_depthwise(dw_args(l, buf[cur], buf[cur ^ 1]), batch, s));
+            dw_done = false;
             Conv1x1Args c1;
             c1.x = buf[cur ^ 1]; c1.w = params + l.pw_off; c1.y = buf[cur]; c1.scale = ss + l.pss_off; c1.shift = ss + l.pss_off + cp;
             c1.npos = batch * P; c1.cin = l.cin; c1.cout = l.cout; c1.tpi = pp; c1.tout = P; c1.tpo = pp; c1.stride = 1; c1.relu = 1;

@@ -141,7 +141,8 @@ def test_dscnn_full_batch_independence(hip_lib):
 @pytest.mark.parametrize("size", ["M", "L"])
 def test_dscnn_pointwise_kernel_paths_agree(hip_lib, size):
     """The LDS-tiled pointwise kernel (default for 97..288 output channels) and the register-fed 1x1 kernel
-    (TCR_TUNE_CONV_B = 3) accumulate over the input channels in the same order: bit-identical logits, eval mode, at a
+    (TCR_TUNE_CONV_B = 3; the knob also un-fuses conv_1 from the first depthwise layer) accumulate in the same order:
+    bit-identical logits, eval mode, at a
     batch whose last workgroup is partial (97 utterances x 65 positions = 98.5 workgroups of 64 positions)."""
     from oracle import dscnn_ref as D
     p, s = D.init_params(D.net_def(size), seed=3)
