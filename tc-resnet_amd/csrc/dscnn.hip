@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds_kernel(const DsDwArgs
 
 // Eval-mode fusion of conv_1 (+ folded BN + ReLU) with the first depthwise layer (+ folded BN + ReLU).  conv_1 writes
 // B x 276 x 250 activations (1.17 GB at B = 4096) that the stride-2 depthwise layer immediately reduces 4x; here a workgroup
-// owns (one utterance, 48 channels): the conv_1 tile goes from the MFMA accumulators straight into zero-padded LDS planes
+// owns (one utterance, 16 MT channels): the conv_1 tile goes from the MFMA accumulators straight into zero-padded LDS planes
 // [48][(oh-1)*sh + 3][(ow-1)*sw + 3], and the 3x3 stencil reads them back -- conv_1's output never reaches HBM.
 // (Requires conv_1's map to fit 256 positions: 25 x 10 for every DS-CNN size.)
 template <int MT>
@@ -364,11 +364,12 @@ __global__ __launch_bounds__(256) void dscnn_conv1_dw_kernel(const DsConv1Args a
 // returns 1 (nothing launched) when the shapes do not fit the fused kernel
 static int launch_dscnn_conv1_dw(const DsConv1Args& a, const DsDwArgs& d, int batch, hipStream_t s) {
     const int ir = (d.oh - 1) * d.sh + 3, ic = (d.ow - 1) * d.sw + 3;
-    const size_t lds = ((size_t)48 * ir * ic + 9 * 48) * sizeof(float);
+    const size_t lds = ((size_t)32 * ir * ic + 9 * 32) * sizeof(float);
     if (a.oh * a.ow > 256 || lds > 64 * 1024 || d.c != a.cout || d.h_in != a.oh || d.w_in != a.ow || !a.scale || !d.scale || !a.relu || !d.relu ||
         d.pad_t + a.oh > ir || d.pad_l + a.ow > ic || batch > 65535 * 16) return 1;
-    const dim3 grid(batch, ceil_div(ceil_div(a.cout, 16), 3));
-    hipLaunchKernelGGL((dscnn_conv1_dw_kernel<3>), grid, dim3(256), lds, s, a, d, ir, ic);
+    // 32 channels per workgroup (38 KB of LDS, 4 workgroups per CU): 4.15 ms; 48 channels: 4.28 ms; 16: 4.41 ms (DS-CNN-L eval)
+    const dim3 grid(batch, ceil_div(ceil_div(a.cout, 16), 2));
+    hipLaunchKernelGGL((dscnn_conv1_dw_kernel<2>), grid, dim3(256), lds, s, a, d, ir, ic);
     return check_launch("dscnn_conv1_dw_kernel");
 }
 
