@@ -373,10 +373,81 @@ static int launch_dscnn_conv1_dw(const DsConv1Args& a, const DsDwArgs& d, int ba
     return check_launch("dscnn_conv1_dw_kernel");
 }
 
+// Small maps (image <= 128 elements: the 13 x 5 layers): every 16-lane group carries TWO planes (g and g + 16 of the
+// workgroup's 32), so twice the bytes are in flight per wave at the same occupancy -- these layers are pure HBM streams
+// (0.27 ms per 688 MB with one plane per group).
+__global__ __launch_bounds__(256) void dscnn_depthwise_lds2_kernel(const DsDwArgs a, const int rows, const int img_r, const int img_c) {
+    float* img = reinterpret_cast<float*>(dyn_lds());               // [32][img_r][img_c]
+    const int g = threadIdx.x >> 4, t16 = threadIdx.x & 15;
+    const int isz = img_r * img_c;
+    const float inv_c = 1.0f / (float)img_c;
+    int row[2];
+    bool live[2];
+    float v[2][8];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const int rr0 = (int)blockIdx.x * 32 + g + 16 * pl;
+        live[pl] = rr0 < rows;
+        row[pl] = min(rr0, rows - 1);
+        const float* xr = a.x + (size_t)row[pl] * a.ppi + kHalo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = min(t16 + 16 * i, isz - 1);
+            const int rr = fast_div(j, img_c, inv_c), cc = j - rr * img_c;
+            const int h = rr - a.pad_t, w = cc - a.pad_l;
+            const bool in = h >= 0 && h < a.h_in && w >= 0 && w < a.w_in;
+            const float xv = xr[in ? h * a.w_in + w : 0];
+            v[pl][i] = in ? xv : 0.f;
+        }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (t16 + 16 * i < isz) img[(g + 16 * pl) * isz + t16 + 16 * i] = v[pl][i];
+    __syncthreads();
+    const int P = a.oh * a.ow;
+    const float inv_ow = 1.0f / (float)a.ow;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        if (!live[pl]) continue;
+        const int c = row[pl] % a.c;
+        float wt[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[k] = a.w[(size_t)k * a.c + c];
+        const float sc = a.scale ? a.scale[c] : 1.0f, sh = a.shift[c];
+        const float* im = img + (g + 16 * pl) * isz;
+        float* yr = a.y + (size_t)row[pl] * a.ppo + kHalo;
+        for (int pos0 = t16; pos0 < P; pos0 += 16 * 5) {
+            float s[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int pos = min(pos0 + 16 * i, P - 1);
+                const int oh = fast_div(pos, a.ow, inv_ow), ow = pos - oh * a.ow;
+                const float* p0 = im + oh * a.sh * img_c + ow * a.sw;
+                s[i] = 0.f;
+#pragma unroll
+                for (int di = 0; di < 3; ++di)
+#pragma unroll
+                    for (int dj = 0; dj < 3; ++dj) s[i] = fmaf(wt[di * 3 + dj], p0[di * img_c + dj], s[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const float o = fmaf(s[i], sc, sh);
+                if (pos0 + 16 * i < P) yr[pos0 + 16 * i] = a.relu ? fmaxf(o, 0.f) : o;
+            }
+        }
+    }
+}
+
 static int launch_dscnn_depthwise(const DsDwArgs& d, int batch, hipStream_t s) {
     const int rows = batch * d.c;
     const int img_r = (d.oh - 1) * d.sh + 3, img_c = (d.ow - 1) * d.sw + 3;
     const size_t lds = (size_t)16 * img_r * img_c * sizeof(float);
+    if (img_r * img_c <= 128 && (int64_t)batch * d.c < ((int64_t)1 << 31) && tune_get(TCR_TUNE_CONV_B) != 3) {
+        hipLaunchKernelGGL(dscnn_depthwise_lds2_kernel, dim3(ceil_div(rows, 32)), dim3(256), 2 * lds, s, d, rows, img_r, img_c);
+        return check_launch("dscnn_depthwise_lds2_kernel");
+    }
     if (lds <= 64 * 1024 && (int64_t)batch * d.c < ((int64_t)1 << 31)) {
         hipLaunchKernelGGL(dscnn_depthwise_lds_kernel, dim3(ceil_div(rows, 16)), dim3(256), lds, s, d, rows, img_r, img_c);
         return check_launch("dscnn_depthwise_lds_kernel");
