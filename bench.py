@@ -315,7 +315,8 @@ def pmc_traffic(kernel: str):
     both in KiB.  None when no profile is committed."""
     import csv
     import glob
-    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.csv")), reverse=True):
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.csv")), reverse=True)
+    for path in sorted(paths, key=lambda q: "_final_" not in os.path.basename(q)):      # the round's final profile first (stable sort)
         vals = {}
         for r in csv.DictReader(open(path)):
             if r["kernel"].startswith(kernel) and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
