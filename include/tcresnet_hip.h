@@ -165,13 +165,14 @@ int tcr_net_backward(const tcr_net* net, const float* params, const float* feat,
 
 /* Cross-replica (sync) BN.  forward_train / backward can be run stage by stage: stage s ends right
  * after the per-channel partial sums of its BN layer ({sum y, sum y^2} forward, {sum dz, sum dz*xhat}
- * backward; 2*C floats) have been written to a contiguous device buffer, which the host
- * all-reduces (sum) across replicas before calling stage s+1.  Statistics then span global_batch,
- * exactly as in the single-device reference.  Stages 0 .. tcr_net_num_stages()-1; the last stage
+ * backward; 2*C float64 values, the per-workgroup partial rows added up in the fixed order the unstaged
+ * path uses) have been written to a contiguous device buffer, which the host all-reduces (sum) across
+ * replicas before calling stage s+1.  Statistics then span global_batch, exactly as in the single-device
+ * reference; with one replica the staged run is bitwise the unstaged one.  Stages 0 .. tcr_net_num_stages()-1; the last stage
  * has no hand-off.  See DESIGN.md "Data parallel". */
 int tcr_net_num_stages(const tcr_net* net, int backward);
 int tcr_net_stage_sums(const tcr_net* net, int backward, int stage, void* workspace, int batch,
-                       float** sums_dev, int64_t* n_floats);
+                       double** sums_dev, int64_t* n_doubles);
 int tcr_net_forward_train_stage(const tcr_net* net, const float* params, float* stats, const float* feat,
                                 const float* labels, int batch, int global_batch, float keep_prob,
                                 uint64_t seed, int64_t sample_offset, float label_smoothing,
@@ -234,6 +235,13 @@ int tcr_sgd_momentum_step(float* params, const float* grads, float* momentum, in
 int tcr_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t n_decay,
                   float lr, float beta1, float beta2, float eps, int64_t t, float weight_decay,
                   float grad_scale, void* stream);
+/* tf.train.RMSPropOptimizer (decay .9, momentum 0, eps 1e-10 defaults; helper/trainer.py:186-188):
+ * ms <- decay*ms + (1-decay)*g'^2 ; mom <- momentum*mom + lr*g'/sqrt(ms + eps) ; w <- w - mom.  The `ms` slot starts at one. */
+int tcr_rmsprop_step(float* params, const float* grads, float* ms, float* mom, int64_t n, int64_t n_decay,
+                     float lr, float decay, float momentum, float eps, float weight_decay, float grad_scale, void* stream);
+/* tf.train.ExponentialMovingAverage(decay).apply(variables_to_train) (helper/trainer.py:213-217):
+ * shadow <- shadow - (1 - decay) * (shadow - params), over the trainable arena. */
+int tcr_ema_step(float* shadow, const float* params, int64_t n, float decay, void* stream);
 /* out[0] = weight_decay * sum_{i<n_decay} 0.5*w_i^2 (device float). */
 int tcr_l2_loss(const float* params, int64_t n_decay, float weight_decay, float* out, void* stream);
 

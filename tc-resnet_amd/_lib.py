@@ -94,6 +94,9 @@ _PROTOTYPES = {
     "tcr_sgd_momentum_step": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "tcr_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int64, C.c_float, C.c_float, _P]),
+    "tcr_rmsprop_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, _P]),
+    "tcr_ema_step": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "tcr_l2_loss": (C.c_int, [_P, C.c_int64, C.c_float, _P, _P]),
 }
 

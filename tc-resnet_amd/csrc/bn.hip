@@ -121,29 +121,13 @@ int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t 
     return check_launch("chan_reduce_kernel");
 }
 
-// sums[2][C] = sum over chunks (double accumulation, fixed order).  Used on its own when the
-// host all-reduces the sums across replicas (sync BN) before the finalize kernels.
-__global__ __launch_bounds__(128) void chan_sums_kernel(const float* __restrict__ partial, int nchunk, int c, float* __restrict__ sums) {
-    for (int i = threadIdx.x; i < 2 * c; i += 128) {
-        const int which = i / c, ch = i % c;
-        double acc = 0.0;
-        for (int k = 0; k < nchunk; ++k) acc += (double)partial[((size_t)k * 2 + which) * c + ch];
-        sums[i] = (float)acc;
-    }
-}
-
-int launch_chan_sums(const float* partial, int nchunk, int c, float* sums, hipStream_t s) {
-    hipLaunchKernelGGL(chan_sums_kernel, dim3(1), dim3(128), 0, s, partial, nchunk, c, sums);
-    return check_launch("chan_sums_kernel");
-}
-
 // Train-mode forward finalize from sums[2][C] over `count` elements.
 // A workgroup owns kBnCB consecutive channels.  Sum of the per-workgroup partial rows (double accumulation, FIXED
 // order: chunk k goes to slice k % nparts, the slices are then added in order), spread over the whole workgroup; or
 // the pre-reduced sums (sync BN).  Returns through s_out[which * cb + (ch - c0)]; ends with a barrier.
 constexpr int kBnCB = 32;           // channels per finalize workgroup (64 columns x 8 slices of chunks)
 
-__device__ __forceinline__ void reduce_partials(const float* partial, int nchunk, const float* sums, int nc, int c0, int cb,
+__device__ __forceinline__ void reduce_partials(const float* partial, int nchunk, const double* sums, int nc, int c0, int cb,
                                                 double* s_slices, double* s_out) {
     const int n2 = 2 * cb;
     if (nchunk > 0) {
@@ -164,10 +148,29 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk
     } else {
         for (int i = threadIdx.x; i < n2; i += blockDim.x) {
             const int which = i / cb;
-            s_out[i] = (double)sums[which * nc + c0 + i - which * cb];
+            s_out[i] = sums[which * nc + c0 + i - which * cb];
         }
     }
     __syncthreads();
+}
+
+// sums[2][C] (double) = the per-workgroup partial rows added up exactly as the finalize kernels do it themselves (same
+// channel blocks, same slice order), so that "reduce, hand the sums to the host, finalize" is bitwise the unstaged path.
+// The host all-reduces these doubles across replicas (sync BN) before the finalize kernels.
+__global__ __launch_bounds__(512) void chan_sums_kernel(const float* __restrict__ partial, int nchunk, int c, double* __restrict__ sums) {
+    __shared__ double s_slices[512];
+    __shared__ double s_tot[2 * kBnCB];
+    const int c0 = blockIdx.x * kBnCB, cb = min(kBnCB, c - c0);
+    reduce_partials(partial, nchunk, nullptr, c, c0, cb, s_slices, s_tot);
+    for (int i = threadIdx.x; i < 2 * cb; i += blockDim.x) {
+        const int which = i / cb;
+        sums[which * c + c0 + i - which * cb] = s_tot[i];
+    }
+}
+
+int launch_chan_sums(const float* partial, int nchunk, int c, double* sums, hipStream_t s) {
+    hipLaunchKernelGGL(chan_sums_kernel, dim3(ceil_div(c, kBnCB)), dim3(512), 0, s, partial, nchunk, c, sums);
+    return check_launch("chan_sums_kernel");
 }
 
 __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a) {

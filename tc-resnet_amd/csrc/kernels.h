@@ -168,7 +168,7 @@ struct ChanReduceArgs {
 struct BnFinalizeArgs {
     const float* partial;       // [nchunk][2][C] per-workgroup partial sums (nchunk > 0), reduced here in double ...
     int nchunk;                 // ... or 0: take the already reduced (possibly cross-replica) `sums`
-    const float* sums;          // [2][C]: sum y, sum y^2
+    const double* sums;         // [2][C]: sum y, sum y^2
     const float* gamma;
     const float* beta;
     float* moving_mean;
@@ -196,7 +196,7 @@ struct BnApplyArgs {
 struct BnBwdFinalizeArgs {
     const float* partial;   // as in BnFinalizeArgs
     int nchunk;
-    const float* sums;      // [2][C]: sum dz, sum dz*xhat
+    const double* sums;     // [2][C]: sum dz, sum dz*xhat
     const float* gamma;
     const float* invstd;
     float* dgamma;
@@ -229,7 +229,7 @@ int launch_bn_fold(const BnFoldArgs& a, hipStream_t s);
 int chan_reduce_chunks(int npos);
 int chan_reduce_launch_chunks(int npos);
 int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t s);
-int launch_chan_sums(const float* partial, int nchunk, int c, float* sums, hipStream_t s);
+int launch_chan_sums(const float* partial, int nchunk, int c, double* sums, hipStream_t s);
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 int launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);

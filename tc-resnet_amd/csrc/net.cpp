@@ -107,7 +107,7 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
     }
     if (train) {
         w.partial = take((int64_t)512 * 2 * cmax);
-        w.sums = take(2 * cmax);
+        w.sums = take(2 * 2 * cmax);        // doubles
         w.kcoef = take(3 * (int64_t)align_up(cmax, 64));
         w.partial2 = take((int64_t)512 * 2 * cmax);
         w.kcoef2 = take(3 * (int64_t)align_up(cmax, 64));
@@ -513,7 +513,7 @@ static int fwd_unit_pre(const TrainCtx& c, int li, hipStream_t rs, float* partia
     int nchunk = 0;
     TCR_TRY(launch_chan_reduce(0, r, &nchunk, rs));
     if (!c.sync_bn) return TCR_OK;          // the finalize kernel sums the partial rows itself
-    return launch_chan_sums(partial, nchunk, l.cout, c.base + c.w.sums, rs);
+    return launch_chan_sums(partial, nchunk, l.cout, reinterpret_cast<double*>(c.base + c.w.sums), rs);
 }
 
 // statistics -> scale/shift, moving-stat update, normalise (+ReLU / +residual)
@@ -523,7 +523,7 @@ static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* r
     BnFinalizeArgs f;
     f.partial = partial;
     f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout);
-    f.sums = c.base + c.w.sums;
+    f.sums = reinterpret_cast<const double*>(c.base + c.w.sums);
     f.gamma = c.params + l.gamma_off; f.beta = c.params + l.beta_off;
     f.moving_mean = stats + l.mean_off; f.moving_var = stats + l.var_off;
     f.scale = ss; f.shift = ss + l.c_pad;
@@ -638,14 +638,14 @@ extern "C" int tcr_net_forward_train_stage(const tcr_net* net, const float* para
 namespace tcr { static std::vector<int> backward_order(const tcr_net& net); }
 
 extern "C" int tcr_net_stage_sums(const tcr_net* net, int backward, int stage, void* workspace, int batch,
-                                  float** sums_dev, int64_t* n_floats) {
-    TCR_REQUIRE(net && workspace && sums_dev && n_floats, "tcr_net_stage_sums: null argument");
+                                  double** sums_dev, int64_t* n_doubles) {
+    TCR_REQUIRE(net && workspace && sums_dev && n_doubles, "tcr_net_stage_sums: null argument");
     const int nu = (int)net->units.size();
     TCR_REQUIRE(stage >= 0 && stage < nu, "tcr_net_stage_sums: stage %d has no BN hand-off", stage);
     const Workspace w = carve(*net, batch, true);
     const int li = backward ? backward_order(*net)[stage] : net->units[stage];
-    *sums_dev = static_cast<float*>(workspace) + w.sums;
-    *n_floats = 2 * (int64_t)net->layers[li].cout;
+    *sums_dev = reinterpret_cast<double*>(static_cast<float*>(workspace) + w.sums);
+    *n_doubles = 2 * (int64_t)net->layers[li].cout;
     return TCR_OK;
 }
 
@@ -699,7 +699,7 @@ static int bwd_unit_pre(const TrainCtx& c, const BwdUnit& u, hipStream_t st, flo
     int nchunk = 0;
     TCR_TRY(launch_chan_reduce(1, r, &nchunk, st));
     if (!c.sync_bn) return TCR_OK;
-    return launch_chan_sums(partial, nchunk, l.cout, c.base + c.w.sums, st);
+    return launch_chan_sums(partial, nchunk, l.cout, reinterpret_cast<double*>(c.base + c.w.sums), st);
 }
 
 // parts: 1 = BN backward (finalize + apply -> dy), 2 = weight gradient, 4 = data gradient.  bn_stream / partial / kc: where the
@@ -717,7 +717,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
         BnBwdFinalizeArgs f;
         f.partial = partial;
         f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout);
-        f.sums = c.base + c.w.sums; f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[u.li];
+        f.sums = reinterpret_cast<const double*>(c.base + c.w.sums); f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[u.li];
         f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
         f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
         f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
@@ -742,9 +742,16 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
         }
         TCR_TRY(launch_conv_wgrad_partial(l.k, l.stride, l.pad_lo, x, dy, c.base + c.w.wg[u.li], c.batch, l.cin, l.cout, tpi, l.tout, tp,
                                           nullptr, c.side));
-    } else
+    } else {
+        // Wide layers (Cout > 80) reduce their slabs at once through the shared scratch, on the main stream.  When this unit's BN
+        // backward ran early on the side stream (a block's shortcut), dy is written THERE: the main stream waits for it first.
+        if (bn_stream != c.s && hipStreamWaitEvent(c.s, c.net->ev_down, 0) != hipSuccess) {
+            set_error("tcr_net_backward: stream wait failed");
+            return TCR_ERR_HIP;
+        }
         TCR_TRY(launch_conv_wgrad(l.k, l.stride, l.pad_lo, x, dy, grads + l.w_off, c.base + c.w.wgrad_scratch,
                                   c.batch, l.cin, l.cout, tpi, l.tout, tp, c.s));
+    }
     if (l.in_act < 0 || !(parts & BWD_DGRAD)) return TCR_OK;        // (no gradient flows into the features)
     // data gradient into gact[in_act]; the shortcut branch of the block adds its contribution in the same pass
     float* wt = c.base + c.w.wtl[u.li];       // filled for every layer by the first backward stage

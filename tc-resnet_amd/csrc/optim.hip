@@ -39,6 +39,31 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
     }
 }
 
+// tf.train.RMSPropOptimizer (centered=False): ms <- decay*ms + (1-decay)*g^2 ; mom <- momentum*mom + lr*g/sqrt(ms + eps) ;
+// var <- var - mom.  (training_ops ApplyRMSProp: epsilon sits INSIDE the square root; the `rms` slot starts at ONE.)
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ ms,
+                                                      float* __restrict__ mom, int64_t n, int64_t n_decay, float lr, float decay,
+                                                      float momentum, float eps, float wd, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float wv = w[i];
+        float gv = g[i] * gscale;
+        if (i < n_decay) gv = fmaf(wd, wv, gv);
+        const float msv = ms[i] + (1.0f - decay) * (gv * gv - ms[i]);
+        const float mv = momentum * mom[i] + lr * gv / sqrtf(msv + eps);
+        ms[i] = msv;
+        mom[i] = mv;
+        w[i] = wv - mv;
+    }
+}
+
+// tf.train.ExponentialMovingAverage.apply: shadow -= (1 - decay) * (shadow - var)   (assign_moving_average, zero_debias off)
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, const float* __restrict__ w, int64_t n, float one_minus_decay) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float sv = shadow[i];
+        shadow[i] = sv - one_minus_decay * (sv - w[i]);
+    }
+}
+
 __global__ __launch_bounds__(256) void l2_loss_kernel(const float* __restrict__ w, int64_t n, float wd, float* __restrict__ out) {
     __shared__ double s_part[256];
     double s = 0.0;
@@ -83,4 +108,18 @@ extern "C" int tcr_l2_loss(const float* params, int64_t n_decay, float weight_de
     TCR_REQUIRE(params && out && n_decay >= 0, "tcr_l2_loss: bad argument");
     hipLaunchKernelGGL(l2_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), params, n_decay, weight_decay, out);
     return check_launch("l2_loss_kernel");
+}
+
+extern "C" int tcr_rmsprop_step(float* params, const float* grads, float* ms, float* mom, int64_t n, int64_t n_decay, float lr,
+                                float decay, float momentum, float eps, float weight_decay, float grad_scale, void* stream) {
+    TCR_REQUIRE(params && grads && ms && mom && n > 0 && n_decay >= 0 && n_decay <= n, "tcr_rmsprop_step: bad argument");
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads, ms, mom, n,
+                       n_decay, lr, decay, momentum, eps, weight_decay, grad_scale);
+    return check_launch("rmsprop_kernel");
+}
+
+extern "C" int tcr_ema_step(float* shadow, const float* params, int64_t n, float decay, void* stream) {
+    TCR_REQUIRE(shadow && params && n > 0 && decay >= 0.f && decay <= 1.f, "tcr_ema_step: bad argument");
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), shadow, params, n, 1.0f - decay);
+    return check_launch("ema_kernel");
 }

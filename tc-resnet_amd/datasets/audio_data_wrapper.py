@@ -70,11 +70,28 @@ class SingleLabelAudioDataWrapper:
         self.background = PcmPool(clips, device=device) if clips else None
         self.log.info("%d background files are loaded.", len(clips))
         self._aug = get_audio_augmentation_fn(args.augmentation_method)
-        self._rng = np.random.RandomState(int(getattr(args, "seed", 0) or 0))
+        # two generators: the epoch reshuffle must be IDENTICAL on every data-parallel rank (shards of one global order),
+        # the augmentation draws must DIFFER per rank (else every shard gets the same shifts / background crops)
+        self._seed = int(getattr(args, "seed", 0) or 0)
+        self._shuffle_rng = np.random.RandomState(self._seed)
+        self._aug_rngs = {}
         self._order = np.arange(self.num_samples)
         self._cursor = 0
         if self.shuffle:
             random.Random(0).shuffle(self._order)
+        self._order0 = self._order.copy()
+
+    def _aug_rng(self, rank: int) -> np.random.RandomState:
+        if rank not in self._aug_rngs:
+            self._aug_rngs[rank] = np.random.RandomState((self._seed + 7919 * (rank + 1)) % (2 ** 31))
+        return self._aug_rngs[rank]
+
+    def setup_iterator(self, *_args):
+        """Re-initialise the iterator (data_wrapper_base.py setup_iterator): evaluation starts from the first sample."""
+        self._cursor = 0
+        self._order = self._order0.copy()
+        self._shuffle_rng = np.random.RandomState(self._seed)
+        self._aug_rngs = {}
 
     def next_batch(self, rank: int = 0, world: int = 1):
         """(wavs [B, desired_samples, 1] f32, labels_onehot [B, num_classes] f32) for this rank's shard of the next global batch."""
@@ -89,13 +106,19 @@ class SingleLabelAudioDataWrapper:
         if self._cursor >= self.num_samples:
             self._cursor %= self.num_samples
             if self.is_training and self.shuffle:
-                self._rng.shuffle(self._order)
+                self._shuffle_rng.shuffle(self._order)
         wavs = self._aug(self.pool, idx, self.desired_samples, "wav", int(self.args.sample_rate), background_data=self.background,
                          is_training=self.is_training, background_frequency=float(getattr(self.args, "background_frequency", 0.8)),
-                         background_max_volume=float(getattr(self.args, "background_max_volume", 0.1)), rng=self._rng)
+                         background_max_volume=float(getattr(self.args, "background_max_volume", 0.1)), rng=self._aug_rng(rank))
         labels = torch.zeros((b, self.num_labels), dtype=torch.float32, device=wavs.device)
         labels[torch.arange(b, device=wavs.device), torch.from_numpy(self.labels[idx]).to(wavs.device)] = 1.0      # parse_label :114-118
         return wavs, labels
 
     def get_input_and_output_op(self):
-        return self.next_batch()
+        """The (wavs, labels) pair the model is first built on.  A peek: cursor, order and generators are restored, like
+        building the reference's graph does not consume the dataset."""
+        import copy
+        saved = (self._cursor, self._order.copy(), copy.deepcopy(self._shuffle_rng), copy.deepcopy(self._aug_rngs))
+        out = self.next_batch()
+        self._cursor, self._order, self._shuffle_rng, self._aug_rngs = saved
+        return out

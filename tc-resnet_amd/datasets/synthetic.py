@@ -34,6 +34,16 @@ class SyntheticAudioDataWrapper:
         labels[torch.arange(b, device=self.device), idx % self.num_classes] = 1.0      # one-hot float32
         return wav, labels
 
+    def setup_iterator(self, *_args):
+        """Re-initialise the iterator: the next batch is the first of the split again (data_wrapper_base.py setup_iterator)."""
+        self._cursor = 0
+        self._gen.manual_seed(1234)
+
     def get_input_and_output_op(self):
-        """Reference name: returns the first (wavs [B, n, 1], labels [B, num_classes]) pair."""
-        return self.next_batch()
+        """Reference name: the (wavs [B, n, 1], labels [B, num_classes]) pair the graph is built on.  A peek: the iterator is
+        where it was afterwards, like building the reference's graph does not consume the dataset."""
+        state, cursor = self._gen.get_state(), self._cursor
+        out = self.next_batch()
+        self._gen.set_state(state)
+        self._cursor = cursor
+        return out

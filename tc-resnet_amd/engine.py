@@ -295,7 +295,7 @@ class TCResNet(_Base):
         self.lib.check(self.lib.tcr_net_stage_sums(self._h, backward, stage, ws.data_ptr(), batch, C.byref(ptr), C.byref(n)),
                        "tcr_net_stage_sums")
         off = (ptr.value - ws.data_ptr()) // 4
-        return ws[off:off + n.value]
+        return ws[off:off + 2 * n.value].view(torch.float64)        # 2*C float64 sums living inside the f32 workspace
 
     def backward(self) -> torch.Tensor:
         """Gradient of the mean cross-entropy wrt every trainable, into self.grads (L2 excluded)."""
@@ -319,6 +319,21 @@ class TCResNet(_Base):
             self.slots[name] = torch.zeros_like(self.params)
         return self.slots[name]
 
+    def slot_arena(self, name: str) -> torch.Tensor:
+        """Arena-shaped optimiser slot under its TF name, created with TF's initial value: `RMSProp` (the rms accumulator)
+        starts at one, `ExponentialMovingAverage` as a copy of the variables, every other slot at zero."""
+        if name not in self.slots:
+            if name == "RMSProp":
+                self.slots[name] = torch.ones_like(self.params)
+            elif name == "ExponentialMovingAverage":
+                self.slots[name] = self.params.clone()
+            else:
+                self.slots[name] = torch.zeros_like(self.params)
+        return self.slots[name]
+
+    def ema_init(self):
+        self.slots["ExponentialMovingAverage"] = self.params.clone()
+
     def sgd_momentum_step(self, lr: float, momentum: float = 0.9, weight_decay: float = 0.0, grad_scale: float = 1.0):
         m = self._slot("Momentum")
         self.lib.check(self.lib.tcr_sgd_momentum_step(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), self.n_param,
@@ -331,6 +346,21 @@ class TCResNet(_Base):
         self.lib.check(self.lib.tcr_adam_step(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), v.data_ptr(),
                                               self.n_param, self.n_decay, float(lr), float(beta1), float(beta2), float(eps),
                                               int(step), float(weight_decay), float(grad_scale), self._stream()), "tcr_adam_step")
+
+    def rmsprop_step(self, lr: float, decay: float = 0.9, momentum: float = 0.0, eps: float = 1e-10, weight_decay: float = 0.0,
+                     grad_scale: float = 1.0):
+        """tf.train.RMSPropOptimizer; slot names as in TF (`RMSProp` = rms, initialised to one; `RMSProp_1` = momentum)."""
+        ms, mom = self.slot_arena("RMSProp"), self.slot_arena("RMSProp_1")
+        self.lib.check(self.lib.tcr_rmsprop_step(self.params.data_ptr(), self.grads.data_ptr(), ms.data_ptr(), mom.data_ptr(),
+                                                 self.n_param, self.n_decay, float(lr), float(decay), float(momentum), float(eps),
+                                                 float(weight_decay), float(grad_scale), self._stream()), "tcr_rmsprop_step")
+
+    def ema_step(self, decay: float):
+        """tf.train.ExponentialMovingAverage(decay).apply(trainables): the shadow arena starts as a copy of the variables'
+        initial values (`ema_init()`, called when the train op is built)."""
+        sh = self.slot_arena("ExponentialMovingAverage")
+        self.lib.check(self.lib.tcr_ema_step(sh.data_ptr(), self.params.data_ptr(), self.n_param, float(decay), self._stream()),
+                       "tcr_ema_step")
 
     def l2_loss(self, weight_decay: float) -> torch.Tensor:
         out = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -392,6 +422,10 @@ class DSCNN(_Base):
     _slot = TCResNet._slot
     adam_step = TCResNet.adam_step
     sgd_momentum_step = TCResNet.sgd_momentum_step
+    rmsprop_step = TCResNet.rmsprop_step
+    ema_step = TCResNet.ema_step
+    slot_arena = TCResNet.slot_arena
+    ema_init = TCResNet.ema_init
 
     def total_params(self) -> int:
         return sum(int(ti.size) for ti in self.tensors.values() if ti.arena == 0)

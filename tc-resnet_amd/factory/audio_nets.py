@@ -17,6 +17,7 @@ import torch
 from .. import runtime
 from ..audio_nets import tc_resnet
 from ..datasets import preprocessor_factory
+from ..common import tf_utils
 from ..parallel import DataParallel
 from .base import TFModel
 
@@ -43,8 +44,7 @@ class AudioNetModel(TFModel):
         self.preprocess_input()
         self.inputs, self.logits, self._outputs, self.endpoints = self.build_output(self.audio, self.is_training, self.args.output_name)
         self._total_loss, self._model_loss, self.endpoints_loss = self.build_loss(self.logits, self.outputs, self.labels)
-        self.total_params = self.engine.total_params()
-        self.log.info("total trainable parameters: %d", self.total_params)
+        self.total_params = tf_utils.show_models(self.log, self.engine)
 
     def preprocess_input(self, for_deploy=False):
         window_size_samples = int(self.args.sample_rate * self.args.window_size_ms / 1000)
@@ -113,9 +113,18 @@ class AudioNetModel(TFModel):
             self._dp = DataParallel(self.engine, sync_bn=sync_bn)
         return self._dp
 
-    def train_step(self, wavs, labels, learning_rate, optimizer="mom", momentum=0.9, sync_bn=False,
-                   adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8):
-        """One optimisation step on a (local shard of a) batch; returns (total_loss, model_loss) as device scalars."""
+    def set_step(self, step: int):
+        """Continue the step counter of a restored run: Adam's bias-correction power t and the dropout stream are functions of it."""
+        self._step = int(step)
+
+    def step_count(self) -> int:
+        return self._step
+
+    def train_step(self, wavs, labels, learning_rate, optimizer="mom", momentum=None, decay=None, epsilon=None, sync_bn=False,
+                   ema_decay=None):
+        """One optimisation step on a (local shard of a) batch; returns (total_loss, model_loss) as device scalars.
+        momentum / decay / epsilon: the tf.train optimiser constructor overrides (None = TF's default:
+        Momentum needs `momentum`; Adam beta1 .9, beta2 .999, epsilon 1e-8; RMSProp decay .9, momentum 0, epsilon 1e-10)."""
         self._audio_original, self.labels, self.is_training = wavs, labels, True
         self.preprocess_input()
         self._step += 1
@@ -128,13 +137,18 @@ class AudioNetModel(TFModel):
         l2 = self.engine.l2_loss(self.args.weight_decay)
         wd = float(self.args.weight_decay)
         if optimizer == "mom":
-            self.engine.sgd_momentum_step(learning_rate, momentum, wd)
+            self.engine.sgd_momentum_step(learning_rate, 0.9 if momentum is None else momentum, wd)
         elif optimizer == "gd":
             self.engine.sgd_momentum_step(learning_rate, 0.0, wd)
         elif optimizer == "adam":
-            self.engine.adam_step(learning_rate, self._step, adam_beta1, adam_beta2, adam_epsilon, wd)
+            self.engine.adam_step(learning_rate, self._step, 0.9, 0.999, 1e-8 if epsilon is None else epsilon, wd)
+        elif optimizer == "rmsprop":
+            self.engine.rmsprop_step(learning_rate, 0.9 if decay is None else decay, 0.0 if momentum is None else momentum,
+                                     1e-10 if epsilon is None else epsilon, wd)
         else:
             raise NotImplementedError(f"optimizer {optimizer}")
+        if ema_decay is not None:
+            self.engine.ema_step(ema_decay)
         self._model_loss = dp.mean_loss(loss_sum, b)
         self._total_loss = self._model_loss + l2
         return self._total_loss, self._model_loss
