@@ -100,6 +100,8 @@ def main():
             dist.init_process_group(backend)
 
     B = args.batch
+    # what the collective of the training legs actually is: dist.get_backend() ("nccl" on ROCm is RCCL over xGMI)
+    coll = {"nccl": "RCCL (backend nccl)", "gloo": "gloo (CPU rehearsal, not RCCL)"}.get(dist.get_backend(), dist.get_backend()) if dist_on else None
 
     def build(tag):
         w = WORK[tag]
@@ -150,7 +152,8 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
     traffic, traffic_src = pmc_traffic("frontend_pk_kernel<512,")
-    roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": "frontend_pk_kernel<512, 10, false>", "kernel_ms": round(fe_ms, 4),
+    prof_avg_us, prof_src = profile_avg_us("frontend_pk_kernel<512,")
+    roof.update({"traffic": traffic, "traffic_source": traffic_src, "profile_avg_us": prof_avg_us, "profile_source": prof_src, "kernel": "frontend_pk_kernel<512, 10, false>", "kernel_ms": round(fe_ms, 4),
                  "note": "f32 VALU pipe; its 157.3 TFLOP/s peak equals the exact-f32 MFMA peak. HIP-event-bracketed launch on the "
                          "launch stream, inside the timed region",
                  "hbm_gbs": round(fe_gbs, 1), "hbm_frac": round(hbm_frac, 4), "fp32_tflops": round(fe_tf, 3), "fp32_frac": round(fp_frac, 4),
@@ -161,7 +164,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"TCResNet8-1.0 eval forward, waveform->softmax, batch {B}/GPU, 49x40 MFCC (40/20 ms, FFT 1024), 12 classes",
-                   "global_batch": world * B, "parallelism": f"dp{world} (utterance shards, no collective)"},
+                   "global_batch": world * B, "parallelism": f"dp{world} (utterance shards, no collective)", "collective_backend": dist.get_backend() if dist_on else None},
         "roofline": roof,
         "phases_ms": {"frontend": round(fe_ms, 4), "net": round(net_ms, 4)},
         "step_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
@@ -193,7 +196,7 @@ def main():
         tdt = timed(train_step, tsteps, max(2, args.warmup // 2), dist_on)
         out["train"] = {"value": round(world * B * tsteps / tdt, 1), "unit": "utterances/s", "ms_per_step": round(tdt / tsteps * 1e3, 4),
                         "steps": tsteps, "workload": "TCResNet8-1.0 train step: MFCC (prefetched on a second stream) + train-mode BN fwd + bwd + momentum (wd 1e-3, keep_prob 0.5), "
-                                                     "batch 4096/GPU" + (", RCCL all-reduce of the flat gradient arena" if dist_on else "")}
+                                                     f"batch {B}/GPU" + (f", {coll} all-reduce of the flat gradient arena" if dist_on else "")}
         # ---------------- TCResNet14-1.5 training (configs[3]: global batch 32768 = 8 x 4096 over RCCL) ----------------
         net14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, fe.n_frames, 12, device=dev)
         net14.init_xavier(0)
@@ -211,7 +214,7 @@ def main():
         dt14 = timed(train14_step, t14, 2, dist_on)
         out["train_tcresnet14_1.5"] = {"value": round(world * B * t14 / dt14, 1), "unit": "utterances/s", "ms_per_step": round(dt14 / t14 * 1e3, 4),
                                        "steps": t14, "workload": f"TCResNet14-1.5 train step, batch 4096/GPU (global {world * B}), 303 144 params"
-                                                                 + (", RCCL all-reduce of the 1.21 MB gradient arena" if dist_on else "")}
+                                                                 + (f", {coll} all-reduce of the 1.21 MB gradient arena" if dist_on else "")}
         del net14, dp14
         # ---------------- 30/10 ms front-end (98x40, the reference's training scripts) ----------------
         fe2, net2 = build("3010")
@@ -258,7 +261,7 @@ def main():
         out["dscnn_l_train"] = {"value": round(world * B * tds / dtd, 1), "unit": "utterances/s", "ms_per_step": round(dtd / tds * 1e3, 4),
                                 "steps": tds, "net_tflops": round(B * tds / dtd * 3.0 * ds_flops / 1e12, 2),
                                 "workload": "DSCNNLModel train step: MFCC + train-mode BN fwd + bwd + Adam, batch 4096/GPU"
-                                            + (", RCCL all-reduce of the gradient arena" if dist_on else "")}
+                                            + (f", {coll} all-reduce of the gradient arena" if dist_on else "")}
         # ---------------- TCResNet8 training with the 30/10 ms front-end (the reference's training scripts) ----------------
         dp2 = DataParallel(net2)
         pf2 = FeaturePrefetcher(fe2, B, overlap=overlap)
@@ -326,8 +329,22 @@ def pmc_traffic(kernel: str):
     return None, None
 
 
+def profile_avg_us(kernel: str):
+    """Average launch duration of `kernel` in the committed forward-only rocprofv3 --kernel-trace --stats summary of this command
+    (`bench.py --no-extras --no-cpu-baseline` under scripts/gpu_prof.sh -> profiles/*_fwd_kernel_stats.csv): the file the
+    roofline's `kernel_ms` can be recomputed from."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_fwd_kernel_stats.csv")), reverse=True):
+        for r in csv.DictReader(open(path)):
+            if r["kernel"].startswith(kernel):
+                return round(float(r["avg_ns"]) / 1e3, 2), os.path.join("profiles", os.path.basename(path))
+    return None, None
+
+
 def cpu_baseline():
-    """The oracle's PyTorch-CPU float32 restatement of the same path, timed on the host cores (bounded sample)."""
+    """The oracle's PyTorch-CPU float32 restatement of the same path, timed on the host cores (bounded sample, ~25 s):
+    eval forward at batch 1 (BASELINE.json configs[0]), 256 and 4096, and one training step (fwd + autograd bwd + momentum) at 256."""
     from oracle import numpy_ref as R
     from oracle import torch_ref as TR
     try:
@@ -349,18 +366,31 @@ def cpu_baseline():
         if rate > best:
             best, threads = rate, th
     cb = TR.CpuBaseline(arch, R.FRONTEND_4020, p, s, threads)
-    b = 256
-    wav = torch.from_numpy(R.synth_waveforms(b))
-    cb.infer(wav)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < 10.0:
-        cb.infer(wav)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n * b / dt, 1), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} x batch {b} eval forwards (waveform->softmax, 49x40 MFCC) in {dt:.1f} s; PyTorch-CPU f32 restatement "
+
+    def rate_of(fn, b, budget):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            fn()
+            n += 1
+        dt = time.perf_counter() - t0
+        return round(n * b / dt, 1), n, dt
+
+    legs = {}
+    base256 = torch.from_numpy(R.synth_waveforms(256))
+    for b, budget in ((1, 3.0), (256, 6.0), (4096, 6.0)):
+        wav = base256[:b] if b <= 256 else base256.repeat(b // 256, 1)
+        legs[b] = rate_of(lambda: cb.infer(wav), b, budget)
+    lab = torch.from_numpy(R.synth_labels(256).astype("float32"))
+    tr = rate_of(lambda: cb.train_step(base256, lab, 0.1, 0.9, 0.001), 256, 5.0)
+    v, n, dt = legs[256]
+    return {"value": v, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x batch 256 eval forwards (waveform->softmax, 49x40 MFCC) in {dt:.1f} s; PyTorch-CPU f32 restatement "
                       f"of the TF1 graph (oracle/torch_ref.py); {torch.get_num_threads()} threads (best of a 1 s sweep), "
-                      f"{avail} usable of os.cpu_count()={os.cpu_count()}"}
+                      f"{avail} usable of os.cpu_count()={os.cpu_count()}",
+            "forward_by_batch": {str(b): {"value": legs[b][0], "batches": legs[b][1], "seconds": round(legs[b][2], 1)} for b in legs},
+            "train_step_batch_256": {"value": tr[0], "steps": tr[1], "seconds": round(tr[2], 1),
+                                     "what": "MFCC + train-mode BN forward + autograd backward + momentum update, keep_prob 1"}}
 
 
 if __name__ == "__main__":

@@ -111,3 +111,22 @@ class CpuBaseline:
     @torch.no_grad()
     def infer(self, wav: torch.Tensor) -> torch.Tensor:
         return forward(self.arch, self.params, self.stats, mfcc(wav, self.cfg), False)["probs"]
+
+    def train_step(self, wav: torch.Tensor, labels: torch.Tensor, lr: float, mu: float, weight_decay: float) -> float:
+        """One float32 training step on the host cores: MFCC, train-mode forward, autograd backward, momentum update, moving
+        statistics (the bench's CPU train-step leg)."""
+        if not hasattr(self, "_mom"):
+            self._mom = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        params = {k: v.detach().requires_grad_(True) for k, v in self.params.items()}
+        with torch.no_grad():
+            x = mfcc(wav, self.cfg)
+        out = forward(self.arch, params, self.stats, x, True)
+        tot, _ = total_loss(out["logits"], labels, params, weight_decay)
+        tot.backward()
+        with torch.no_grad():
+            for k, v in params.items():
+                g = v.grad if v.grad is not None else torch.zeros_like(v)
+                self._mom[k].mul_(mu).add_(g)
+                self.params[k] = v.detach() - lr * self._mom[k]
+            self.stats = {k: v.detach() for k, v in out["new_stats"].items()}
+        return float(tot.detach())

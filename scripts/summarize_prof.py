@@ -22,14 +22,17 @@ def short(name: str) -> str:
 
 def main(src, dst):
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
-    if stats:
+    for sub, suffix in (("trace", "_kernel_stats.csv"), ("trace_fwd", "_fwd_kernel_stats.csv")):
+        stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+        if not stats:
+            continue
         rows = list(csv.DictReader(open(stats[0])))
-        with open(dst + "_kernel_stats.csv", "w", newline="") as fh:
+        with open(dst + suffix, "w", newline="") as fh:
             w = csv.writer(fh)
             w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "percent"])
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
+        print("wrote", dst + suffix)
     agg = collections.OrderedDict()
     for f in sorted(glob.glob(os.path.join(src, "pmc*", "*counter_collection.csv"))):
         for r in csv.DictReader(open(f)):

@@ -333,7 +333,7 @@ static int forward_infer_fused(const tcr_net& net, const float* params, const fl
     }
     if (!ok || net.param_floats >= (int64_t)1 << 31) return 1;
     const int per_utt = sz[0] + sz[1] + sz[2];
-    // Policy (scripts/fused_test.py, B = 4096, TCResNet8-1.0 / TCResNet14-1.5 at 49 and 98 frames): the largest group of
+    // Policy (scripts/fused_sweep.py, B = 4096, TCResNet8-1.0 / TCResNet14-1.5 at 49 and 98 frames): the largest group of
     // up to 8 utterances whose activations fit the CU's 160 KB of LDS (more positions per layer = fuller MFMA tiles and
     // more jobs per barrier phase), and as many waves per workgroup as keeps ~16 waves on the CU (the kernel needs
     // ~90 VGPRs: 5 waves / SIMD at most).

@@ -274,3 +274,90 @@ def check_dscnn_train_live(lib, size, grad_rtol=2e-4):
     for k, ref in f["new_stats"].items():
         assert np.abs(net._view(k).cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), k
     return worst
+
+
+# ---- live-oracle checks at sizes without a committed fixture --------------------------------------------------------------
+def relu_margin(arch, fwd) -> float:
+    """Distance of the closest ReLU input of a train-mode forward to the kink: an f32 implementation cannot be expected to
+    land on the same side of an input within round-off of zero, and one flipped mask moves that channel's gradient."""
+    cache = fwd["cache"]
+    m = min(np.abs(cache[c.name]["z"]).min() for c in arch.convs() if c.bn and c.relu)
+    return float(min(m, min(np.abs(cache[f"block{b.index}/out"]["pre"]).min() for b in arch.blocks)))
+
+
+def pick_waveforms(arch, p, s, cfg, batch, seeds=range(100, 112)):
+    """The candidate waveform batch whose train-mode pre-activations stay farthest from the ReLU kink (as make_golden does)."""
+    best = None
+    for seed in seeds:
+        wav = R.synth_waveforms(batch, seed=seed)
+        f = R.forward(arch, p, s, R.mfcc(wav, cfg), True)
+        mg = relu_margin(arch, f)
+        if best is None or mg > best[0]:
+            best = (mg, wav)
+    return best
+
+
+def check_small_batch(lib, batch, name="TCResNet8", width=1.0, tag="4020", seeds=range(100, 112)):
+    """BASELINE.json configs[0] (batch = 1) and batch 2: eval forward + one training step (train-mode BN over `batch` x T'
+    positions, backward, momentum) against the oracle evaluated on the spot."""
+    cfg = R.FRONTEND_4020 if tag == "4020" else R.FRONTEND_3010
+    arch = R.make_tcresnet(name, float(width))
+    p, s = R.init_params(arch, 5)
+    R.randomize_bn(arch, p, s, 6)
+    margin, wav = pick_waveforms(arch, p, s, cfg, batch, seeds)
+    assert margin > 1e-6, margin
+    labels = R.synth_labels(batch).astype(np.float64)
+    x = R.mfcc(wav, cfg)
+    fe = make_frontend(lib, cfg.win, cfg.hop)
+    feat = fe(to_dev(lib, wav))
+    net = make_net(lib, name, width, fe.n_frames, p, s)
+    ev = R.forward(arch, p, s, x, False)
+    logits, probs = net.forward_infer(feat)
+    assert np.abs(logits.cpu().numpy() - ev["logits"]).max() < LOGIT_TOL
+    assert np.array_equal(logits.cpu().numpy().argmax(1), ev["logits"].argmax(1)) and np.abs(probs.cpu().numpy() - ev["probs"]).max() < 1e-5
+    tr = R.forward(arch, p, s, x, True)
+    tl, tp, loss_sum = net.forward_train(feat, to_dev(lib, labels), keep_prob=1.0)
+    net.backward()
+    assert np.abs(tl.cpu().numpy() - tr["logits"]).max() < LOGIT_TOL
+    assert abs(float(loss_sum) / batch - R.loss(tr["logits"], labels, p, 0.0)[1]) < 1e-4
+    g = R.backward(arch, p, tr, labels, 0.0)
+    worst = 0.0
+    for k, ref in g.items():
+        got = net.grad_view(k).cpu().numpy().reshape(ref.shape).astype(np.float64)
+        e = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3)
+        worst = max(worst, e)
+        assert e < 2e-4, f"{k}: grad rel err {e} (batch {batch})"
+    for k, ref in tr["new_stats"].items():
+        assert np.abs(net._view(k).cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), k
+    net.sgd_momentum_step(0.1, 0.9, 0.001)
+    for k, ref in g.items():
+        w1 = p[k] - 0.1 * (ref + (0.001 * p[k] if R.is_l2_param(k) else 0.0))
+        assert np.abs(net._view(k).cpu().numpy().reshape(w1.shape) - w1).max() < 2e-5, k
+    return worst
+
+
+def check_staged_equals_unstaged(lib, name, width, batch, tag="4020", keep_prob=0.5):
+    """One replica: forward_train / backward run stage by stage through the sync-BN hand-off API with an identity hook must be
+    BITWISE the unstaged path (logits, loss, every gradient, moving statistics)."""
+    cfg = R.FRONTEND_4020 if tag == "4020" else R.FRONTEND_3010
+    arch = R.make_tcresnet(name, float(width))
+    p, s = R.init_params(arch, 2)
+    R.randomize_bn(arch, p, s, 3)
+    base = R.synth_waveforms(min(batch, 64), seed=21)
+    reps = max(batch // base.shape[0], 1)
+    wav = to_dev(lib, np.tile(base, (reps, 1)))
+    labels = to_dev(lib, np.tile(R.synth_labels(base.shape[0]), (reps, 1)))
+    fe = make_frontend(lib, cfg.win, cfg.hop)
+    feat = fe(wav)
+    outs = []
+    seen = []
+    for hook in (None, lambda sums: seen.append((sums.dtype, sums.numel()))):
+        net = make_net(lib, name, width, fe.n_frames, p, s)
+        logits, probs, loss = net.forward_train(feat, labels, keep_prob=keep_prob, seed=11, sync_hook=hook)
+        g = net.backward().clone()
+        outs.append((logits.clone(), probs.clone(), loss.clone(), g, net.stats.clone()))
+    nbn = len([c for c in arch.convs() if c.bn])
+    assert len(seen) == 2 * nbn and all(dt == torch.float64 for dt, _ in seen)
+    for a, b, what in zip(outs[0], outs[1], ("logits", "probs", "loss", "grads", "moving stats")):
+        assert torch.equal(a, b), f"staged {what} differ from the unstaged run (max |d| {float((a - b).abs().max())})"
+    assert torch.isfinite(outs[0][3]).all()

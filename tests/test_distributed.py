@@ -1,6 +1,10 @@
-"""CPU, world_size 2 over gloo: the data-parallel path (utterance shards, sync-BN statistic hand-off, one
-all-reduce of the flat gradient arena) reproduces the single-process global-batch step.  On the GPU box the same
-code runs over RCCL (backend "nccl"); kernels here come from the emulator build (test infrastructure)."""
+"""world_size 2: the data-parallel path (utterance shards, sync-BN statistic hand-off, one all-reduce of the flat gradient
+arena) reproduces the single-process global-batch step.
+
+  * CPU (`-m "not gpu"`): gloo, kernels from the emulator build (test infrastructure);
+  * GPU (`-m gpu`): the SAME code with the gfx950 library -- two processes time-sharing the one GPU of the test box over gloo
+    (the box has a single device, so RCCL itself cannot be exercised there; on the 8-GPU node the identical calls go through
+    backend "nccl"), TCResNet14-1.5 = BASELINE.json configs[3]'s model."""
 import os
 import socket
 
@@ -16,38 +20,42 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "emu", "_build", "libtcr_emu.so")
 
 
-def _setup(lib):
+def _lib_of(kind):
     import tcresnet_amd as T
-    arch = R.make_tcresnet("TCResNet8", 1.0)
+    return T._lib.load_from(EMU) if kind == "emu" else T._lib.get()
+
+
+def _setup(lib, name="TCResNet8", width=1.0):
+    import tcresnet_amd as T
+    arch = R.make_tcresnet(name, width)
     p, s = R.init_params(arch, 0)
     R.randomize_bn(arch, p, s)
-    fe = T.Frontend(window_size_samples=640, window_stride_samples=320, lib=lib)
-    net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, fe.n_frames, 12, lib=lib)
+    dev = "cuda" if lib.kind == "hip" else None
+    fe = T.Frontend(window_size_samples=640, window_stride_samples=320, lib=lib, device=dev)
+    net = T.TCResNet(name, R.tcresnet_channels(name, width), 40, fe.n_frames, 12, lib=lib, device=dev)
     sd = dict(p); sd.update(s)
     net.load_state_dict(sd)
     return fe, net
 
 
-def _worker(rank, world, port, sync_bn, out_dir):
+def _worker(rank, world, port, sync_bn, out_dir, kind, name, width, b):
     import sys
     sys.path.insert(0, ROOT)
-    import tcresnet_amd as T
     from tcresnet_amd.parallel import DataParallel
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lib = T._lib.load_from(EMU)
-    fe, net = _setup(lib)
-    b = 3
-    wav = torch.from_numpy(R.synth_waveforms(b, seed=77, start=rank * b))
-    lab = torch.from_numpy(R.synth_labels(b, start=rank * b))
+    lib = _lib_of(kind)
+    fe, net = _setup(lib, name, width)
+    wav = torch.from_numpy(R.synth_waveforms(b, seed=77, start=rank * b)).to(fe.device)
+    lab = torch.from_numpy(R.synth_labels(b, start=rank * b)).to(fe.device)
     dp = DataParallel(net, sync_bn=sync_bn)
     assert dp.enabled and dp.world == world and dp.rank == rank
     logits, probs, loss_sum = dp.forward_train(fe(wav), lab, keep_prob=0.5, seed=3)
     g = dp.backward()
     mean_loss = dp.mean_loss(loss_sum, b)
     net.sgd_momentum_step(0.1, 0.9, 0.001)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), grads=g.numpy(), logits=logits.numpy(), loss=float(mean_loss),
-             params=net.params.numpy(), stats=net.stats.numpy())
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), grads=g.cpu().numpy(), logits=logits.cpu().numpy(), loss=float(mean_loss),
+             params=net.params.cpu().numpy(), stats=net.stats.cpu().numpy())
     dist.destroy_process_group()
 
 
@@ -57,30 +65,80 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("sync_bn", [True, False])
-def test_two_replicas_match_global_batch(emu_lib, tmp_path, sync_bn):
+def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), sync_bn, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), sync_bn, str(tmp_path), kind, name, width, b), nprocs=world, join=True)
     r = [dict(np.load(tmp_path / f"rank{i}.npz")) for i in range(world)]
     # replicas hold identical gradients / parameters / moving statistics after the all-reduce
     assert np.array_equal(r[0]["grads"], r[1]["grads"]) and np.array_equal(r[0]["params"], r[1]["params"])
     assert abs(float(r[0]["loss"]) - float(r[1]["loss"])) == 0.0
     if sync_bn:
         assert np.array_equal(r[0]["stats"], r[1]["stats"])
-    # single process, global batch of 6, same dropout stream (masks are indexed by global sample id)
-    fe, net = _setup(emu_lib)
-    wav = torch.from_numpy(R.synth_waveforms(6, seed=77))
-    lab = torch.from_numpy(R.synth_labels(6))
+    # single process, global batch of 2b, same dropout stream (masks are indexed by global sample id)
+    fe, net = _setup(lib, name, width)
+    wav = torch.from_numpy(R.synth_waveforms(2 * b, seed=77)).to(fe.device)
+    lab = torch.from_numpy(R.synth_labels(2 * b)).to(fe.device)
     logits, probs, loss_sum = net.forward_train(fe(wav), lab, keep_prob=0.5, seed=3)
-    g = net.backward().numpy().copy()
+    g = net.backward().cpu().numpy().copy()
     if sync_bn:
         # cross-replica statistics == the reference's single-device global-batch BN: everything matches
-        assert np.abs(np.concatenate([r[0]["logits"], r[1]["logits"]]) - logits.numpy()).max() < 2e-5
-        assert abs(float(r[0]["loss"]) - float(loss_sum) / 6) < 1e-5
+        assert np.abs(np.concatenate([r[0]["logits"], r[1]["logits"]]) - logits.cpu().numpy()).max() < 2e-5
+        assert abs(float(r[0]["loss"]) - float(loss_sum) / (2 * b)) < 1e-5
         assert np.abs(r[0]["grads"] - g).max() < 2e-5 * max(1.0, np.abs(g).max())
         net.sgd_momentum_step(0.1, 0.9, 0.001)
-        assert np.abs(r[0]["params"] - net.params.numpy()).max() < 1e-5
-        assert np.abs(r[0]["stats"] - net.stats.numpy()).max() < 1e-5
+        assert np.abs(r[0]["params"] - net.params.cpu().numpy()).max() < 1e-5
+        assert np.abs(r[0]["stats"] - net.stats.cpu().numpy()).max() < 1e-5
     else:
         # per-replica BN is the documented deviation: finite, but not the global-batch statistics
         assert np.isfinite(r[0]["grads"]).all() and np.abs(r[0]["grads"] - g).max() > 1e-4
+
+
+@pytest.mark.parametrize("sync_bn", [True, False])
+def test_two_replicas_match_global_batch(emu_lib, tmp_path, sync_bn):
+    _two_replicas(emu_lib, "emu", tmp_path, sync_bn, "TCResNet8", 1.0, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sync_bn", [True, False])
+def test_two_replicas_match_global_batch_hip(hip_lib, tmp_path, sync_bn):
+    """TCResNet14-1.5 (configs[3]) on the gfx950 library: staged sync-BN + arena all-reduce across two processes."""
+    _two_replicas(hip_lib, "hip", tmp_path, sync_bn, "TCResNet14", 1.5, 16)
+
+
+def _cli_worker(rank, world, port, kind, train_dir, sync_bn):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LOCAL_WORLD_SIZE=str(world), TCR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from tcresnet_amd import runtime, train_audio
+    from tests.test_boundary import REF_TRAIN_CMD
+    runtime.set_default(_lib_of(kind), "cpu" if kind == "emu" else "cuda")
+    cmd = REF_TRAIN_CMD.replace("--batch_size 6", "--batch_size 3").replace("--max_step_from_restore 3", "--max_step_from_restore 2")
+    if sync_bn:
+        cmd = cmd.replace("--optimizer mom", "--sync_bn --optimizer mom")
+    tr = train_audio.train(train_audio.parse_arguments(cmd.format(d=train_dir).split()))
+    np.savez(os.path.join(train_dir, f"final{rank}.npz"), params=tr.model.engine.params.cpu().numpy(), stats=tr.model.engine.stats.cpu().numpy(),
+             step=tr.global_step)
+    dist.destroy_process_group()
+
+
+def _cli_two_ranks(kind, tmp_path, sync_bn):
+    from tcresnet_amd.common import tf_bundle
+    mp.spawn(_cli_worker, args=(2, _free_port(), kind, str(tmp_path), sync_bn), nprocs=2, join=True)
+    r = [dict(np.load(tmp_path / f"final{i}.npz")) for i in range(2)]
+    assert int(r[0]["step"]) == int(r[1]["step"]) == 2
+    assert np.array_equal(r[0]["params"], r[1]["params"])          # one all-reduced gradient, one identical update on every rank
+    assert np.array_equal(r[0]["stats"], r[1]["stats"])            # sync BN: identical by construction; otherwise averaged before the save
+    ck = tf_bundle.read_checkpoint(str(tmp_path / "TCResNet8Model-2"))      # written by rank 0 only
+    assert int(ck["global_step"]) == 2 and np.isfinite(ck["TCResNet8/conv0/weights"]).all()
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_train_audio_cli_two_ranks(emu_lib, tmp_path, sync_bn):
+    """The reference command line under torch.distributed (2 ranks, gloo): shards of one global batch, replicas stay in lockstep."""
+    _cli_two_ranks("emu", tmp_path, sync_bn)
+
+
+@pytest.mark.gpu
+def test_train_audio_cli_two_ranks_hip(hip_lib, tmp_path):
+    _cli_two_ranks("hip", tmp_path, True)

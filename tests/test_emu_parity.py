@@ -106,3 +106,18 @@ def test_dscnn_eval_forward(emu_lib, size):
 def test_dscnn_train_steps(emu_lib, size):
     """Train-mode forward + backward + Adam (3 steps) of DS-CNN; S: (2,2)/(1,1) strides, L: (2,1)/(2,2) and 276 channels."""
     Cm.check_dscnn_train(emu_lib, size, steps=3 if size == "S" else 1)
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_small_batches_against_live_oracle(emu_lib, batch):
+    """BASELINE.json configs[0]: batch = 1 (and 2) eval forward + a training step."""
+    Cm.check_small_batch(emu_lib, batch, seeds=range(100, 104))
+
+
+def test_staged_sync_bn_api_is_bitwise_the_unstaged_path(emu_lib):
+    Cm.check_staged_equals_unstaged(emu_lib, "TCResNet8", 1.0, batch=5)
+
+
+def test_wide_net_training(emu_lib):
+    """width_multiplier 2.0: 96 output channels take the non-deferrable weight-gradient branch."""
+    Cm.check_small_batch(emu_lib, 3, name="TCResNet8", width=2.0, seeds=range(100, 103))

@@ -287,3 +287,34 @@ def test_feature_prefetch_matches_sequential(hip_lib):
         torch.cuda.synchronize()
         finals.append((net.params.clone(), net.stats.clone()))
     assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_small_batches_against_live_oracle(hip_lib, batch):
+    """BASELINE.json configs[0] on the HIP path: batch = 1 (and 2) eval forward + a training step against the oracle."""
+    Cm.check_small_batch(hip_lib, batch)
+    Cm.check_small_batch(hip_lib, batch, tag="3010")
+
+
+@pytest.mark.parametrize("name,width,batch", [("TCResNet8", 1.0, 4096), ("TCResNet14", 1.5, 4096), ("TCResNet14", 1.5, 37)])
+def test_staged_sync_bn_api_is_bitwise_the_unstaged_path(hip_lib, name, width, batch):
+    """configs[3]'s per-replica work (TCResNet14-1.5 at 4096 utterances) through the staged sync-BN API, world = 1."""
+    Cm.check_staged_equals_unstaged(hip_lib, name, width, batch)
+
+
+def test_wide_net_training(hip_lib):
+    """width_multiplier 2.0 (Cout = 96 > 80): the shortcut's weight gradient is reduced on the main stream while its BN
+    backward ran on the side stream -- a missing stream dependency shows up as wrong or run-to-run different gradients."""
+    Cm.check_small_batch(hip_lib, 3, name="TCResNet8", width=2.0)
+    Cm.check_small_batch(hip_lib, 3, name="TCResNet14", width=2.0)
+    arch = R.make_tcresnet("TCResNet8", 2.0)
+    p, s = R.init_params(arch, 1)
+    fe = Cm.make_frontend(hip_lib, 640, 320)
+    feat = fe(torch.from_numpy(np.tile(R.synth_waveforms(64, seed=3), (16, 1))).cuda())
+    lab = torch.from_numpy(np.tile(R.synth_labels(64), (16, 1))).cuda()
+    grads = []
+    for _ in range(4):
+        net = Cm.make_net(hip_lib, "TCResNet8", 2.0, fe.n_frames, p, s)
+        net.forward_train(feat, lab, keep_prob=0.5, seed=1)
+        grads.append(net.backward().clone())
+    assert all(torch.equal(grads[0], g) for g in grads[1:])
