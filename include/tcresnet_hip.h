@@ -142,6 +142,18 @@ int tcr_net_forward_infer(const tcr_net* net, const float* params, const float* 
                           int batch, void* workspace, size_t workspace_bytes,
                           float* logits, float* probs, float* ranges, void* stream);
 
+/* Deployable ("frozen") form of the network (factory/audio_nets.py:87-125 build_deployable_model + freeze.py:16-49
+ * convert_variables_to_constants): eval-mode BN folded into per-channel (scale, shift) constants.
+ *   tcr_net_frozen_floats   size of the constant table;
+ *   tcr_net_fold_bn         params + moving stats -> the table (what a frozen export stores next to the conv weights);
+ *   tcr_net_forward_frozen  eval forward from (conv weights in `params`, table): no variable is read, the BN entries of
+ *                           `params` and the moving statistics are not needed.  Bitwise tcr_net_forward_infer. */
+int64_t tcr_net_frozen_floats(const tcr_net* net);
+int tcr_net_fold_bn(const tcr_net* net, const float* params, const float* stats, float* frozen_ss, void* stream);
+int tcr_net_forward_frozen(const tcr_net* net, const float* params, const float* frozen_ss, const float* feat,
+                           int batch, void* workspace, size_t workspace_bytes,
+                           float* logits, float* probs, float* ranges, void* stream);
+
 /* Train-mode forward (is_training=True): batch-statistics BN with moving-stat update
  * (decay, Bessel-corrected variance), inverted dropout after the global pool, softmax,
  * mean cross-entropy (factory/audio_nets.py:161-173).  Saves what backward needs in `workspace`.

@@ -372,10 +372,55 @@ static int forward_infer_fused(const tcr_net& net, const float* params, const fl
 
 }  // namespace tcr
 
+namespace tcr {
+// eval-mode BN of every unit folded to per-channel (scale, shift) at `ss` (layout: unit u at ss_off: scale[c_pad], shift[c_pad])
+static int fold_bn(const tcr_net& net, const float* params, const float* stats, float* ss, hipStream_t s) {
+    BnFoldArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.params = params; f.stats = stats; f.out = ss; f.eps = net.cfg.bn_eps;
+    for (int li : net.units) {
+        const ConvLayer& l = net.layers[li];
+        f.c[f.n] = l.cout; f.c_pad[f.n] = l.c_pad;
+        f.gamma_off[f.n] = l.gamma_off; f.beta_off[f.n] = l.beta_off;
+        f.mean_off[f.n] = l.mean_off; f.var_off[f.n] = l.var_off; f.out_off[f.n] = l.ss_off; f.bias_off[f.n] = -1;
+        ++f.n;
+    }
+    return launch_bn_fold(f, s);
+}
+static int64_t ss_floats(const tcr_net& net) {
+    int64_t n = 0;
+    for (const ConvLayer& l : net.layers) if (l.bn) n += 2 * l.c_pad;
+    return n;
+}
+}  // namespace tcr
+
+static int forward_infer_impl(const tcr_net* net, const float* params, const float* stats, const float* frozen_ss, const float* feat,
+                              int batch, void* workspace, size_t workspace_bytes, float* logits, float* probs, float* ranges, void* stream);
+
 extern "C" int tcr_net_forward_infer(const tcr_net* net, const float* params, const float* stats, const float* feat,
                                      int batch, void* workspace, size_t workspace_bytes,
                                      float* logits, float* probs, float* ranges, void* stream) {
-    TCR_REQUIRE(net && params && stats && feat && workspace && logits && probs, "tcr_net_forward_infer: null argument");
+    TCR_REQUIRE(stats, "tcr_net_forward_infer: null argument");
+    return forward_infer_impl(net, params, stats, nullptr, feat, batch, workspace, workspace_bytes, logits, probs, ranges, stream);
+}
+
+extern "C" int64_t tcr_net_frozen_floats(const tcr_net* net) { return net ? ss_floats(*net) : 0; }
+
+extern "C" int tcr_net_fold_bn(const tcr_net* net, const float* params, const float* stats, float* frozen_ss, void* stream) {
+    TCR_REQUIRE(net && params && stats && frozen_ss, "tcr_net_fold_bn: null argument");
+    return fold_bn(*net, params, stats, frozen_ss, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tcr_net_forward_frozen(const tcr_net* net, const float* params, const float* frozen_ss, const float* feat,
+                                      int batch, void* workspace, size_t workspace_bytes,
+                                      float* logits, float* probs, float* ranges, void* stream) {
+    TCR_REQUIRE(frozen_ss, "tcr_net_forward_frozen: null argument");
+    return forward_infer_impl(net, params, nullptr, frozen_ss, feat, batch, workspace, workspace_bytes, logits, probs, ranges, stream);
+}
+
+static int forward_infer_impl(const tcr_net* net, const float* params, const float* stats, const float* frozen_ss, const float* feat,
+                              int batch, void* workspace, size_t workspace_bytes, float* logits, float* probs, float* ranges, void* stream) {
+    TCR_REQUIRE(net && params && feat && workspace && logits && probs, "tcr_net_forward_infer: null argument");
     TCR_REQUIRE(batch > 0, "tcr_net_forward_infer: batch must be positive (got %d)", batch);
     const Workspace w = carve(*net, batch, false);
     if ((size_t)w.total * sizeof(float) > workspace_bytes) {
@@ -384,19 +429,11 @@ extern "C" int tcr_net_forward_infer(const tcr_net* net, const float* params, co
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* base = static_cast<float*>(workspace);
-    float* ss = base + w.ss;
-
-    BnFoldArgs f;
-    std::memset(&f, 0, sizeof(f));
-    f.params = params; f.stats = stats; f.out = ss; f.eps = net->cfg.bn_eps;
-    for (int li : net->units) {
-        const ConvLayer& l = net->layers[li];
-        f.c[f.n] = l.cout; f.c_pad[f.n] = l.c_pad;
-        f.gamma_off[f.n] = l.gamma_off; f.beta_off[f.n] = l.beta_off;
-        f.mean_off[f.n] = l.mean_off; f.var_off[f.n] = l.var_off; f.out_off[f.n] = l.ss_off; f.bias_off[f.n] = -1;
-        ++f.n;
+    const float* ss = frozen_ss;
+    if (!ss) {
+        TCR_TRY(fold_bn(*net, params, stats, base + w.ss, s));
+        ss = base + w.ss;
     }
-    TCR_TRY(launch_bn_fold(f, s));
 
     if (tune_get(TCR_TUNE_NET_FUSED) != 1) {
         const int rc = forward_infer_fused(*net, params, ss, feat, batch, logits, probs, ranges, s);

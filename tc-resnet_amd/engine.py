@@ -262,6 +262,27 @@ class TCResNet(_Base):
                                                       _ptr(ranges), self._stream()), "tcr_net_forward_infer")
         return (logits, probs, ranges) if want_ranges else (logits, probs)
 
+    def fold_bn(self) -> torch.Tensor:
+        """Eval-mode BN of every layer folded to per-channel (scale, shift) constants: the table a frozen export stores."""
+        ss = torch.zeros(self.lib.tcr_net_frozen_floats(self._h), dtype=torch.float32, device=self.device)
+        self.lib.check(self.lib.tcr_net_fold_bn(self._h, self.params.data_ptr(), self.stats.data_ptr(), ss.data_ptr(), self._stream()),
+                       "tcr_net_fold_bn")
+        return ss
+
+    def forward_frozen(self, feat: torch.Tensor, frozen_ss: torch.Tensor, want_ranges: bool = False):
+        """Eval forward from constants only (conv / fc weights of the arena + the folded table); bitwise forward_infer."""
+        self._check_feat(feat)
+        self._check_tensor(frozen_ss, "frozen table")
+        b = feat.shape[0]
+        ws = self.workspace(b, False)
+        logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
+        probs = torch.empty_like(logits)
+        ranges = torch.empty((b, 2), dtype=torch.float32, device=self.device) if want_ranges else None
+        self.lib.check(self.lib.tcr_net_forward_frozen(self._h, self.params.data_ptr(), frozen_ss.data_ptr(), feat.data_ptr(), b,
+                                                       ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(),
+                                                       _ptr(ranges), self._stream()), "tcr_net_forward_frozen")
+        return (logits, probs, ranges) if want_ranges else (logits, probs)
+
     def forward_train(self, feat: torch.Tensor, labels: torch.Tensor, keep_prob: float = 1.0, seed: int = 0,
                       sample_offset: int = 0, global_batch: Optional[int] = None, label_smoothing: float = 0.0,
                       sync_hook=None):

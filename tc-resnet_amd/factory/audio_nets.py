@@ -60,7 +60,37 @@ class AudioNetModel(TFModel):
         self.input_preprocessors_for_tflite = [self._preprocessor]
 
     def build_deployable_model(self, include_preprocess=True):
-        raise NotImplementedError("frozen-graph / TFLite export is outside the MI355X hot path (SURVEY 8(f) #3)")
+        """Reference :87-125.  Returns (input_tensors, output_tensor): specs of the deploy graph's placeholder(s) and of the
+        node named --output_name.  include_preprocess=True: waveform `input/audio/before_preprocessing`
+        [input_batch_size, samples, 1] through the DEPLOY-path MFCC (for_deploy=True); False: features `input`
+        [1, height, width, channels].  The graph is built in eval mode on a zero input (this is what creates the variables);
+        `freeze()` then converts the current variables to constants (deploy.FrozenModel)."""
+        from ..deploy import TensorSpec
+        dev = runtime.default_device() or ("cuda" if runtime.default_lib() is None or runtime.default_lib().kind == "hip" else "cpu")
+        self.is_training = False
+        self.labels = None
+        if include_preprocess:
+            desired_samples = int(self.args.sample_rate * self.args.clip_duration_ms / 1000)
+            spec = TensorSpec("input/audio/before_preprocessing", (int(self.args.input_batch_size), desired_samples, 1))
+            self._audio_original = torch.zeros(spec.shape, dtype=torch.float32, device=dev)
+            self.preprocess_input(for_deploy=True)
+            inputs = self._audio
+        else:
+            self.log.info("Build graph which excludes preprocessing for freezing!")
+            assert self.args.height > 0 and self.args.width > 0 and self.args.channels > 0
+            spec = TensorSpec("input", (1, int(self.args.height), int(self.args.width), int(self.args.channels)))
+            self._preprocessor = preprocessor_factory.factory("no_preprocessing", "input/audio/preprocessing", "input/audio/preprocessed")
+            inputs = self._preprocessor.preprocess(torch.zeros(spec.shape, dtype=torch.float32, device=dev))
+            self._audio = inputs
+        _, _, out, _ = self.build_output(inputs, False, self.args.output_name)
+        self._deploy = (bool(include_preprocess), [spec], TensorSpec(self.args.output_name, tuple(int(d) for d in out.shape)))
+        return self._deploy[1], self._deploy[2]
+
+    def freeze(self):
+        """graph_util.convert_variables_to_constants (freeze.py:36-40) for the deployable model built last."""
+        from ..deploy import export_frozen
+        include_preprocess, inputs, output = self._deploy
+        return export_frozen(self, include_preprocess, inputs, output)
 
     @property
     def model_loss(self):
@@ -84,7 +114,7 @@ class AudioNetModel(TFModel):
 
     def build_output(self, inputs, is_training, output_name):
         logits, endpoints = self.build_inference(inputs, is_training=is_training)
-        return inputs, logits, self._probs, endpoints
+        return inputs, logits, self._probs, endpoints          # self._probs: slim.softmax(logits), the node named output_name
 
     def build_inference(self, inputs, is_training=True):
         raise NotImplementedError

@@ -269,6 +269,54 @@ def test_model_build_matches_oracle(rt):
         preprocessor_factory.factory("log_mel_spectrogram", "s", "n").preprocess(wavs[:1], 640, 320, True, **vars(args))
 
 
+def test_deployable_model_and_freeze(rt, tmp_path):
+    """build_deployable_model (both variants) + freeze.py: variables -> constants, `<checkpoint>.pb`, reloaded and run."""
+    from tcresnet_amd import deploy, freeze, train_audio
+    from tcresnet_amd.audio_nets import tc_resnet
+    from tcresnet_amd.factory import audio_nets
+    dev = Cm.device_of(rt)
+    fx = Cm.load("tcresnet8_1.0_4020.npz")
+    arch, p, s = Cm.fixture_params(fx, "TCResNet8", 1.0)
+    # a checkpoint holding the fixture's variables, as a training run would leave it
+    from tcresnet_amd.common import tf_bundle
+    sd = {k: np.asarray(v, np.float32).reshape((v.shape[0], 1) + v.shape[1:]) if k.endswith("/weights") else np.asarray(v, np.float32) for k, v in {**p, **s}.items()}
+    tf_bundle.write_checkpoint(str(tmp_path / "TCResNet8Model-30000"), sd)
+    cmd = (f"--checkpoint_path {tmp_path / 'TCResNet8Model-30000'} --output_name output/softmax --num_classes 12 --preprocess_method no_preprocessing "
+           "--height 49 --width 40 --channels 1 --window_size_ms 40 --window_stride_ms 20 --num_mfccs 40 TCResNet8Model --width_multiplier 1.0")
+    out = freeze.freeze(freeze.parse_arguments(cmd.split()))
+    assert out == str(tmp_path / "TCResNet8Model-30000.pb")
+    tc_resnet.reset_engines()
+    frozen = deploy.FrozenModel.load(out, lib=rt, device=dev)
+    assert [(t.name, t.shape) for t in frozen.input_tensors] == [("input", (1, 49, 40, 1))] and frozen.output_tensor.name == "output/softmax"
+    assert "TCResNet8/conv0/BatchNorm/gamma" not in frozen.constants and frozen.constants["TCResNet8/conv0/weights"].shape == (3, 1, 40, 16)
+    feats = torch.from_numpy(fx["mfcc"].astype(np.float32)).unsqueeze(-1).to(dev)           # [B, 49, 40, 1]
+    probs = frozen(feats).cpu().numpy()
+    assert np.abs(probs - fx["eval_probs"]).max() < 1e-5 and np.array_equal(probs.argmax(1), fx["eval_probs"].argmax(1))
+    # bitwise the variable-reading eval path
+    net = Cm.make_net(rt, "TCResNet8", 1.0, 49, p, s)
+    assert torch.equal(frozen(feats), net.forward_infer(T.features_to_planar(feats, lib=rt))[1])
+    # include_preprocess=True: waveform placeholder [input_batch_size, 16000, 1] through the DEPLOY-path MFCC
+    args = _model_args(input_batch_size=2)
+    model = audio_nets.TCResNet8Model(args)
+    inputs, output = model.build_deployable_model(include_preprocess=True)
+    assert (inputs[0].name, inputs[0].shape) == ("input/audio/before_preprocessing", (2, 16000, 1)) and output.shape == (2, 12)
+    model.engine.load_state_dict({**p, **s})
+    fz = model.freeze()
+    fz.save(str(tmp_path / "with_pre.pb"))
+    fz2 = deploy.FrozenModel.load(str(tmp_path / "with_pre.pb"), lib=rt, device=dev)
+    assert fz2.meta["frontend"]["method"] == "mfcc_deploy"
+    wav = torch.from_numpy(fx["wav"][:2]).unsqueeze(-1).to(dev)
+    ref = R.forward(arch, p, s, R.mfcc_deploy(fx["wav"][:2], R.FRONTEND_4020), False)
+    assert np.abs(fz2(wav).cpu().numpy() - ref["probs"]).max() < 1e-5
+    # DS-CNN freezes too
+    args10 = _model_args(num_mfccs=10, weight_decay=0.0, height=49, width=10, channels=1)
+    ds = audio_nets.DSCNNSModel(args10)
+    ds.build_deployable_model(include_preprocess=False)
+    f3 = ds.freeze()
+    x = torch.randn(3, 49, 10, 1, device=dev)
+    assert torch.equal(f3(x), ds.engine.forward_infer(T.features_to_planar(x, lib=rt))[1])
+
+
 def test_lr_schedule():
     from tcresnet_amd.helper.trainer import piecewise_constant
     assert [piecewise_constant(s, [10000, 20000], [0.1, 0.01, 0.001]) for s in (0, 10000, 10001, 20000, 20001)] == [0.1, 0.1, 0.01, 0.01, 0.001]
