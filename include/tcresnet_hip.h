@@ -237,6 +237,51 @@ int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, const float* f
                        void* workspace, size_t workspace_bytes, float* grads, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Generic 2-D layer graph: the other model families behind the factory        */
+/*   ResNet2D8 / ResNet2D8Pool (audio_nets/tc_resnet.py:14-15,23-24,73-99),                       */
+/*   Res8 / Res8Narrow / Res15 / Res15Narrow (audio_nets/res.py:6-123),                           */
+/*   KWSModel architectures (audio_nets/kws.py:15-63).                                            */
+/* ------------------------------------------------------------------------------------------ */
+/* The host describes the topology node by node, as the reference's Python builds its TF graph; every builder returns the
+ * node id (>= 0) or a negative tcr_status.  Input id -1 is the network input [batch][c][h*w + 2*TCR_HALO] (planar, the
+ * plane at offset TCR_HALO).  Variables live in one trainable arena (all variables whose TF name lacks "BatchNorm" first:
+ * the L2-regularised set of factory/audio_nets.py:175-180) and one moving-statistics arena, under the names given here. */
+typedef struct tcr_g2d tcr_g2d;
+int tcr_g2d_create(const char* scope, int h, int w, int c, tcr_g2d** out);
+void tcr_g2d_destroy(tcr_g2d* g);
+/* slim.conv2d / tf.nn.conv2d (+ bias, + ReLU): kernel kh x kw, stride, dilation `rate` (audio_nets/res.py:11-16), SAME
+ * (valid_padding = 0) or VALID padding; weights HWIO under `weights_name`, bias under `biases_name` (NULL / "": none).
+ * A fully connected layer over a flattened [h][w][c] activation is the VALID conv with kh = h, kw = w. */
+int tcr_g2d_conv(tcr_g2d* g, int in, int kh, int kw, int cout, int sh, int sw, int dh, int dw, int valid_padding, int relu,
+                 const char* weights_name, const char* biases_name);
+/* slim.batch_norm(fused): optional beta (center) / gamma (scale), optional ReLU; variables `<prefix>/gamma|beta|moving_*`. */
+int tcr_g2d_batch_norm(tcr_g2d* g, int in, int center, int scale, int relu, float decay, float eps, const char* prefix);
+/* slim.avg_pool2d / tf.nn.max_pool; kh <= 0: the window is the whole plane (global pool). */
+int tcr_g2d_pool(tcr_g2d* g, int in, int is_max, int kh, int kw, int sh, int sw, int valid_padding);
+int tcr_g2d_add(tcr_g2d* g, int a, int b, int relu);                 /* net += layer_in [; relu] */
+int tcr_g2d_dropout(tcr_g2d* g, int in, float keep_prob);            /* tf.nn.dropout / slim.dropout; identity in eval mode */
+int tcr_g2d_node_shape(const tcr_g2d* g, int node, int* c, int* h, int* w);
+int tcr_g2d_finalize(tcr_g2d* g, int logits_node);                   /* logits node: [num_classes] x 1 x 1 */
+int64_t tcr_g2d_param_floats(const tcr_g2d* g);
+int64_t tcr_g2d_decay_floats(const tcr_g2d* g);
+int64_t tcr_g2d_stat_floats(const tcr_g2d* g);
+int tcr_g2d_num_tensors(const tcr_g2d* g);
+int tcr_g2d_num_classes(const tcr_g2d* g);
+int tcr_g2d_tensor_info(const tcr_g2d* g, int index, tcr_tensor_info* out);
+size_t tcr_g2d_workspace_bytes(const tcr_g2d* g, int batch, int train);
+/* front-end output [batch][f][tcr_padded_len(t)] -> the [t x f] single-channel plane these networks read ([N, T, F, 1]) */
+int tcr_g2d_input_from_features(const float* feat, int batch, int t, int f, float* plane, void* stream);
+/* eval forward + softmax; train forward (batch statistics, dropout keyed by (seed, node, sample), mean cross-entropy:
+ * arguments as tcr_net_forward_train); backward of the model loss wrt every trainable (same seed / sample_offset). */
+int tcr_g2d_forward_infer(const tcr_g2d* g, const float* params, const float* stats, const float* x, int batch,
+                          void* workspace, size_t workspace_bytes, float* logits, float* probs, void* stream);
+int tcr_g2d_forward_train(const tcr_g2d* g, const float* params, float* stats, const float* x, const float* labels, int batch,
+                          int global_batch, uint64_t seed, int64_t sample_offset, float label_smoothing, void* workspace,
+                          size_t workspace_bytes, float* logits, float* probs, float* loss_out, void* stream);
+int tcr_g2d_backward(const tcr_g2d* g, const float* params, const float* x, int batch, uint64_t seed, int64_t sample_offset,
+                     void* workspace, size_t workspace_bytes, float* grads, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Optimiser (helper/trainer.py:171-197) and L2 (factory/audio_nets.py:175-182)                */
 /* ------------------------------------------------------------------------------------------ */
 /* tf.train.MomentumOptimizer, use_nesterov=False:  g' = g*grad_scale + wd*w (first n_decay floats)

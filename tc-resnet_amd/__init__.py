@@ -6,6 +6,6 @@ The directory name carries a hyphen (it is the name the build was given); import
 """
 from . import _lib
 from ._lib import TcrError
-from .engine import DSCNN, Frontend, TCResNet, features_to_planar
+from .engine import DSCNN, Frontend, Graph2D, TCResNet, features_to_planar
 
-__all__ = ["_lib", "TcrError", "Frontend", "TCResNet", "DSCNN", "features_to_planar"]
+__all__ = ["_lib", "TcrError", "Frontend", "TCResNet", "DSCNN", "Graph2D", "features_to_planar"]

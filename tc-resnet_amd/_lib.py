@@ -94,6 +94,28 @@ _PROTOTYPES = {
     "tcr_dscnn_train_workspace_bytes": (C.c_size_t, [_P, C.c_int]),
     "tcr_dscnn_forward_train": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, C.c_size_t, _P, _P, _P, _P]),
     "tcr_dscnn_backward": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P, _P]),
+    "tcr_g2d_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "tcr_g2d_destroy": (None, [_P]),
+    "tcr_g2d_conv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                               C.c_char_p]),
+    "tcr_g2d_batch_norm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_char_p]),
+    "tcr_g2d_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tcr_g2d_add": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "tcr_g2d_dropout": (C.c_int, [_P, C.c_int, C.c_float]),
+    "tcr_g2d_node_shape": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tcr_g2d_finalize": (C.c_int, [_P, C.c_int]),
+    "tcr_g2d_param_floats": (C.c_int64, [_P]),
+    "tcr_g2d_decay_floats": (C.c_int64, [_P]),
+    "tcr_g2d_stat_floats": (C.c_int64, [_P]),
+    "tcr_g2d_num_tensors": (C.c_int, [_P]),
+    "tcr_g2d_num_classes": (C.c_int, [_P]),
+    "tcr_g2d_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(TensorInfo)]),
+    "tcr_g2d_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
+    "tcr_g2d_input_from_features": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "tcr_g2d_forward_infer": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P, _P, _P]),
+    "tcr_g2d_forward_train": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_float, _P, C.c_size_t, _P, _P, _P,
+                                        _P]),
+    "tcr_g2d_backward": (C.c_int, [_P, _P, _P, C.c_int, C.c_uint64, C.c_int64, _P, C.c_size_t, _P, _P]),
     "tcr_sgd_momentum_step": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "tcr_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int64, C.c_float, C.c_float, _P]),

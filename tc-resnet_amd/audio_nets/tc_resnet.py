@@ -89,3 +89,66 @@ def TCResNet8(inputs, num_classes, width_multiplier=1.0, scope="TCResNet8", plan
 
 def TCResNet14(inputs, num_classes, width_multiplier=1.0, scope="TCResNet14", planar=None):
     return tc_resnet(inputs, num_classes, 6, tcresnet_channels([16, 24, 24, 32, 32, 48, 48], width_multiplier), scope, planar)
+
+
+# ---- the 2-D ablations (reference :14-15,23-24,73-99): 3 x 3 convolutions over the [L, F] plane -------------------------------
+def build_resnet2d(g, num_classes, n_channels, scope, keep_prob, pool=None):
+    """tc_resnet(..., debug_2d=True[, pool]) as Graph2D nodes; returns the logits node."""
+    def conv_bn(inp, cout, kernel, stride, name, relu):
+        net = g.conv(inp, kernel, cout, f"{scope}/{name}/weights", stride=stride)
+        return g.batch_norm(net, f"{scope}/{name}/BatchNorm", center=True, scale=True, relu=relu, decay=0.997, eps=0.001)
+
+    net = conv_bn(-1, n_channels[0], 3, 1, "conv0", True)
+    if pool is not None:
+        net = g.pool(net, "avg", tuple(pool[0]), stride=pool[1], padding="VALID")       # scope avg_pool_0
+    c = n_channels[0]
+    for i, n in enumerate(n_channels[1:]):
+        if n != c:
+            stride = 2
+            layer_in = conv_bn(net, n, 1, 2, f"block{i}/down", True)
+        else:
+            stride, layer_in = 1, net
+        h = conv_bn(net, n, 3, stride, f"block{i}/conv{i}_0", True)
+        h = conv_bn(h, n, 3, 1, f"block{i}/conv{i}_1", False)
+        net = g.add(h, layer_in, relu=True)
+        c = n
+    net = g.pool(net, "avg", None)
+    net = g.dropout(net, keep_prob)
+    logits = g.conv(net, 1, num_classes, f"{scope}/fc/weights")
+    g.conv(net, 1, 2, f"{scope}/fc2/weights")           # endpoints["ranges"]: a variable of the graph, outside the loss
+    return logits
+
+
+def _resnet2d_channels(f, width_multiplier):
+    n = tcresnet_channels([16, 24, 32, 48], width_multiplier)
+    c1, c2 = n[0:2]
+    n[0] = int((3 * f * c1 + 10 * c1 * c2) / (9 + 10 * c2))       # reference :79-82: same MACs as the temporal first block
+    return n
+
+
+def get_engine_2d(scope, h, w, num_classes, width_multiplier, keep_prob, pool):
+    from ..engine import Graph2D
+    key = (scope, h, w, num_classes, float(width_multiplier), float(keep_prob), id(runtime.default_lib()))
+    eng = _engines.get(key)
+    if eng is None:
+        eng = Graph2D(scope, h, w, 1, lib=runtime.default_lib(), device=runtime.default_device())
+        eng.finalize(build_resnet2d(eng, num_classes, _resnet2d_channels(w, width_multiplier), scope, keep_prob, pool))
+        _engines[key] = eng
+    return eng
+
+
+def _run_2d(scope, inputs, num_classes, width_multiplier, planar, pool):
+    sc = current_scope()
+    eng = get_engine_2d(scope, int(inputs.shape[1]), int(inputs.shape[2]), num_classes, width_multiplier, sc["keep_prob"], pool)
+    if sc["is_training"]:
+        raise RuntimeError("train-mode graphs are driven by AudioNetModel.build/train_step (they need labels)")
+    logits, probs = eng.forward_infer(planar if planar is not None else _planar_of(inputs))
+    return logits, {"softmax": probs, "engine": eng}
+
+
+def ResNet2D8(inputs, num_classes, width_multiplier=1.0, scope="ResNet2D8", planar=None):
+    return _run_2d(scope, inputs, num_classes, width_multiplier, planar, None)
+
+
+def ResNet2D8Pool(inputs, num_classes, width_multiplier=1.0, scope="ResNet2D8Pool", planar=None):
+    return _run_2d(scope, inputs, num_classes, width_multiplier, planar, ([4, 4], 4))

@@ -273,6 +273,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
         if (a.m1 && !(a.m1[i] > 0.f)) dz = 0.f;
         if (a.m2 && !(a.m2[i] > 0.f)) dz = 0.f;
         v = a.k1[c] * (dz - a.k2[c] - (a.y[i] - a.mean[c]) * a.k3[c]);
+        if (a.accumulate) v += a.dy[i];
+    } else if (a.accumulate) {
+        return;
     }
     a.dy[i] = v;
 }

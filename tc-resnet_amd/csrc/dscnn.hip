@@ -906,6 +906,7 @@ extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, con
         f.c = u.c; f.count = (double)batch * (double)u.P; f.grad_scale = 1.0f;
         TCR_TRY(launch_bn_bwd_finalize(f, s));
         BnBwdApplyArgs ap;
+        ap.accumulate = 0;
         ap.y = raw; ap.da = da; ap.m1 = act; ap.m2 = nullptr; ap.mean = base + w.mean[ui];
         ap.k1 = f.k1; ap.k2 = f.k2; ap.k3 = f.k3; ap.dy = dz;
         ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.bcast = bcast;

@@ -223,6 +223,7 @@ struct BnBwdApplyArgs {
     int64_t total;
     int c, t, tp, bcast;
     float inv_tp;           // (set by the launcher)
+    int accumulate;         // dy += ... (interior positions only) instead of dy = ...: gradient buffers with several producers (net2d)
 };
 
 int launch_bn_fold(const BnFoldArgs& a, hipStream_t s);

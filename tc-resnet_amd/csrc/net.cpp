@@ -761,6 +761,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
         f.grad_scale = (float)((double)c.batch / c.bn_batch);
         TCR_TRY(launch_bn_bwd_finalize(f, bn_stream));
         BnBwdApplyArgs a;
+        a.accumulate = 0;
         a.y = c.base + c.w.raw[u.li]; a.da = u.da; a.m1 = u.m1; a.m2 = u.m2; a.mean = c.base + c.w.mean[u.li];
         a.k1 = f.k1; a.k2 = f.k2; a.k3 = f.k3; a.dy = dy;
         a.total = (int64_t)c.batch * l.cout * tp; a.c = l.cout; a.t = l.tout; a.tp = tp; a.bcast = u.da_bcast;

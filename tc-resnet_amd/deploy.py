@@ -20,7 +20,7 @@ import torch
 
 from . import runtime
 from ._lib import HALO
-from .engine import DSCNN, Frontend, TCResNet, features_to_planar
+from .engine import DSCNN, Frontend, Graph2D, TCResNet, features_to_planar
 
 FORMAT = "tcresnet_amd.frozen/1"
 
@@ -52,6 +52,18 @@ class FrozenModel:
             self.frozen_ss = torch.from_numpy(np.ascontiguousarray(constants["__folded_batch_norm__"])).to(self.engine.device)
         elif fam == "dscnn":
             self.engine = DSCNN(meta["size"], meta["height"], meta["width"], meta["num_classes"], lib=lib, device=device)
+            self.engine.load_state_dict(constants)
+            self.frozen_ss = None
+        elif fam == "graph2d":
+            import argparse
+            from .factory import audio_nets
+            saved = runtime.default_lib(), runtime.default_device()
+            runtime.set_default(lib, device)
+            try:
+                model = getattr(audio_nets, meta["model"])(argparse.Namespace(**meta["args"]))
+                self.engine = model._engine_for(torch.empty((1, meta["height"], meta["width"], 1)))
+            finally:
+                runtime.set_default(*saved)
             self.engine.load_state_dict(constants)
             self.frozen_ss = None
         else:
@@ -113,6 +125,9 @@ def export_frozen(model, include_preprocess: bool, inputs: List[TensorSpec], out
         consts["__folded_batch_norm__"] = eng.fold_bn().cpu().numpy()
     elif isinstance(eng, DSCNN):
         meta.update(family="dscnn", size=eng.size)
+        consts = dict(sd)
+    elif isinstance(eng, Graph2D):
+        meta.update(family="graph2d", args={k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool)) or v is None})
         consts = dict(sd)
     else:
         raise NotImplementedError(f"frozen export of {type(eng).__name__}")

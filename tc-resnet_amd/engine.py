@@ -526,3 +526,199 @@ class DSCNN(_Base):
         self.lib.check(self.lib.tcr_l2_loss(self.params.data_ptr(), self.n_decay, float(weight_decay), out.data_ptr(),
                                             self._stream()), "tcr_l2_loss")
         return out[0]
+
+
+class Graph2D(_Base):
+    """Generic 2-D layer graph on the HIP kernels (C ABI tcr_g2d_*): the remaining model families of the reference's factory
+    -- ResNet2D8(/Pool), Res8/15(/Narrow), KWSModel (audio_nets/tc_resnet.py:73-99, res.py:6-123, kws.py:15-63).  The topology
+    is described node by node by the builders in tcresnet_amd/audio_nets, the way the reference's Python builds its TF graph;
+    variables are created under the TF names given there.  Input: the [T x F] single-channel feature plane ([N, T, F, 1])."""
+
+    def __init__(self, scope: str, h: int, w: int, c: int = 1, lib: Optional[_lib.Library] = None, device=None):
+        self.lib, self.device = _resolve(lib, device)
+        handle = C.c_void_p()
+        self.lib.check(self.lib.tcr_g2d_create(scope.encode(), int(h), int(w), int(c), C.byref(handle)), "tcr_g2d_create")
+        self._h, self.scope = handle, scope
+        self.h_in, self.w_in, self.c_in = int(h), int(w), int(c)
+        self.initializers: Dict[str, object] = {}           # variable name -> "xavier" | ("truncated_normal", stddev) | "zeros"
+        self.dropout_nodes: List[int] = []                  # node ids of the dropout layers (each mask is keyed by its node id)
+        self.finalized = False
+        self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
+        self.slots: Dict[str, torch.Tensor] = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.tcr_g2d_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- topology ---------------------------------------------------------------------------------------------------
+    def _node(self, rc: int, what: str) -> int:
+        if rc < 0:
+            self.lib.check(rc, what)
+        return rc
+
+    def conv(self, inp: int, kernel, cout: int, weights_name: str, stride=(1, 1), rate=(1, 1), padding: str = "SAME", relu: bool = False,
+             biases_name: Optional[str] = None, init="xavier") -> int:
+        kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
+        sh, sw = (stride, stride) if isinstance(stride, int) else stride
+        dh, dw = (rate, rate) if isinstance(rate, int) else rate
+        if padding not in ("SAME", "VALID"):
+            raise ValueError(padding)
+        self.initializers[weights_name] = init
+        if biases_name:
+            self.initializers[biases_name] = "zeros"
+        return self._node(self.lib.tcr_g2d_conv(self._h, inp, kh, kw, int(cout), sh, sw, dh, dw, int(padding == "VALID"), int(relu),
+                                                weights_name.encode(), (biases_name or "").encode()), "tcr_g2d_conv")
+
+    def batch_norm(self, inp: int, prefix: str, center: bool = True, scale: bool = True, relu: bool = False, decay: float = 0.997,
+                   eps: float = 0.001) -> int:
+        return self._node(self.lib.tcr_g2d_batch_norm(self._h, inp, int(center), int(scale), int(relu), float(decay), float(eps),
+                                                      prefix.encode()), "tcr_g2d_batch_norm")
+
+    def pool(self, inp: int, kind: str, kernel=None, stride=(1, 1), padding: str = "VALID") -> int:
+        kh, kw = (0, 0) if kernel is None else ((kernel, kernel) if isinstance(kernel, int) else kernel)
+        sh, sw = (stride, stride) if isinstance(stride, int) else stride
+        return self._node(self.lib.tcr_g2d_pool(self._h, inp, int(kind == "max"), kh, kw, sh, sw, int(padding == "VALID")), "tcr_g2d_pool")
+
+    def add(self, a: int, b: int, relu: bool = False) -> int:
+        return self._node(self.lib.tcr_g2d_add(self._h, a, b, int(relu)), "tcr_g2d_add")
+
+    def dropout(self, inp: int, keep_prob: float) -> int:
+        node = self._node(self.lib.tcr_g2d_dropout(self._h, inp, float(keep_prob)), "tcr_g2d_dropout")
+        self.dropout_nodes.append(node)
+        return node
+
+    def shape(self, node: int) -> Tuple[int, int, int]:
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        self.lib.check(self.lib.tcr_g2d_node_shape(self._h, node, C.byref(c), C.byref(h), C.byref(w)), "tcr_g2d_node_shape")
+        return c.value, h.value, w.value
+
+    def finalize(self, logits: int):
+        self.lib.check(self.lib.tcr_g2d_finalize(self._h, logits), "tcr_g2d_finalize")
+        self.finalized = True
+        self.num_classes = self.lib.tcr_g2d_num_classes(self._h)
+        self.n_param = self.lib.tcr_g2d_param_floats(self._h)
+        self.n_decay = self.lib.tcr_g2d_decay_floats(self._h)
+        self.n_stat = self.lib.tcr_g2d_stat_floats(self._h)
+        self.tensors: Dict[str, TensorInfo] = {}
+        for i in range(self.lib.tcr_g2d_num_tensors(self._h)):
+            ti = TensorInfo()
+            self.lib.check(self.lib.tcr_g2d_tensor_info(self._h, i, C.byref(ti)), "tcr_g2d_tensor_info")
+            self.tensors[ti.name.decode()] = ti
+        self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.init_variables(0)
+
+    # ---- variables ---------------------------------------------------------------------------------------------------
+    _view = TCResNet._view
+    grad_view = TCResNet.grad_view
+    trainable_names = TCResNet.trainable_names
+    total_params = TCResNet.total_params
+    state_dict = TCResNet.state_dict
+    _slot = TCResNet._slot
+    slot_arena = TCResNet.slot_arena
+    ema_init = TCResNet.ema_init
+    ema_step = TCResNet.ema_step
+    adam_step = TCResNet.adam_step
+    sgd_momentum_step = TCResNet.sgd_momentum_step
+    rmsprop_step = TCResNet.rmsprop_step
+    l2_loss = TCResNet.l2_loss
+
+    def load_state_dict(self, sd: Dict[str, np.ndarray], strict: bool = True):
+        for n, ti in self.tensors.items():
+            if n not in sd:
+                if strict:
+                    raise KeyError(n)
+                continue
+            v = torch.as_tensor(np.asarray(sd[n], dtype=np.float32))
+            shape = tuple(ti.shape[i] for i in range(ti.rank))
+            if v.numel() != int(ti.size):
+                raise TcrError(f"{n}: shape {tuple(v.shape)} != {shape}")
+            self._view(n).copy_(v.reshape(shape).to(self.device))       # (a [K, N] matmul weight IS the [h, w, c, N] conv weight)
+
+    def init_variables(self, seed: int = 0):
+        """Weights by the initializer the reference gives each variable (xavier uniform under the slim arg scopes,
+        truncated normal in kws.py), biases / beta / moving_mean 0, gamma / moving_variance 1."""
+        gen = torch.Generator().manual_seed(int(seed))
+        for n, ti in self.tensors.items():
+            shape = tuple(ti.shape[i] for i in range(ti.rank))
+            if ti.kind == 0:
+                init = self.initializers.get(n, "xavier")
+                if init == "xavier":
+                    kh, kw, cin, cout = shape
+                    lim = math.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+                    w = (torch.rand(shape, generator=gen, dtype=torch.float32) * 2.0 - 1.0) * lim
+                else:                       # ("truncated_normal", stddev): redraw beyond two standard deviations
+                    std = float(init[1])
+                    w = torch.randn(shape, generator=gen, dtype=torch.float32)
+                    bad = w.abs() > 2.0
+                    while bool(bad.any()):
+                        w[bad] = torch.randn(int(bad.sum()), generator=gen, dtype=torch.float32)
+                        bad = w.abs() > 2.0
+                    w = w * std
+                self._view(n).copy_(w.to(self.device))
+            elif ti.kind in (1, 4):
+                self._view(n).fill_(1.0)
+            else:
+                self._view(n).zero_()
+
+    # ---- compute ------------------------------------------------------------------------------------------------------
+    def workspace(self, batch: int, train: bool) -> torch.Tensor:
+        key = (int(batch), int(train))
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.empty(self.lib.tcr_g2d_workspace_bytes(self._h, batch, int(train)) // 4, dtype=torch.float32, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def input_from_features(self, feat: torch.Tensor) -> torch.Tensor:
+        """Front-end planar features [B, F, T + 2*HALO] -> the network's input plane [B, 1, T*F + 2*HALO] ([N, T, F, 1])."""
+        self._check_tensor(feat, "features")
+        b = feat.shape[0]
+        if self.c_in != 1 or tuple(feat.shape[1:]) != (self.w_in, padded_len(self.h_in)):
+            raise TcrError(f"features must be planar [B, {self.w_in}, {padded_len(self.h_in)}], got {tuple(feat.shape)}")
+        x = torch.empty((b, 1, self.h_in * self.w_in + 2 * HALO), dtype=torch.float32, device=self.device)
+        self.lib.check(self.lib.tcr_g2d_input_from_features(feat.data_ptr(), b, self.h_in, self.w_in, x.data_ptr(), self._stream()),
+                       "tcr_g2d_input_from_features")
+        return x
+
+    def forward_infer(self, feat: torch.Tensor):
+        x = self.input_from_features(feat)
+        b = x.shape[0]
+        ws = self.workspace(b, False)
+        logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
+        probs = torch.empty_like(logits)
+        self.lib.check(self.lib.tcr_g2d_forward_infer(self._h, self.params.data_ptr(), self.stats.data_ptr(), x.data_ptr(), b, ws.data_ptr(),
+                                                      ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), self._stream()), "tcr_g2d_forward_infer")
+        return logits, probs
+
+    def forward_train(self, feat: torch.Tensor, labels: torch.Tensor, keep_prob: float = 1.0, seed: int = 0, sample_offset: int = 0,
+                      global_batch: Optional[int] = None, label_smoothing: float = 0.0, sync_hook=None):
+        """Train-mode forward; returns (logits, probs, loss_sum) like TCResNet.forward_train.  Dropout probabilities belong to the
+        graph (they are fixed where the reference builds it), so `keep_prob` is not read here."""
+        if sync_hook is not None:
+            raise NotImplementedError("cross-replica BN statistics are built for TC-ResNet only; these replicas use per-replica BN")
+        self._check_tensor(labels, "labels")
+        x = self.input_from_features(feat)
+        b = x.shape[0]
+        ws = self.workspace(b, True)
+        logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
+        probs = torch.empty_like(logits)
+        loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self.lib.check(self.lib.tcr_g2d_forward_train(self._h, self.params.data_ptr(), self.stats.data_ptr(), x.data_ptr(), labels.data_ptr(), b,
+                                                      int(global_batch or b), int(seed), int(sample_offset), float(label_smoothing),
+                                                      ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), loss.data_ptr(),
+                                                      self._stream()), "tcr_g2d_forward_train")
+        self._last = (x, b, int(seed), int(sample_offset))
+        return logits, probs, loss[0]
+
+    def backward(self) -> torch.Tensor:
+        x, b, seed, off = self._last
+        ws = self.workspace(b, True)
+        self.lib.check(self.lib.tcr_g2d_backward(self._h, self.params.data_ptr(), x.data_ptr(), b, seed, off, ws.data_ptr(), ws.numel() * 4,
+                                                 self.grads.data_ptr(), self._stream()), "tcr_g2d_backward")
+        return self.grads

@@ -15,7 +15,7 @@ from typing import Dict, Tuple
 import torch
 
 from .. import runtime
-from ..audio_nets import tc_resnet
+from ..audio_nets import kws, res, tc_resnet
 from ..datasets import preprocessor_factory
 from ..common import tf_utils
 from ..parallel import DataParallel
@@ -280,22 +280,101 @@ class DSCNNLModel(_DSCNNModel):
     size = "L"
 
 
-def _not_built(name, ref):
-    class _Stub(AudioNetModel):
-        @staticmethod
-        def add_arguments(parser):
-            parser.add_argument("--weight_decay", default=0.0, type=float)
+class _GraphModel(AudioNetModel):
+    """Model classes whose network runs on the generic 2-D graph engine (engine.Graph2D)."""
 
-        def build_inference(self, inputs, is_training=True):
-            raise NotImplementedError(f"{name} ({ref}) is outside the TC-ResNet hot path built so far (SURVEY 8(f))")
-    _Stub.__name__ = name
-    return _Stub
+    def _engine_for(self, inputs):
+        raise NotImplementedError
+
+    def build_inference(self, inputs, is_training=True):
+        eng = self._engine_for(inputs)
+        self.engine = eng
+        planar = self._preprocessor.planar
+        self._loss_sum = None
+        if is_training:     # read-only build of the training graph (see _TCResNetModel.build_inference)
+            saved = eng.stats.clone()
+            logits, probs, loss_sum = eng.forward_train(planar, self.labels, seed=0, label_smoothing=float(getattr(self.args, "label_smoothing", 0.0)))
+            eng.stats.copy_(saved)
+            self._loss_sum, self._mean_loss = loss_sum, loss_sum / float(planar.shape[0])
+        else:
+            logits, probs = eng.forward_infer(planar)
+        self._probs = probs
+        return logits, {"engine": eng}
 
 
-KWSModel = _not_built("KWSModel", "audio_nets/kws.py")
-Res8Model = _not_built("Res8Model", "audio_nets/res.py")
-Res8NarrowModel = _not_built("Res8NarrowModel", "audio_nets/res.py")
-Res15Model = _not_built("Res15Model", "audio_nets/res.py")
-Res15NarrowModel = _not_built("Res15NarrowModel", "audio_nets/res.py")
-ResNet2D8Model = _not_built("ResNet2D8Model", "audio_nets/tc_resnet.py:73-84")
-ResNet2D8PoolModel = _not_built("ResNet2D8PoolModel", "audio_nets/tc_resnet.py:88-99")
+class GoogleKWS:
+    def __init__(self, args):
+        self.args = args
+
+    def build_model_settings(self, inputs):
+        """Reference :194-202."""
+        t, f = int(inputs.shape[1]), int(inputs.shape[2])
+        return {"fingerprint_width": f, "spectrogram_length": t, "fingerprint_size": t * f, "label_count": self.args.num_classes,
+                "sample_rate": self.args.sample_rate, "window_stride_samples": int(self.args.sample_rate * self.args.window_stride_ms / 1000)}
+
+
+class KWSModel(_GraphModel):
+    """factory/audio_nets.py:205-225 -> audio_nets/kws.py; `--architecture` as in the reference (low_latency_svdf is refused)."""
+
+    def __init__(self, args, dataset=None):
+        super().__init__(args, dataset)
+        self.google_kws = GoogleKWS(args)
+
+    @staticmethod
+    def add_arguments(parser):
+        parser.add_argument("--architecture", default="conv", choices=kws.ARCHITECTURES)
+
+    def _engine_for(self, inputs):
+        return kws.get_engine(self.google_kws.build_model_settings(inputs), self.args.architecture)
+
+
+class _ResModel(_GraphModel):
+    variant = None
+
+    @staticmethod
+    def add_arguments(parser):
+        parser.add_argument("--weight_decay", default=0.00001, type=float)
+
+    def _engine_for(self, inputs):
+        res.Res_arg_scope(is_training=self.is_training, weight_decay=self.args.weight_decay)
+        return res.get_engine(self.variant, int(inputs.shape[1]), int(inputs.shape[2]), self.args.num_classes)
+
+
+class Res8Model(_ResModel):
+    variant = "Res8"
+
+
+class Res8NarrowModel(_ResModel):
+    variant = "Res8Narrow"
+
+
+class Res15Model(_ResModel):
+    variant = "Res15"
+
+
+class Res15NarrowModel(_ResModel):
+    variant = "Res15Narrow"
+
+
+class _ResNet2D8Model(_GraphModel):
+    scope = None
+    pool = None
+
+    @staticmethod
+    def add_arguments(parser):
+        parser.add_argument("--weight_decay", default=0.0001, type=float)
+        parser.add_argument("--dropout_keep_prob", default=0.5, type=float)
+        parser.add_argument("--width_multiplier", default=1.0, type=float)
+
+    def _engine_for(self, inputs):
+        return tc_resnet.get_engine_2d(self.scope, int(inputs.shape[1]), int(inputs.shape[2]), self.args.num_classes, self.args.width_multiplier,
+                                       self.args.dropout_keep_prob, self.pool)
+
+
+class ResNet2D8Model(_ResNet2D8Model):
+    scope = "ResNet2D8"
+
+
+class ResNet2D8PoolModel(_ResNet2D8Model):
+    scope = "ResNet2D8Pool"
+    pool = ([4, 4], 4)

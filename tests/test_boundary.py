@@ -315,6 +315,15 @@ def test_deployable_model_and_freeze(rt, tmp_path):
     f3 = ds.freeze()
     x = torch.randn(3, 49, 10, 1, device=dev)
     assert torch.equal(f3(x), ds.engine.forward_infer(T.features_to_planar(x, lib=rt))[1])
+    # ... and the graph-engine families (rebuilt from the stored model name + arguments)
+    kargs = _model_args(num_mfccs=12, height=16, width=12, channels=1, architecture="tiny_conv")
+    km = audio_nets.KWSModel(kargs)
+    km.build_deployable_model(include_preprocess=False)
+    km.freeze().save(str(tmp_path / "kws.pb"))
+    tc_resnet.reset_engines()
+    kf = deploy.FrozenModel.load(str(tmp_path / "kws.pb"), lib=rt, device=dev)
+    xk = torch.randn(2, 16, 12, 1, device=dev)
+    assert torch.equal(kf(xk), km.engine.forward_infer(T.features_to_planar(xk, lib=rt))[1])
 
 
 def test_lr_schedule():
