@@ -337,7 +337,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_FUSED_WAVES = 5, /* fused kernel: waves per workgroup (4, 8, 16) + 100 * weight-ring depth (4, 8, 16); 0: default */
        TCR_TUNE_CONV_KSPLIT = 6, /* train-mode conv / data-gradient: waves sharing one 32-position group's reduction (0 auto, 1, 2, 4) */
        TCR_TUNE_WGRAD_STREAM = 7,/* backward: 0 weight-gradient kernels on an internal second stream (default), 1 everything on the caller's stream */
-       TCR_TUNE_COUNT = 8 };
+       TCR_TUNE_TRAIN_FWD = 8,   /* train-mode forward: 0 group-resident phases (train_fused.hip; BN affine / ReLU / residual applied while the next conv stages its input, statistics from the conv epilogue), 1 per-layer kernels (conv -> statistics -> finalize -> normalise) */
+       TCR_TUNE_COUNT = 9 };
 int tcr_tune(int knob, int value);
 
 #ifdef __cplusplus

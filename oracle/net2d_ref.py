@@ -24,6 +24,17 @@ from . import numpy_ref as R
 
 DT = torch.float64
 
+# ReLU-kink bookkeeping for the tests: with `KINK_LOG["on"]` every ReLU input is scanned for elements within `tau` of zero -- an
+# f32 implementation cannot be expected to land on the same side of such an input, and each flipped mask moves the gradients.
+KINK_LOG = {"on": False, "tau": 1e-5, "near": 0, "total": 0}
+
+
+def _relu(x):
+    if KINK_LOG["on"]:
+        KINK_LOG["near"] += int((x.detach().abs() < KINK_LOG["tau"]).sum())
+        KINK_LOG["total"] += x.numel()
+    return F.relu(x)
+
 
 def _same_pads(length: int, k_eff: int, stride: int):
     out = -(-length // stride)
@@ -94,7 +105,7 @@ def resnet2d_forward(params, stats, x, scope="ResNet2D8", width_multiplier=1.0, 
     def conv_bn(h, name, stride, relu):
         y = conv2d(h, params[f"{scope}/{name}/weights"], (stride, stride))
         y = batch_norm(y, f"{scope}/{name}/BatchNorm", params, stats, new_stats, is_training, 0.997, 0.001, True, True)
-        return F.relu(y) if relu else y
+        return _relu(y) if relu else y
 
     net = conv_bn(x.unsqueeze(1), "conv0", 1, True)
     if pool is not None:
@@ -107,7 +118,7 @@ def resnet2d_forward(params, stats, x, scope="ResNet2D8", width_multiplier=1.0, 
             stride, layer_in = 1, net
         h = conv_bn(net, f"block{i}/conv{i}_0", stride, True)
         h = conv_bn(h, f"block{i}/conv{i}_1", 1, False)
-        net = F.relu(h + layer_in)
+        net = _relu(h + layer_in)
         c = n
     net = net.mean(dim=(2, 3), keepdim=True)                            # :43
     net = drop.apply(net, keep_prob, is_training)                       # :45
@@ -129,10 +140,10 @@ def res_forward(params, stats, x, variant="Res8", is_training=False, scope="Res"
 
     def conv_relu_bn(h, idx, with_bn):                                  # :6-26
         rate = int(2 ** (idx // 3)) if use_dilation else 1
-        h = F.relu(conv2d(h, params[f"{scope}/conv{idx}/weights"], rate=(rate, rate)))
+        h = _relu(conv2d(h, params[f"{scope}/conv{idx}/weights"], rate=(rate, rate)))
         return bn(h, f"conv{idx}_bn") if with_bn else h
 
-    net = F.relu(conv2d(x.unsqueeze(1), params[f"{scope}/f_conv/weights"]))
+    net = _relu(conv2d(x.unsqueeze(1), params[f"{scope}/f_conv/weights"]))
     if pool_size:
         net = F.avg_pool2d(net, pool_size, 1)
     idx = 0
@@ -165,30 +176,30 @@ def kws_forward(params, x, architecture, is_training=False, masks=None):
     if architecture == "single_fc":
         logits = x.flatten(1) @ p["weights"].reshape(-1, p["weights"].shape[-1]) + p["bias"]
     elif architecture == "conv":
-        h = d(F.relu(conv2d(x4, p["first_weights"], padding="SAME", bias=p["first_bias"])))
+        h = d(_relu(conv2d(x4, p["first_weights"], padding="SAME", bias=p["first_bias"])))
         h = max_pool(h, (2, 2), (2, 2), "SAME")
-        h = d(F.relu(conv2d(h, p["second_weights"], padding="SAME", bias=p["second_bias"])))
+        h = d(_relu(conv2d(h, p["second_weights"], padding="SAME", bias=p["second_bias"])))
         logits = _flat(h) @ p["final_fc_weights"].reshape(-1, p["final_fc_weights"].shape[-1]) + p["final_fc_bias"]
     elif architecture == "trad_fpool3":
-        h = d(F.relu(conv2d(x4, p["first_weights"], padding="VALID")))
+        h = d(_relu(conv2d(x4, p["first_weights"], padding="VALID")))
         h = max_pool(h, (1, 3), (1, 3), "VALID")
-        h = d(F.relu(conv2d(h, p["second_weights"], padding="VALID")))
+        h = d(_relu(conv2d(h, p["second_weights"], padding="VALID")))
         h = _flat(h) @ p["linear_weights"].reshape(-1, 32)
         h = h @ p["first_fc_weights"].reshape(32, 128)
         logits = h @ p["final_fc_weights"].reshape(128, -1)
     elif architecture == "low_latency_conv":
-        h = d(F.relu(conv2d(x4, p["first_weights"], padding="VALID", bias=p["first_bias"])))
+        h = d(_relu(conv2d(x4, p["first_weights"], padding="VALID", bias=p["first_bias"])))
         h = d(_flat(h) @ p["first_fc_weights"].reshape(-1, 128) + p["first_fc_bias"])
         h = d(h @ p["second_fc_weights"].reshape(128, 128) + p["second_fc_bias"])
         logits = h @ p["final_fc_weights"].reshape(128, -1) + p["final_fc_bias"]
     elif architecture == "one_fstride4":
-        h = d(F.relu(conv2d(x4, p["first_weights"], stride=(1, 4), padding="VALID")))
+        h = d(_relu(conv2d(x4, p["first_weights"], stride=(1, 4), padding="VALID")))
         h = _flat(h) @ p["first_linear_weights"].reshape(-1, 32)
         h = d(h @ p["first_fc_weights"].reshape(32, 128))
         h = d(h @ p["second_fc_weights"].reshape(128, 128))
         logits = h @ p["final_fc_weights"].reshape(128, -1)
     elif architecture == "tiny_conv":
-        h = d(F.relu(conv2d(x4, p["first_weights"], stride=(2, 2), padding="SAME", bias=p["first_bias"])))
+        h = d(_relu(conv2d(x4, p["first_weights"], stride=(2, 2), padding="SAME", bias=p["first_bias"])))
         logits = _flat(h) @ p["final_fc_weights"].reshape(-1, p["final_fc_weights"].shape[-1]) + p["final_fc_bias"]
     else:
         raise ValueError(architecture)

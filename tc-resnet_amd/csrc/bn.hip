@@ -135,8 +135,20 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk
         const int part = threadIdx.x / n2, col = threadIdx.x - part * n2;     // col = which * cb + (ch - c0)
         if (part < nparts) {
             const int which = col / cb, ch = c0 + col - which * cb;
+            // The rows of a slice are added in order, but their loads are independent: eight in flight per trip (a one-load-
+            // per-trip loop pays a full L2 round trip per row: 15 us per finalize at 512 rows).
             double acc = 0.0;
-            for (int k = part; k < nchunk; k += nparts) acc += (double)partial[((size_t)k * 2 + which) * nc + ch];
+            const float* src = partial + (size_t)which * nc + ch;
+            const size_t rstride = (size_t)2 * nc;
+            int k = part;
+            for (; k + 7 * nparts < nchunk; k += 8 * nparts) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u * nparts) * rstride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (double)v[u];
+            }
+            for (; k < nchunk; k += nparts) acc += (double)src[(size_t)k * rstride];
             s_slices[part * n2 + col] = acc;
         }
         __syncthreads();

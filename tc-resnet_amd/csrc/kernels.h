@@ -137,6 +137,38 @@ struct FusedArgs {
 // returns 1 when the launch could not be configured (caller falls back to the per-layer kernels)
 int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, int ring, hipStream_t s);
 
+// ---- train_fused.hip : group-resident phases of the train-mode forward ---------------------------
+struct PhaseSrc {           // how a phase's input activation X [c][t] is produced while it is staged into LDS
+    int kind;               // 0: plain rows `a` (features, or an already materialised activation); 1: relu(bn(a)); 2: relu(bn(a) + S)
+    const float* a;         // [B][c][tp]
+    const float* ss_a;      // scale at [0, c), shift at [c_pad_a, c_pad_a + c)
+    int c_pad_a;
+    int s_kind;             // kind 2: 0: S = rows `s` (identity shortcut); 1: S = relu(bn(s)) (the block's `down` branch)
+    const float* s;
+    const float* ss_s;
+    int c_pad_s;
+    float* out_x;           // where X is materialised for backward (halo zeroed), or nullptr
+    float* out_s;           // where S is materialised (s_kind 1), or nullptr
+    int c, t;
+};
+struct PhaseLayer {
+    int k, stride, cin, cout, tin, tout, pad_lo;
+    int w_off;              // floats into params
+    float* raw;             // [B][cout][tpo] raw conv output (interior written)
+    float* partial;         // [rows][2][cout] per-workgroup sums / sums of squares
+};
+struct TrainPhaseArgs {
+    const float* params;
+    PhaseSrc src;
+    int n_layers;           // 0: staging only (materialise X / S)
+    PhaseLayer layer[2];
+    int batch;
+    int group, n_groups, in_sz, cstat, stat_off;     // (set by the launcher)
+};
+// rows_out: partial rows written per layer (= workgroups).  Returns 1 when the phase does not fit (nothing launched).
+int launch_train_phase(TrainPhaseArgs a, int* rows_out, hipStream_t s);
+int train_phase_rows(const TrainPhaseArgs& a);      // the same number without launching (-1: does not fit)
+
 // ---- bn.hip ---------------------------------------------------------------------------------
 constexpr int kBnMaxLayers = 40;
 

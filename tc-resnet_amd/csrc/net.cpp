@@ -554,12 +554,14 @@ static int fwd_unit_pre(const TrainCtx& c, int li, hipStream_t rs, float* partia
 }
 
 // statistics -> scale/shift, moving-stat update, normalise (+ReLU / +residual)
-static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* res, hipStream_t rs, float* partial) {
+static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* res, hipStream_t rs, float* partial, int rows = -1) {
+    // rows >= 0: the partial rows come from a group-resident phase (train_fused.hip), which also normalises on the fly in its
+    // consumer: only the finalize runs here
     const ConvLayer& l = c.net->layers[li];
     float* ss = c.base + c.w.ss + l.ss_off;
     BnFinalizeArgs f;
     f.partial = partial;
-    f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout);
+    f.nchunk = c.sync_bn ? 0 : (rows >= 0 ? rows : chan_reduce_launch_chunks(c.batch * l.tout));
     f.sums = reinterpret_cast<const double*>(c.base + c.w.sums);
     f.gamma = c.params + l.gamma_off; f.beta = c.params + l.beta_off;
     f.moving_mean = stats + l.mean_off; f.moving_var = stats + l.var_off;
@@ -568,6 +570,7 @@ static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* r
     f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
     f.decay = c.net->cfg.bn_decay; f.eps = c.net->cfg.bn_eps;
     TCR_TRY(launch_bn_finalize(f, rs));
+    if (rows >= 0) return TCR_OK;
     BnApplyArgs a;
     a.y = c.base + c.w.raw[li]; a.scale = ss; a.shift = ss + l.c_pad; a.res = res; a.out = c.base + c.w.act[li];
     a.total = (int64_t)c.batch * l.cout * tcr_padded_len(l.tout);
@@ -583,6 +586,89 @@ static const float* unit_residual(const TrainCtx& c, int li) {
         cur = b.b;
     }
     return nullptr;
+}
+
+// ---- group-resident phases (train_fused.hip) ------------------------------------------------------------------------------
+static const float* ss_of(const TrainCtx& c, int li) { return c.base + c.w.ss + c.net->layers[li].ss_off; }
+
+// The activation entering block `bi` (bi == number of blocks: the activation the head reads), built from raw tensors while a
+// phase stages it: X_0 = relu(bn(raw conv0)); X_i = relu(bn(raw conv_b) + shortcut) of block i-1 (tc_resnet.py:21,40-41).
+static PhaseSrc block_input_src(const TrainCtx& c, int bi) {
+    const tcr_net& net = *c.net;
+    PhaseSrc s;
+    std::memset(&s, 0, sizeof(s));
+    if (bi == 0) {
+        const ConvLayer& l = net.layers[0];
+        s.kind = 1; s.a = c.base + c.w.raw[0]; s.ss_a = ss_of(c, 0); s.c_pad_a = l.c_pad; s.out_x = c.base + c.w.act[0];
+        s.c = l.cout; s.t = l.tout;
+        return s;
+    }
+    const Block& pb = net.blocks[bi - 1];
+    const ConvLayer& lb = net.layers[pb.b];
+    s.kind = 2; s.a = c.base + c.w.raw[pb.b]; s.ss_a = ss_of(c, pb.b); s.c_pad_a = lb.c_pad; s.out_x = c.base + c.w.act[pb.b];
+    s.c = lb.cout; s.t = lb.tout;
+    if (pb.down >= 0) {
+        s.s_kind = 1; s.s = c.base + c.w.raw[pb.down]; s.ss_s = ss_of(c, pb.down); s.c_pad_s = net.layers[pb.down].c_pad;
+        s.out_s = c.base + c.w.act[pb.down];
+    } else {
+        s.s_kind = 0; s.s = c.base + c.w.act[bi - 1 == 0 ? 0 : net.blocks[bi - 2].b];      // identity: the previous block output
+    }
+    return s;
+}
+
+static PhaseLayer phase_layer_of(const TrainCtx& c, int li, float* partial) {
+    const ConvLayer& l = c.net->layers[li];
+    PhaseLayer p;
+    p.k = l.k; p.stride = l.stride; p.cin = l.cin; p.cout = l.cout; p.tin = l.tin; p.tout = l.tout; p.pad_lo = l.pad_lo;
+    p.w_off = (int)l.w_off; p.raw = c.base + c.w.raw[li]; p.partial = partial;
+    return p;
+}
+
+// The phase that computes unit `li` (li < 0: the closing, staging-only phase).  *first: the phase is launched when this unit's
+// turn comes (false for conv_a of a block with a `down` shortcut: it ran together with `down`).
+static TrainPhaseArgs phase_of_unit(const TrainCtx& c, int li, bool* first) {
+    const tcr_net& net = *c.net;
+    TrainPhaseArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.params = c.params; a.batch = c.batch;
+    *first = true;
+    float* p1 = c.base + c.w.partial;
+    float* p2 = c.base + c.w.partial2;
+    if (li < 0) { a.src = block_input_src(c, (int)net.blocks.size()); a.n_layers = 0; return a; }
+    if (li == 0) {
+        a.src.kind = 0; a.src.a = c.feat; a.src.c = net.cfg.in_channels; a.src.t = net.cfg.t_in;
+        a.n_layers = 1; a.layer[0] = phase_layer_of(c, 0, p1);
+        return a;
+    }
+    for (size_t bi = 0; bi < net.blocks.size(); ++bi) {
+        const Block& b = net.blocks[bi];
+        if (li == b.down || li == b.a) {
+            a.src = block_input_src(c, (int)bi);
+            if (b.down >= 0) {
+                a.n_layers = 2; a.layer[0] = phase_layer_of(c, b.down, p2); a.layer[1] = phase_layer_of(c, b.a, p1);
+                *first = li == b.down;
+            } else {
+                a.n_layers = 1; a.layer[0] = phase_layer_of(c, b.a, p1);
+            }
+            return a;
+        }
+        if (li == b.b) {
+            const ConvLayer& la = net.layers[b.a];
+            a.src.kind = 1; a.src.a = c.base + c.w.raw[b.a]; a.src.ss_a = ss_of(c, b.a); a.src.c_pad_a = la.c_pad;
+            a.src.out_x = c.base + c.w.act[b.a]; a.src.c = la.cout; a.src.t = la.tout;
+            a.n_layers = 1; a.layer[0] = phase_layer_of(c, b.b, p1);
+            return a;
+        }
+    }
+    return a;
+}
+
+static bool phases_usable(const TrainCtx& c) {
+    if (tune_get(TCR_TUNE_TRAIN_FWD) == 1 || tune_get(TCR_TUNE_CONV_PATH) == 1) return false;
+    bool first;
+    for (int li : c.net->units)
+        if (train_phase_rows(phase_of_unit(c, li, &first)) < 0) return false;
+    return train_phase_rows(phase_of_unit(c, -1, &first)) >= 0;
 }
 
 }  // namespace tcr
@@ -609,6 +695,42 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
     if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1 && !sync_bn) TCR_TRY(side_stream(*net, &c.side));
     const int nu = (int)net->units.size();
     TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_forward_train: bad stage range [%d, %d)", stage_begin, stage_end);
+    const bool phases = phases_usable(c);
+    for (int st = stage_begin; phases && st < stage_end; ++st) {
+        // Group-resident phases: conv (+ the block's `down`) with the statistics in its epilogue; the previous unit's BN affine,
+        // ReLU and residual are applied while the phase stages its input.  Between phases only the tiny finalize kernels run.
+        auto is_down = [&](int li) { for (const Block& b : net->blocks) if (b.down == li) return true; return false; };
+        auto partial_of = [&](int li) { return c.base + (is_down(li) ? c.w.partial2 : c.w.partial); };
+        bool first = true;
+        if (st > 0) {
+            const int li = net->units[st - 1];
+            const int rows = train_phase_rows(phase_of_unit(c, li, &first));
+            TCR_TRY(fwd_unit_post(c, li, stats, nullptr, c.s, partial_of(li), rows));
+        }
+        if (st < nu) {
+            const int li = net->units[st];
+            const TrainPhaseArgs pa = phase_of_unit(c, li, &first);
+            int rows = train_phase_rows(pa);
+            if (first) TCR_TRY(launch_train_phase(pa, &rows, c.s));
+            if (c.sync_bn) TCR_TRY(launch_chan_sums(partial_of(li), rows, net->layers[li].cout, reinterpret_cast<double*>(c.base + c.w.sums), c.s));
+        } else {
+            TCR_TRY(launch_train_phase(phase_of_unit(c, -1, &first), nullptr, c.s));       // the head's input + the last shortcut
+            HeadArgs h;
+            std::memset(&h, 0, sizeof(h));
+            h.feat = c.base + c.w.act[net->units[nu - 1]];
+            h.wfc = params + net->layers[net->fc].w_off;
+            h.wfc2 = params + net->layers[net->fc2].w_off;
+            h.labels = labels; h.logits = logits; h.probs = probs; h.ranges = nullptr;
+            h.dropped = c.base + c.w.dropped; h.dscale = c.base + c.w.dscale;
+            h.dlogits = c.base + c.w.dlogits; h.loss_utt = c.base + c.w.loss_utt;
+            h.batch = batch; h.c = net->feat_c; h.nc = net->cfg.num_classes; h.t = net->feat_t; h.tp = tcr_padded_len(net->feat_t);
+            h.keep_prob = keep_prob; h.seed = seed; h.sample_offset = sample_offset;
+            h.inv_global_batch = 1.0f / (float)global_batch; h.label_smoothing = label_smoothing;
+            TCR_TRY(launch_head_fwd(h, true, c.s));
+            TCR_TRY(launch_sum_vector(c.base + c.w.loss_utt, batch, loss_out, c.s));
+        }
+    }
+    if (phases) return TCR_OK;
     for (int st = stage_begin; st < stage_end; ++st) {
         // Without cross-replica statistics the BN chain (statistics -> finalize -> normalise) of a block's shortcut conv runs
         // on the side stream next to conv_a's: the two raw outputs come from ONE fused launch and nothing reads the shortcut

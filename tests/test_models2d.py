@@ -74,7 +74,15 @@ def _check(lib, eng, oracle_fwd, t, f, batch, masks_of=None, grad_rtol=3e-4, see
     stats0 = eng.stats.clone()
     tl, tpb, loss_sum = eng.forward_train(planar, torch.from_numpy(labels.astype(np.float32)).to(dev), seed=tseed, sample_offset=off)
     g = eng.backward()
+    O.KINK_LOG.update(on=True, near=0, total=0)
     out, model, _tot, grads = O.loss_and_grads(lambda pp: oracle_fwd(pp, s, xt, True, masks), p, labels)
+    O.KINK_LOG["on"] = False
+    # ReLU inputs within 1e-5 of zero (of `total`): an f32 forward may fall on the other side of each of them, and one flipped mask
+    # moves a gradient entry by O(its patch's contribution).  Without such inputs the gradients must agree to grad_rtol; with them
+    # (full-size planes: millions of ReLU inputs, a handful at the kink) to 2e-3 of the tensor's largest entry.
+    near = O.KINK_LOG["near"]
+    if near:
+        grad_rtol = max(grad_rtol, 2e-3)
     assert np.abs(tl.cpu().numpy() - out["logits"]).max() < Cm.LOGIT_TOL
     assert abs(float(loss_sum) / batch - model) < 1e-4
     worst = 0.0
