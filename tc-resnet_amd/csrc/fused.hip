@@ -112,6 +112,194 @@ if (++c4 == C4) { c4 = 0; off = ++j; }                                          
     }
 }
 
+// The same layer with its shape known at COMPILE time (the flagship configurations: TCResNet8-1.0 at 49 and 98 frames).
+// Every K-step of the generic walk above costs ~14 scalar / vector instructions next to its two MFMAs -- step counters, the
+// (tap, channel-quad) -> offset bookkeeping, clamped weight indices -- and with 3-8 jobs per barrier phase a wave cannot keep
+// the matrix pipe busy at that ratio.  With K, stride, Cin, Cout and T as template parameters the K loop unrolls, the LDS
+// operands are read at immediate offsets (c4 * 4 * Tp + tap), the weights at immediate offsets from one per-tap base, and the
+// position -> (utterance, frame) split divides by a constant.  Same accumulation order (tap-major, channel quads inner): the
+// result is bitwise the generic layer's.
+template <int NW, int K, int S, int CIN, int COUT, int TIN>
+__device__ __forceinline__ void fused_layer_t(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
+                                              float* lds, const int ng, const int wave, const int r, const int q) {
+    constexpr int TOUT = (TIN + S - 1) / S;
+    constexpr int PADT = ((TOUT - 1) * S + K - TIN) > 0 ? ((TOUT - 1) * S + K - TIN) : 0;
+    constexpr int PADLO = PADT / 2;
+    constexpr int TPI = TIN + 2 * kHalo, TPO = TOUT + 2 * kHalo;
+    constexpr int C4 = CIN / 4, NRT = (COUT + 15) / 16;
+    constexpr int WSTEP = 4 * COUT, XSTEP = 4 * TPI;
+    static_assert(CIN % 4 == 0, "channel quads");
+    float* yout = lds + a.buf_off[L.out_buf];
+    const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
+    const int out_sz = a.buf_sz[L.out_buf];
+    const int res_sz = L.res_buf >= 0 ? a.buf_sz[L.res_buf] : 0;
+    const int npos = ng * TOUT;
+    const int ncp = (npos + 31) / 32;
+    const float* w = a.params + L.w_off;
+    const float* scale = a.ss + L.ss_off;
+    const float* shift = scale + L.c_pad;
+    for (int job = wave; job < ncp * NRT; job += NW) {
+        const int cp = job / NRT, m = job - cp * NRT;
+        const int p0 = min(cp * 32 + r, npos - 1), p1 = min(cp * 32 + 16 + r, npos - 1);
+        const int g0 = p0 / TOUT, g1 = p1 / TOUT;
+        const int t0 = p0 - g0 * TOUT, t1 = p1 - g1 * TOUT;
+        const float* wp = w + q * COUT + min(m * 16 + r, COUT - 1);
+        const float* x0 = xin + g0 * in_sz + q * TPI + t0 * S + kHalo - PADLO;
+        const float* x1 = xin + g1 * in_sz + q * TPI + t1 * S + kHalo - PADLO;
+        float sc[4], sh[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int co = min(m * 16 + q * 4 + reg, COUT - 1);
+            sc[reg] = scale[co];
+            sh[reg] = shift[co];
+        }
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (taps stay a loop -- one pointer increment each -- and only the channel quads unroll: unrolling both lets the
+        // scheduler hoist all K * C4 operand loads, 207 VGPRs and half the occupancy)
+#pragma unroll 1
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+                const float av = wp[(j * C4 + c4) * WSTEP];
+                const float b0 = x0[c4 * XSTEP + j], b1 = x1[c4 * XSTEP + j];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if (cp * 32 + nt * 16 + r >= npos) continue;
+            const int g = nt == 0 ? g0 : g1, t = nt == 0 ? t0 : t1;
+            const f32x4 ac = nt == 0 ? acc0 : acc1;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = m * 16 + q * 4 + reg;
+                if (co >= COUT) continue;
+                float v = fmaf(ac[reg], sc[reg], sh[reg]);
+                if (res) v = fmaxf(v + res[g * res_sz + co * TPO + kHalo + t], 0.f);
+                else if (L.relu) v = fmaxf(v, 0.f);
+                float* dst = yout + g * out_sz + co * TPO + kHalo + t;
+                dst[0] = v;
+                if (t == 0) { dst[-4] = 0.f; dst[-3] = 0.f; dst[-2] = 0.f; dst[-1] = 0.f; }
+                if (t == TOUT - 1) { dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f; dst[4] = 0.f; }
+            }
+        }
+    }
+}
+
+// ---- head: global average pool -> fc / fc2 -> softmax / sigmoid (tc_resnet.py:43-52), shared by the fused kernels ----
+template <int NT>
+__device__ __forceinline__ void fused_head(const FusedArgs& a, float* lds, const int n0, const int ng, const int tid) {
+    {
+        const float* fb = lds + a.buf_off[a.feat_buf];
+        const int fsz = a.buf_sz[a.feat_buf], tp = a.feat_t + 2 * kHalo;
+        float* pooled = lds + a.buf_off[(a.feat_buf + 1) % 3];         // any buffer other than the feature buffer
+        for (int i = tid; i < ng * a.feat_c; i += NT) {
+            const int g = i / a.feat_c, c = i - g * a.feat_c;
+            const float* row = fb + g * fsz + c * tp + kHalo;
+            float s = 0.f;
+            for (int t = 0; t < a.feat_t; ++t) s += row[t];
+            pooled[i] = s / (float)a.feat_t;
+        }
+        __syncthreads();
+        float* lg = pooled + a.group * a.feat_c;                        // [ng][nc + 2]
+        const int no = a.nc + 2;
+        for (int i = tid; i < ng * no; i += NT) {
+            const int g = i / no, o = i - g * no;
+            const float* pv = pooled + g * a.feat_c;
+            float s = 0.f;
+            if (o < a.nc) {
+                const float* wf = a.params + a.fc_off + o;
+#pragma unroll 8
+                for (int c = 0; c < a.feat_c; ++c) s = fmaf(pv[c], wf[(size_t)c * a.nc], s);
+            } else {
+                const float* wf = a.params + a.fc2_off + (o - a.nc);
+#pragma unroll 8
+                for (int c = 0; c < a.feat_c; ++c) s = fmaf(pv[c], wf[(size_t)c * 2], s);
+            }
+            lg[i] = s;
+        }
+        __syncthreads();
+        // softmax / sigmoid: one thread per (utterance, output); the max and the sum are recomputed per thread
+        // from the LDS row in the SAME order as the single-thread form (bitwise identical results)
+        for (int i = tid; i < ng * no; i += NT) {
+            const int g = i / no, o = i - g * no;
+            const float* z = lg + g * no;
+            const size_t n = (size_t)(n0 + g);
+            if (o < a.nc) {
+                float mx = z[0];
+                for (int k = 1; k < a.nc; ++k) mx = fmaxf(mx, z[k]);
+                float se = 0.f;
+                for (int k = 0; k < a.nc; ++k) se += expf(z[k] - mx);
+                a.logits[n * a.nc + o] = z[o];
+                a.probs[n * a.nc + o] = expf(z[o] - mx) / se;
+            } else if (a.ranges) {
+                a.ranges[n * 2 + (o - a.nc)] = 1.0f / (1.0f + expf(-z[o]));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// TCResNet8-1.0 on 40 coefficients with every layer shape fixed at compile time (T0 = 49 or 98 frames): the flagship
+// configurations of BASELINE.json.  Same walk, same LDS plan (FusedArgs), bitwise the generic kernel's results.
+#if defined(TCR_HOST_EMULATION)
+#define TCR_WAVES_PER_SIMD_4
+#else
+#define TCR_WAVES_PER_SIMD_4 __attribute__((amdgpu_waves_per_eu(4, 4)))     // two 8-wave workgroups per CU: <= 128 VGPRs
+#endif
+template <int NW, int T0>
+__global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_kernel(const FusedArgs a) {
+    constexpr int NT = NW * 64;
+    constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2;
+    float* lds = reinterpret_cast<float*>(dyn_lds());
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int row = a.in_c * a.in_tp;
+#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_t<NW, K_, S_, CI_, CO_, T_>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.buf_sz[a.layer[LI].in_buf], lds, ng, wave, r, q)
+    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+        const int n0 = grp * a.group;
+        const int ng = min(a.group, a.batch - n0);
+        fused_layer_t<NW, 3, 1, 40, 16, T0>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
+        __syncthreads();
+        TCR_TC8(1, 1, 2, 16, 24, T0);           // block0/down (reads the same rows as conv0_0: no barrier in between)
+        TCR_TC8(2, 9, 2, 16, 24, T0);
+        __syncthreads();
+        TCR_TC8(3, 9, 1, 24, 24, T1);
+        __syncthreads();
+        TCR_TC8(4, 1, 2, 24, 32, T1);
+        TCR_TC8(5, 9, 2, 24, 32, T1);
+        __syncthreads();
+        TCR_TC8(6, 9, 1, 32, 32, T2);
+        __syncthreads();
+        TCR_TC8(7, 1, 2, 32, 48, T2);
+        TCR_TC8(8, 9, 2, 32, 48, T2);
+        __syncthreads();
+        TCR_TC8(9, 9, 1, 48, 48, (T2 + 1) / 2);
+        __syncthreads();
+        fused_head<NT>(a, lds, n0, ng, tid);
+    }
+#undef TCR_TC8
+}
+
+// 49 / 98 when the plan is exactly TCResNet8-1.0 on 40 coefficients read from global memory, else 0
+static int fused_tc8_frames(const FusedArgs& a) {
+    static const int shape[10][4] = {{3, 1, 40, 16}, {1, 2, 16, 24}, {9, 2, 16, 24}, {9, 1, 24, 24}, {1, 2, 24, 32},
+                                     {9, 2, 24, 32}, {9, 1, 32, 32}, {1, 2, 32, 48}, {9, 2, 32, 48}, {9, 1, 48, 48}};
+    if (a.n_layers != 10 || !a.in_global || a.in_c != 40) return 0;
+    const int t0 = a.layer[0].tin;
+    if (t0 != 49 && t0 != 98) return 0;
+    int t = t0;
+    for (int i = 0; i < 10; ++i) {
+        const FusedLayer& L = a.layer[i];
+        if (L.k != shape[i][0] || L.stride != shape[i][1] || L.cin != shape[i][2] || L.cout != shape[i][3] || L.tin != t) return 0;
+        if (i == 2 || i == 5 || i == 8) t = (t + 1) / 2;
+    }
+    return t0;
+}
+
 template <int NW, int R>
 __global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
     constexpr int NT = NW * 64;
@@ -141,62 +329,18 @@ __global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
             if (!L.no_barrier) __syncthreads();         // (a block's shortcut conv and its first conv read the same input: one phase)
         }
 
-        // ---- head: global average pool -> fc / fc2 -> softmax / sigmoid (tc_resnet.py:43-52) ----
-        {
-            const float* fb = lds + a.buf_off[a.feat_buf];
-            const int fsz = a.buf_sz[a.feat_buf], tp = a.feat_t + 2 * kHalo;
-            float* pooled = lds + a.buf_off[(a.feat_buf + 1) % 3];         // any buffer other than the feature buffer
-            for (int i = tid; i < ng * a.feat_c; i += NT) {
-                const int g = i / a.feat_c, c = i - g * a.feat_c;
-                const float* row = fb + g * fsz + c * tp + kHalo;
-                float s = 0.f;
-                for (int t = 0; t < a.feat_t; ++t) s += row[t];
-                pooled[i] = s / (float)a.feat_t;
-            }
-            __syncthreads();
-            float* lg = pooled + a.group * a.feat_c;                        // [ng][nc + 2]
-            const int no = a.nc + 2;
-            for (int i = tid; i < ng * no; i += NT) {
-                const int g = i / no, o = i - g * no;
-                const float* pv = pooled + g * a.feat_c;
-                float s = 0.f;
-                if (o < a.nc) {
-                    const float* wf = a.params + a.fc_off + o;
-#pragma unroll 8
-                    for (int c = 0; c < a.feat_c; ++c) s = fmaf(pv[c], wf[(size_t)c * a.nc], s);
-                } else {
-                    const float* wf = a.params + a.fc2_off + (o - a.nc);
-#pragma unroll 8
-                    for (int c = 0; c < a.feat_c; ++c) s = fmaf(pv[c], wf[(size_t)c * 2], s);
-                }
-                lg[i] = s;
-            }
-            __syncthreads();
-            // softmax / sigmoid: one thread per (utterance, output); the max and the sum are recomputed per thread
-            // from the LDS row in the SAME order as the single-thread form (bitwise identical results)
-            for (int i = tid; i < ng * no; i += NT) {
-                const int g = i / no, o = i - g * no;
-                const float* z = lg + g * no;
-                const size_t n = (size_t)(n0 + g);
-                if (o < a.nc) {
-                    float mx = z[0];
-                    for (int k = 1; k < a.nc; ++k) mx = fmaxf(mx, z[k]);
-                    float se = 0.f;
-                    for (int k = 0; k < a.nc; ++k) se += expf(z[k] - mx);
-                    a.logits[n * a.nc + o] = z[o];
-                    a.probs[n * a.nc + o] = expf(z[o] - mx) / se;
-                } else if (a.ranges) {
-                    a.ranges[n * 2 + (o - a.nc)] = 1.0f / (1.0f + expf(-z[o]));
-                }
-            }
-            __syncthreads();
-        }
+        fused_head<NT>(a, lds, n0, ng, tid);
     }
 }
 
 int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, int ring, hipStream_t s) {
     void (*kern)(const FusedArgs) = nullptr;
-#define TCR_FK(NW_, R_) if (waves == NW_ && ring == R_) kern = net_fused_kernel<NW_, R_>;
+    const int tc8 = tune_get(TCR_TUNE_NET_FUSED) == 3 ? 0 : fused_tc8_frames(a);
+#define TCR_FS(NW_, T_) if (tc8 == T_ && waves == NW_) kern = net_fused_tc8_kernel<NW_, T_>;
+    TCR_FS(4, 49) TCR_FS(8, 49) TCR_FS(16, 49) TCR_FS(4, 98) TCR_FS(8, 98) TCR_FS(16, 98)
+#undef TCR_FS
+    if (kern) ring = 0;
+#define TCR_FK(NW_, R_) if (!kern && waves == NW_ && ring == R_) kern = net_fused_kernel<NW_, R_>;
     TCR_FK(4, 4) TCR_FK(4, 8) TCR_FK(4, 16) TCR_FK(8, 4) TCR_FK(8, 8) TCR_FK(8, 16) TCR_FK(16, 4) TCR_FK(16, 8) TCR_FK(16, 16)
 #undef TCR_FK
     if (!kern) { set_error("fused kernel: no instantiation for %d waves / ring %d", waves, ring); return TCR_ERR_ARG; }

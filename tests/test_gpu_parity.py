@@ -232,7 +232,8 @@ def test_every_kernel_path_agrees(hip_lib):
         results = {}
         for name, knobs in (("per-layer mfma", {3: 1}), ("per-layer mfma, LDS image", {3: 1, 2: 1}), ("per-layer valu", {3: 1, 0: 1}),
                             ("fused g=3", {4: 3}), ("fused g=4, 4 waves", {4: 4, 5: 404}), ("fused, features staged in LDS", {3: 2}),
-                            ("fused g=8, 16 waves, ring 8", {4: 8, 5: 816})):
+                            ("fused g=8, 16 waves, ring 8", {4: 8, 5: 816}), ("fused, generic layer walk (no compile-time shapes)", {3: 3}),
+                            ("fused, generic walk, 4 waves", {3: 3, 5: 404})):
             for k, v in knobs.items():
                 hip_lib.tcr_tune(k, v)
             results[name] = net.forward_infer(feat0)[0].clone()
