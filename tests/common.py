@@ -219,10 +219,20 @@ def check_dscnn_train(lib, size, steps=3, grad_rtol=2e-4):
                 assert np.abs(net._view(k[len("stat1:"):]).cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), k
             for k in [k for k in keys if k.startswith("param1:")]:
                 ref = fx[pre + k]
-                # Adam's first step moves every weight by lr * g / (|g| + eps'): entries whose gradient is within f32
-                # round-off of zero may differ by a fraction of lr
-                d = np.abs(net._view(k[len("param1:"):]).cpu().numpy().reshape(ref.shape) - ref)
-                assert d.max() < 2.5 * lr and np.mean(d > 2e-5) < 0.03, (k, d.max(), np.mean(d > 2e-5))
+                name = k[len("param1:"):]
+                d = np.abs(net._view(name).cpu().numpy().reshape(ref.shape) - ref)
+                # Adam's first step moves every weight by lr * g / (|g| + 1e-8) = lr * sign(g): it is a function of the SIGN of
+                # the gradient only, and the sign of an entry within f32 gradient error of zero (taken as 2e-5 of the tensor's
+                # largest entry, ten times the error the gradient checks above measure) is not determined.  Those entries --
+                # counted, < 3 % -- may differ by up to 2 lr; all others must match to 2e-5.
+                gk = pre + "grad:" + name
+                if gk in fx and not (name.endswith("/biases") and "fc1" not in name):
+                    g = np.abs(fx[gk])
+                    sure = g > 2e-5 * max(g.max(), 1e-3)
+                    assert d[sure].max(initial=0.0) < 2e-5, (k, d[sure].max())
+                    assert np.mean(~sure) < 0.03 and d.max() < 2.5 * lr, (k, np.mean(~sure), d.max())
+                else:           # (gradient not stored in the fixture: the same criterion without the per-entry attribution)
+                    assert d.max() < 2.5 * lr and np.mean(d > 2e-5) < 0.03, (k, d.max(), np.mean(d > 2e-5))
     if steps == 3:
         for k in [k for k in keys if k.startswith("stat3:")]:
             ref = fx[pre + k]
@@ -283,6 +293,13 @@ def relu_margin(arch, fwd) -> float:
     cache = fwd["cache"]
     m = min(np.abs(cache[c.name]["z"]).min() for c in arch.convs() if c.bn and c.relu)
     return float(min(m, min(np.abs(cache[f"block{b.index}/out"]["pre"]).min() for b in arch.blocks)))
+
+
+def relu_near(arch, fwd, tau=1e-5) -> int:
+    """Number of ReLU inputs of a train-mode forward within `tau` of the kink."""
+    cache = fwd["cache"]
+    n = sum(int((np.abs(cache[c.name]["z"]) < tau).sum()) for c in arch.convs() if c.bn and c.relu)
+    return n + sum(int((np.abs(cache[f"block{b.index}/out"]["pre"]) < tau).sum()) for b in arch.blocks)
 
 
 def pick_waveforms(arch, p, s, cfg, batch, seeds=range(100, 112)):

@@ -105,13 +105,17 @@ def test_full_batch_train_properties(hip_lib):
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "training step is not bitwise deterministic"
     x = R.mfcc(base, R.FRONTEND_4020)
     ref = R.forward(arch, p, s, x, True)
-    assert np.abs(outs[0][0][:64].cpu().numpy() - ref["logits"]).max() < 2e-4
+    assert np.abs(outs[0][0][:64].cpu().numpy() - ref["logits"]).max() < Cm.LOGIT_TOL          # north_star: 1e-4
     tot, model, _ = R.loss(ref["logits"], R.synth_labels(64).astype(np.float64), p, 0.0)
     assert abs(float(outs[0][1]) / 4096 - model) < 1e-4
     rg = R.backward(arch, p, ref, R.synth_labels(64).astype(np.float64), 0.0)
+    # 310 k ReLU inputs: those within 1e-5 of the kink (counted from the float64 forward) may be masked differently in f32, and each
+    # flip moves a gradient entry; none -> 2e-4 of the tensor's largest entry, otherwise 5e-4
+    near = Cm.relu_near(arch, ref)
+    tol = 2e-4 if near == 0 else 5e-4
     for k, v in rg.items():
         got = net.grad_view(k).cpu().numpy().reshape(v.shape)
-        assert np.abs(got - v).max() < 5e-4 * max(np.abs(v).max(), 1e-3), k
+        assert np.abs(got - v).max() < tol * max(np.abs(v).max(), 1e-3), (k, near)
     # moving variance uses the Bessel factor n/(n-1) of the ACTUAL count (4096*T), not of the 64-utterance oracle
     k = "TCResNet8/conv0/BatchNorm/moving_mean"
     assert np.abs(net._view(k).cpu().numpy() - ref["new_stats"][k]).max() < 1e-5
@@ -195,11 +199,17 @@ def test_dscnn_train_full_batch(hip_lib):
     assert np.abs(l[0].cpu().numpy() - ref["logits"]).max() < Cm.LOGIT_TOL
     assert abs(float(loss_sum) / 4096 - D.loss(ref["logits"], labels64)) < 1e-4
     gref = D.backward(blocks, p, ref, labels64)
-    # (a few of the ~5 M ReLU inputs sit within f32 round-off of the kink, so individual channels may differ slightly)
+    # 64 utterances x 11 BN+ReLU layers x 276 channels x 65-250 positions = ~20 M ReLU inputs.  Those within 1e-5 of the kink
+    # (counted from the float64 forward) may be masked differently by an f32 forward; one flip in a 276-channel depthwise /
+    # pointwise layer moves that channel's gradient entries by O(1 / positions-per-channel).  No such inputs: every gradient to
+    # 1e-3 of the tensor's largest entry; otherwise per-tensor 1e-3 still holds for the tensors downstream of every ReLU (fc1) and
+    # 2e-2 for the rest.
+    near = sum(int((np.abs(c["xhat"] + p[k + "/beta"]) < 1e-5).sum()) for k, c in ref["cache"].items() if isinstance(c, dict) and "xhat" in c)
     for k in ("DSCNN/fc1/weights", "DSCNN/fc1/biases", "DSCNN/conv_ds_5/pointwise_conv/weights", "DSCNN/conv_ds_3/depthwise_conv/depthwise_weights",
               "DSCNN/conv_ds_1/dw_batch_norm/beta", "DSCNN/conv_1/weights"):
         got = net.grad_view(k).cpu().numpy().reshape(gref[k].shape)
-        assert np.abs(got - gref[k]).max() < 2e-2 * np.abs(gref[k]).max(), k
+        tol = 1e-3 if (near == 0 or "fc1" in k) else 2e-2
+        assert np.abs(got - gref[k]).max() < tol * np.abs(gref[k]).max(), (k, near)
     net.stats.copy_(stats0)
     logits2, _, loss2 = net.forward_train(feat, labels)
     g2 = net.backward()

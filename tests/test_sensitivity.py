@@ -1,0 +1,122 @@
+"""How far the ⚠ items of SURVEY App. A can move a result (CPU, oracle only).
+
+The oracle is "parity unpinned": TF 1.13.1 cannot run here, and four details of its arithmetic were restated from memory of the
+TF source.  Each test evaluates BOTH readings of one detail with everything else fixed and measures the distance -- at the MFCC,
+at the eval logits, and after a training step where it matters.  A reading whose alternative stays inside the 1e-4 parity bar
+cannot surprise a future TF run; the one that does not (the moving-variance estimator at small batches) is flagged as the first
+thing to re-verify if TensorFlow ever becomes available."""
+import dataclasses
+import math
+
+import numpy as np
+
+from oracle import numpy_ref as R
+
+
+def _net(seed=0):
+    arch = R.make_tcresnet("TCResNet8", 1.0)
+    p, s = R.init_params(arch, seed)
+    R.randomize_bn(arch, p, s)
+    return arch, p, s
+
+
+def _mfcc_with(wav, cfg, window=None, mel=None, log_offset_f32=False):
+    """R.mfcc with a substituted Hann window and / or mel matrix."""
+    frames = R.frame_signal(wav.astype(np.float64), cfg.win, cfg.hop) * (R.hann_periodic(cfg.win) if window is None else window)
+    spec = np.fft.rfft(frames, n=cfg.nfft, axis=-1)
+    power = spec.real ** 2 + spec.imag ** 2
+    mel_w = R.linear_to_mel_weight_matrix(cfg.num_mel_bins, cfg.n_bins, cfg.sample_rate, cfg.lower_edge_hertz, cfg.upper_edge_hertz) if mel is None else mel
+    lm = np.log(power @ mel_w + (np.float64(np.float32(R.LOG_OFFSET)) if log_offset_f32 else R.LOG_OFFSET))
+    return (lm @ R.dct2_matrix(cfg.num_mel_bins, cfg.num_mel_bins))[..., :cfg.num_mfccs]
+
+
+def _mel_f32(cfg):
+    """linear_to_mel_weight_matrix evaluated in float32 TF ops (the other reading of App. A.1 step 5)."""
+    f32 = np.float32
+    nyq = f32(cfg.sample_rate / 2.0)
+    lin = np.linspace(f32(0.0), nyq, cfg.n_bins, dtype=f32)[1:]
+    mel = lambda f: f32(1127.0) * np.log(f32(1.0) + f / f32(700.0), dtype=f32)
+    bins = mel(lin)[:, None]
+    edges = np.linspace(mel(f32(cfg.lower_edge_hertz)), mel(f32(cfg.upper_edge_hertz)), cfg.num_mel_bins + 2, dtype=f32)
+    lo, ce, up = edges[:-2][None, :], edges[1:-1][None, :], edges[2:][None, :]
+    m = np.maximum(f32(0.0), np.minimum((bins - lo) / (ce - lo), (up - bins) / (up - ce)))
+    return np.concatenate([np.zeros((1, cfg.num_mel_bins), f32), m], axis=0).astype(np.float64)
+
+
+def test_hann_window_and_mel_matrix_precision():
+    """App. A.1 steps 2 and 5: window / mel matrix computed in f32 instead of f64 (then used in f32 either way)."""
+    arch, p, s = _net()
+    wav = R.synth_waveforms(6, seed=31)
+    for cfg in (R.FRONTEND_4020, R.FRONTEND_3010):
+        base = R.mfcc(wav, cfg)
+        i = np.arange(cfg.win, dtype=np.float32)
+        w32 = (np.float32(0.5) - np.float32(0.5) * np.cos(np.float32(2.0 * math.pi) * i / np.float32(cfg.win), dtype=np.float32)).astype(np.float64)
+        alts = {"hann f32": _mfcc_with(wav, cfg, window=w32), "mel f32": _mfcc_with(wav, cfg, mel=_mel_f32(cfg)),
+                "both": _mfcc_with(wav, cfg, window=w32, mel=_mel_f32(cfg), log_offset_f32=True)}
+        ref = R.forward(arch, p, s, base, False)["logits"]
+        for name, x in alts.items():
+            d_mfcc = np.abs(x - base).max()
+            d_logit = np.abs(R.forward(arch, p, s, x, False)["logits"] - ref).max()
+            assert d_mfcc < 1e-4 and d_logit < 1e-4, (name, cfg.win, d_mfcc, d_logit)
+            assert np.array_equal(R.forward(arch, p, s, x, False)["logits"].argmax(1), ref.argmax(1))
+
+
+def test_dropout_div_versus_reciprocal():
+    """App. A.2: tf.nn.dropout computes div(x, keep_prob) * mask; x * (1 / keep_prob) differs by one f32 rounding."""
+    rng = np.random.RandomState(0)
+    x = rng.randn(4096, 48).astype(np.float32)
+    a = x / np.float32(0.5), x * (np.float32(1.0) / np.float32(0.5))
+    assert np.array_equal(*a)                                    # keep_prob 0.5 (every reference script): exactly equal
+    b = x / np.float32(0.9), x * (np.float32(1.0) / np.float32(0.9))
+    assert np.abs(b[0] - b[1]).max() <= np.abs(x).max() * 2.0 ** -23 * 2
+
+
+def test_moving_variance_estimator():
+    """App. A.2: FusedBatchNorm hands the UNBIASED batch variance to the moving average (what the oracle and the kernels do); the
+    other reading is the biased one.  ONE update differs by (1 - decay) * var / (n - 1): far inside 1e-4 at the reference's batch
+    (100 x 98 positions).  But the moving variance converges to var * n / (n - 1) instead of var, and through ten BN layers
+    that moves the eval-mode logits of a trained model by ~5e-3 at batch 100 -- per-step parity (what the tests pin) is
+    unaffected, end-to-end parity of a trained checkpoint is not: THE first thing to re-verify against a TF run."""
+    decay = R.BN_DECAY_TCRESNET
+    for n, bound in ((100 * 98, 1e-6), (4096 * 49, 1e-7), (7, None)):
+        var = 1.7
+        unbiased = 1.0 - (1.0 - decay) * (1.0 - var * n / (n - 1))
+        biased = 1.0 - (1.0 - decay) * (1.0 - var)
+        d = abs(unbiased - biased)
+        assert abs(d - (1.0 - decay) * var / (n - 1)) < 1e-12
+        if bound is not None:
+            assert d < bound
+        else:
+            assert d > 1e-4                                      # flagged: batch-1 statistics over 7 positions
+    # steady state (many steps on a stationary batch): moving_var -> var * n / (n - 1) vs var; effect on eval logits at the
+    # reference's training batch size
+    arch, p, s = _net(3)
+    x = R.mfcc(R.synth_waveforms(4, seed=9), R.FRONTEND_3010)
+    base = R.forward(arch, p, s, x, False)["logits"]
+    n_small = {c.name: 100 * t for c, t in zip([c for c in arch.convs() if c.bn], [98, 49, 49, 49, 25, 25, 25, 13, 13, 13])}
+    s2 = dict(s)
+    for c in arch.convs():
+        if c.bn:
+            k = f"{arch.scope}/{c.name}/BatchNorm/moving_variance"
+            s2[k] = s[k] * (n_small[c.name] - 1) / n_small[c.name]
+    d = np.abs(R.forward(arch, p, s2, x, False)["logits"] - base).max()
+    assert 1e-4 < d < 1e-2          # measured 5e-3: ABOVE the 1e-4 bar -> the estimator decides eval-mode parity of a trained model
+
+
+def test_same_padding_asymmetry_matters():
+    """App. A.2: the extra SAME-padding element goes on the HIGH side (T = 98, k = 9, s = 2 -> (3, 4)).  Unlike the items above this
+    one is not subtle: putting it on the low side moves the logits by orders of magnitude more than the parity bar, so any
+    mistake here would have been caught by a single TF vector."""
+    arch, p, s = _net()
+    x = R.mfcc(R.synth_waveforms(2, seed=5), R.FRONTEND_3010)
+    ref = R.forward(arch, p, s, x, False)["logits"]
+    orig = R.same_pad
+    try:
+        def low_side(length, k, stride):
+            out, lo, hi = orig(length, k, stride)
+            return out, hi, lo
+        R.same_pad = low_side
+        alt = R.forward(arch, p, s, x, False)["logits"]
+    finally:
+        R.same_pad = orig
+    assert np.abs(alt - ref).max() > 1e-2
