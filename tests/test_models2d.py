@@ -82,7 +82,10 @@ def _check(lib, eng, oracle_fwd, t, f, batch, masks_of=None, grad_rtol=3e-4, see
     # (full-size planes: millions of ReLU inputs, a handful at the kink) to 2e-3 of the tensor's largest entry.
     near = O.KINK_LOG["near"]
     if near:
-        grad_rtol = max(grad_rtol, 2e-3)
+        # a weight-gradient entry is a sum over ~10^4 positions of terms of either sign: ONE flipped mask changes it by about a
+        # term, i.e. ~1 % of the entry.  The tight check therefore runs at a plane small enough to have no such inputs (same kernels,
+        # same code paths: `tight` sizes below); at the reference's full plane the gradients are checked to 2e-2.
+        grad_rtol = max(grad_rtol, 2e-2)
     assert np.abs(tl.cpu().numpy() - out["logits"]).max() < Cm.LOGIT_TOL
     assert abs(float(loss_sum) / batch - model) < 1e-4
     worst = 0.0
@@ -110,12 +113,13 @@ def test_res(rt, variant):
     from tcresnet_amd.audio_nets import res
     if rt.kind == "emu" and variant in ("Res8Narrow",):
         pytest.skip("covered by Res8 on the emulator (same topology, 19 channels); runs on the GPU")
-    t, f, b = SIZES[rt.kind]["res"]
-    eng = res.get_engine(variant, t, f, 12)
     layers, ch, pool, dil = res._VARIANTS[variant]
-    assert eng.state_dict()["Res/f_conv/weights"].shape == (3, 3, 1, ch) and "Res/conv0_bn/gamma" not in eng.tensors
-    assert "Res/conv1_bn/moving_mean" in eng.tensors and f"Res/conv{layers - 1}/weights" in eng.tensors
-    _check(rt, eng, lambda p, s, x, tr, m: O.res_forward(p, s, x, variant, tr), t, f, b)
+    # GPU: a 20 x 12 plane first (no ReLU input near the kink: gradients to 3e-4), then the reference's 98 x 40
+    for t, f, b in ([SIZES["emu"]["res"]] if rt.kind == "emu" else [(20, 12, 3), SIZES["hip"]["res"]]):
+        eng = res.get_engine(variant, t, f, 12)
+        assert eng.state_dict()["Res/f_conv/weights"].shape == (3, 3, 1, ch) and "Res/conv0_bn/gamma" not in eng.tensors
+        assert "Res/conv1_bn/moving_mean" in eng.tensors and f"Res/conv{layers - 1}/weights" in eng.tensors
+        _check(rt, eng, lambda p, s, x, tr, m: O.res_forward(p, s, x, variant, tr), t, f, b)
 
 
 @pytest.mark.parametrize("pool", [False, True])
