@@ -32,20 +32,23 @@ for tag, win, hop in (("4020", 640, 320), ("3010", 480, 160)):
     feat = fe(wav)
     for name, ch in (("TCResNet8", [16, 24, 32, 48]), ("TCResNet14", [24, 36, 36, 48, 48, 72, 72])):
         outs = {}
-        for knob in (1, 0):
+        for knob, bknob in ((1, 0), (0, 0), (0, 1)):
             lib.tcr_tune(8, knob)
+            lib.tcr_tune(9, bknob)
             net = T.TCResNet(name, ch, 40, fe.n_frames, 12, device=dev)
             net.init_xavier(0)
             lg, _, loss = net.forward_train(feat, lab, keep_prob=0.5, seed=1)
             g = net.backward().clone()
-            outs[knob] = (lg.clone(), g, net.stats.clone())
+            outs[(knob, bknob)] = (lg.clone(), g, net.stats.clone())
             tf = timeit(lambda: net.forward_train(feat, lab, keep_prob=0.5, seed=1))
 
             def train():
                 net.forward_train(feat, lab, keep_prob=0.5, seed=1); net.backward(); net.sgd_momentum_step(0.1, 0.9, 0.001)
             tt = timeit(train)
-            print(f"{tag} {name}-{ch[0]} train_fwd={'phases' if knob == 0 else 'per-layer'}: forward {tf:8.1f} us   step {tt:8.1f} us", flush=True)
+            tb = timeit(lambda: (net.forward_train(feat, lab, keep_prob=0.5, seed=1), net.backward()))
+            print(f"{tag} {name}-{ch[0]} fwd={'phases' if knob == 0 else 'per-layer'} bwd={'phases' if bknob == 1 else 'per-layer'}: forward {tf:8.1f} us   fwd+bwd {tb:8.1f} us   step {tt:8.1f} us", flush=True)
             del net
-        d = [float((a - b).abs().max()) for a, b in zip(outs[0], outs[1])]
-        print(f"   max |phases - per-layer|: logits {d[0]:.2e} grads {d[1]:.2e} (max |g| {float(outs[1][1].abs().max()):.2e}) stats {d[2]:.2e}", flush=True)
+        d = [float((a - b).abs().max()) for a, b in zip(outs[(0, 1)], outs[(1, 0)])]
+        print(f"   max |phases - per-layer|: logits {d[0]:.2e} grads {d[1]:.2e} (max |g| {float(outs[(1, 0)][1].abs().max()):.2e}) stats {d[2]:.2e}", flush=True)
 lib.tcr_tune(8, 0)
+lib.tcr_tune(9, 0)

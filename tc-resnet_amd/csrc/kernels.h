@@ -138,6 +138,7 @@ struct FusedArgs {
 int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, int ring, hipStream_t s);
 
 // ---- train_fused.hip : group-resident phases of the train-mode forward ---------------------------
+constexpr int kPhaseMaxRows = 1024;     // partial rows (= workgroups) a phase may write per BN layer
 struct PhaseSrc {           // how a phase's input activation X [c][t] is produced while it is staged into LDS
     int kind;               // 0: plain rows `a` (features, or an already materialised activation); 1: relu(bn(a)); 2: relu(bn(a) + S)
     const float* a;         // [B][c][tp]
@@ -163,11 +164,58 @@ struct TrainPhaseArgs {
     int n_layers;           // 0: staging only (materialise X / S)
     PhaseLayer layer[2];
     int batch;
-    int group, n_groups, in_sz, cstat, stat_off;     // (set by the launcher)
+    int group, n_groups, in_sz, cstat, stat_off, nw; // (set by the launcher)
 };
 // rows_out: partial rows written per layer (= workgroups).  Returns 1 when the phase does not fit (nothing launched).
 int launch_train_phase(TrainPhaseArgs a, int* rows_out, hipStream_t s);
 int train_phase_rows(const TrainPhaseArgs& a);      // the same number without launching (-1: does not fit)
+
+// ---- train_fused_bwd.hip : group-resident phases of the backward pass -----------------------------
+struct BwdSrc {             // a gradient wrt a conv's raw output, built while it is staged: dy = k1 (dz - k2 - (raw - mean) k3)
+    int kind;               // 0: unused; 1: from (da, masks, raw, coefficients); 2: plain rows `da` (an already materialised dy)
+    const float* da;        // gradient wrt the unit's activation [B][c][tp] (or [B][c] when bcast)
+    int bcast;
+    const float* m1;        // ReLU mask sources (activation > 0), or nullptr
+    const float* m2;
+    const float* raw;
+    const float* mean;
+    const float* k1;
+    const float* k2;
+    const float* k3;
+    float* out_dy;          // where dy is materialised (halo zeroed) for the weight-gradient kernels, or nullptr
+    int c, t;
+};
+struct BwdLayer {           // data gradient of one conv, accumulated into the phase's dx rows
+    int src;                // index of the staged dy
+    int k, stride, pad_lo;
+    int cin, tin;           // channels / frames of dx (the conv's input)
+    int cout, tout;         // channels / frames of dy (the conv's output)
+    const float* wt;        // re-arranged weights (launch_dgrad_weights_multi)
+};
+struct BwdStat {            // sums of the BN unit whose output activation dx is the gradient of
+    int on;
+    const float* m1;
+    const float* m2;
+    const float* raw;
+    const float* mean;
+    const float* invstd;
+    float* partial;         // [rows][2][out_c]
+};
+struct TrainBwdPhaseArgs {
+    BwdSrc src[2];
+    int n_layers;           // 0: staging only (materialise dy)
+    BwdLayer layer[2];
+    int out_c, out_t;
+    float* out_dx;          // [B][out_c][tp]
+    const float* add;       // identity shortcut: dx += add [add_mask > 0]; [B][out_c][tp] or [B][out_c] (add_bcast)
+    const float* add_mask;
+    int add_bcast;
+    BwdStat stat[2];
+    int batch;
+    int group, n_groups, src_sz[2], out_sz, src_off[2], out_off, cstat, stat_off, tpc, nw;      // (set by the launcher)
+};
+int launch_train_bwd_phase(TrainBwdPhaseArgs a, int* rows_out, hipStream_t s);       // 1: does not fit (nothing launched)
+int train_bwd_phase_rows(const TrainBwdPhaseArgs& a);                                // -1: does not fit
 
 // ---- bn.hip ---------------------------------------------------------------------------------
 constexpr int kBnMaxLayers = 40;

@@ -106,10 +106,10 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
         wgmax = wg > wgmax ? wg : wgmax;
     }
     if (train) {
-        w.partial = take((int64_t)512 * 2 * cmax);
+        w.partial = take((int64_t)kPhaseMaxRows * 2 * cmax);
         w.sums = take(2 * 2 * cmax);        // doubles
         w.kcoef = take(3 * (int64_t)align_up(cmax, 64));
-        w.partial2 = take((int64_t)512 * 2 * cmax);
+        w.partial2 = take((int64_t)kPhaseMaxRows * 2 * cmax);
         w.kcoef2 = take(3 * (int64_t)align_up(cmax, 64));
         const int c = net.feat_c, nc = net.cfg.num_classes;
         w.dropped = take((int64_t)batch * c);
@@ -958,6 +958,134 @@ static std::vector<int> backward_order(const tcr_net& net) {
     return order;
 }
 
+// ---- group-resident backward phases (train_fused_bwd.hip) ---------------------------------------------------------------------
+// dy of unit `li`, built while a phase stages it (kc: the unit's k1 / k2 / k3 rows left by bn_bwd_finalize)
+static BwdSrc bwd_src_of_unit(const TrainCtx& c, int li, const float* dpool, const float* kc) {
+    const ConvLayer& l = c.net->layers[li];
+    const BwdUnit u = bwd_unit_of(c, li, dpool);
+    const int64_t ks = align_up(l.cout, 64);
+    BwdSrc s;
+    std::memset(&s, 0, sizeof(s));
+    s.kind = 1; s.da = u.da; s.bcast = u.da_bcast; s.m1 = u.m1; s.m2 = u.m2;
+    s.raw = c.base + c.w.raw[li]; s.mean = c.base + c.w.mean[li];
+    s.k1 = kc; s.k2 = kc + ks; s.k3 = kc + 2 * ks;
+    s.out_dy = c.base + c.w.dyb[li]; s.c = l.cout; s.t = l.tout;
+    return s;
+}
+
+static BwdLayer bwd_layer_of(const TrainCtx& c, int li, int src) {
+    const ConvLayer& l = c.net->layers[li];
+    BwdLayer b;
+    b.src = src; b.k = l.k; b.stride = l.stride; b.pad_lo = l.pad_lo; b.cin = l.cin; b.tin = l.tin; b.cout = l.cout; b.tout = l.tout;
+    b.wt = c.base + c.w.wtl[li];
+    return b;
+}
+
+static BwdStat bwd_stat_of(const TrainCtx& c, int li, const float* dpool, float* partial) {
+    const BwdUnit u = bwd_unit_of(c, li, dpool);
+    BwdStat t;
+    t.on = 1; t.m1 = u.m1; t.m2 = u.m2; t.raw = c.base + c.w.raw[li]; t.mean = c.base + c.w.mean[li]; t.invstd = c.base + c.w.invstd[li];
+    t.partial = partial;
+    return t;
+}
+
+// D1 of block bi: dy of conv_b -> its data gradient = the gradient wrt conv_a's activation; statistics of conv_a's BN backward.
+static TrainBwdPhaseArgs bwd_phase_d1(const TrainCtx& c, int bi, const float* dpool) {
+    const tcr_net& net = *c.net;
+    const Block& b = net.blocks[bi];
+    TrainBwdPhaseArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = c.batch;
+    a.src[0] = bwd_src_of_unit(c, b.b, dpool, c.base + c.w.kcoef);
+    a.n_layers = 1; a.layer[0] = bwd_layer_of(c, b.b, 0);
+    a.out_c = net.layers[b.b].cin; a.out_t = net.layers[b.b].tin; a.out_dx = c.base + c.w.gact[b.a];
+    a.stat[0] = bwd_stat_of(c, b.a, dpool, c.base + c.w.partial);
+    return a;
+}
+
+// D2 of block bi: dy of conv_a (and of the `down` shortcut) -> their data gradients summed (+ the identity shortcut's gradient) =
+// the gradient wrt the block input; statistics of the BN backward(s) of the units that produced that input.
+static TrainBwdPhaseArgs bwd_phase_d2(const TrainCtx& c, int bi, const float* dpool) {
+    const tcr_net& net = *c.net;
+    const Block& b = net.blocks[bi];
+    const ConvLayer& la = net.layers[b.a];
+    TrainBwdPhaseArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = c.batch;
+    a.src[0] = bwd_src_of_unit(c, b.a, dpool, c.base + c.w.kcoef);
+    a.n_layers = 1; a.layer[0] = bwd_layer_of(c, b.a, 0);
+    if (b.down >= 0) {
+        a.src[1] = bwd_src_of_unit(c, b.down, dpool, c.base + c.w.kcoef2);
+        a.n_layers = 2; a.layer[1] = bwd_layer_of(c, b.down, 1);
+    } else {                    // identity shortcut: + dOut [out > 0]
+        const BwdUnit ub = bwd_unit_of(c, b.b, dpool);
+        a.add = ub.da; a.add_bcast = ub.da_bcast; a.add_mask = c.base + c.w.act[b.b];
+    }
+    const int in_act = la.in_act;               // conv0 (bi == 0) or the previous block's conv_b
+    a.out_c = la.cin; a.out_t = la.tin; a.out_dx = c.base + c.w.gact[in_act];
+    if (bi == 0) {
+        a.stat[0] = bwd_stat_of(c, 0, dpool, c.base + c.w.partial);
+    } else {
+        const Block& pb = net.blocks[bi - 1];
+        a.stat[0] = bwd_stat_of(c, pb.b, dpool, c.base + c.w.partial);
+        if (pb.down >= 0) a.stat[1] = bwd_stat_of(c, pb.down, dpool, c.base + c.w.partial2);
+    }
+    return a;
+}
+
+// closing phase: dy of conv0 (its weight gradient is all that is left; no gradient flows into the features)
+static TrainBwdPhaseArgs bwd_phase_d0(const TrainCtx& c, const float* dpool) {
+    TrainBwdPhaseArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = c.batch;
+    a.src[0] = bwd_src_of_unit(c, 0, dpool, c.base + c.w.kcoef);
+    a.n_layers = 0;
+    return a;
+}
+
+static bool bwd_phases_usable(const TrainCtx& c, const float* dpool) {
+    if (tune_get(TCR_TUNE_TRAIN_BWD) != 1 || tune_get(TCR_TUNE_CONV_PATH) == 1) return false;      // (opt-in: measured slower)
+    const tcr_net& net = *c.net;
+    for (size_t bi = 0; bi < net.blocks.size(); ++bi) {
+        for (int li : {net.blocks[bi].down, net.blocks[bi].a, net.blocks[bi].b})
+            if (li >= 0 && !conv_dgrad_mfma_covers(net.layers[li].k, net.layers[li].stride, net.layers[li].cout)) return false;
+        if (train_bwd_phase_rows(bwd_phase_d1(c, (int)bi, dpool)) < 0 || train_bwd_phase_rows(bwd_phase_d2(c, (int)bi, dpool)) < 0) return false;
+    }
+    return train_bwd_phase_rows(bwd_phase_d0(c, dpool)) >= 0;
+}
+
+// partial rows the statistics of unit `li` arrive in, and their count
+static float* bwd_partial_of(const TrainCtx& c, int li) {
+    for (const Block& b : c.net->blocks) if (b.down == li) return c.base + c.w.partial2;
+    return c.base + c.w.partial;
+}
+static int bwd_rows_of(const TrainCtx& c, int li, const float* dpool) {
+    const tcr_net& net = *c.net;
+    const int nb = (int)net.blocks.size();
+    if (li == net.blocks[nb - 1].b || li == net.blocks[nb - 1].down) return chan_reduce_launch_chunks(c.batch * net.layers[li].tout);
+    if (li == 0) return train_bwd_phase_rows(bwd_phase_d2(c, 0, dpool));
+    for (int bi = 0; bi < nb; ++bi) {
+        if (li == net.blocks[bi].a) return train_bwd_phase_rows(bwd_phase_d1(c, bi, dpool));
+        if (li == net.blocks[bi].b || li == net.blocks[bi].down) return train_bwd_phase_rows(bwd_phase_d2(c, bi + 1, dpool));
+    }
+    return -1;
+}
+
+// BN backward finalize of unit `li` from `rows` partial rows (or the cross-replica sums): dgamma / dbeta + the k1 / k2 / k3 rows
+static int bwd_finalize(const TrainCtx& c, int li, float* grads, float* partial, float* kc, int rows) {
+    const ConvLayer& l = c.net->layers[li];
+    const int64_t kstride = align_up(l.cout, 64);
+    BnBwdFinalizeArgs f;
+    f.partial = partial;
+    f.nchunk = c.sync_bn ? 0 : rows;
+    f.sums = reinterpret_cast<const double*>(c.base + c.w.sums); f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[li];
+    f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
+    f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
+    f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
+    f.grad_scale = (float)((double)c.batch / c.bn_batch);
+    return launch_bn_bwd_finalize(f, c.s);
+}
+
 }  // namespace tcr
 
 static int backward_stages(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch, int sync_bn,
@@ -980,6 +1108,22 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     const int nu = (int)order.size();
     TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);
     const float* dpool = c.base + c.w.dpool;
+    const bool bwd_phases = bwd_phases_usable(c, dpool);
+    auto reduce_slabs = [&]() -> int {      // every layer's split-K slabs -> dW, one launch (after the side stream has drained)
+        if (c.side != c.s && (hipEventRecord(net->ev_join, c.side) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join, 0) != hipSuccess)) {
+            set_error("tcr_net_backward: stream join failed");
+            return TCR_ERR_HIP;
+        }
+        WgradReduceMulti rm;
+        rm.n = 0;
+        for (int li : order) {
+            const ConvLayer& l = net->layers[li];
+            if (!conv_wgrad_deferrable(l.k, l.cin, l.cout)) continue;
+            if (rm.n == kMultiMax) { TCR_TRY(launch_wgrad_reduce_multi(rm, c.s)); rm.n = 0; }
+            rm.e[rm.n++] = conv_wgrad_entry(l.k, l.cin, l.cout, batch, c.base + c.w.wg[li], grads + l.w_off);
+        }
+        return launch_wgrad_reduce_multi(rm, c.s);
+    };
     for (int st = stage_begin; st < stage_end; ++st) {
         if (st == 0) {
             // head: zero the arena (padding + fc2, which gets no loss gradient), fc wgrad, pooled gradient
@@ -1001,6 +1145,41 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
                 dm.e[dm.n++] = {params + l.w_off, c.base + c.w.wtl[li], l.k, l.cin, l.cout, l.stride, l.pad_lo};
             }
             TCR_TRY(launch_dgrad_weights_multi(dm, c.s));
+        }
+        if (bwd_phases) {
+            // Group-resident phases.  Per unit, in `order` (block: conv_b, conv_a, down):
+            //   pre  = the unit's sums exist as partial rows (written by an earlier phase; the last block's by a reduce here)
+            //   post = finalize; then conv_b: D1, conv_a of an identity block / down: D2; conv0: the closing phase.
+            // The weight gradients follow their dy on the side stream.
+            const int nb = (int)net->blocks.size();
+            auto block_of = [&](int li) { for (int bi = 0; bi < nb; ++bi) { const Block& b = net->blocks[bi]; if (li == b.b || li == b.a || li == b.down) return bi; } return -1; };
+            if (st > 0) {
+                const int li = order[st - 1];
+                const int bi = block_of(li);
+                const bool is_dn = bi >= 0 && net->blocks[bi].down == li;
+                TCR_TRY(bwd_finalize(c, li, grads, bwd_partial_of(c, li), c.base + (is_dn ? c.w.kcoef2 : c.w.kcoef), bwd_rows_of(c, li, dpool)));
+                if (li == 0) {
+                    TCR_TRY(launch_train_bwd_phase(bwd_phase_d0(c, dpool), nullptr, c.s));
+                    TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, 0, dpool), grads, dpool, BWD_WGRAD, c.s, nullptr, nullptr));
+                } else if (li == net->blocks[bi].b) {
+                    TCR_TRY(launch_train_bwd_phase(bwd_phase_d1(c, bi, dpool), nullptr, c.s));
+                    TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, li, dpool), grads, dpool, BWD_WGRAD, c.s, nullptr, nullptr));
+                } else if (is_dn || (li == net->blocks[bi].a && net->blocks[bi].down < 0)) {
+                    TCR_TRY(launch_train_bwd_phase(bwd_phase_d2(c, bi, dpool), nullptr, c.s));
+                    TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, net->blocks[bi].a, dpool), grads, dpool, BWD_WGRAD, c.s, nullptr, nullptr));
+                    if (is_dn) TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, li, dpool), grads, dpool, BWD_WGRAD, c.s, nullptr, nullptr));
+                }
+            }
+            if (st < nu) {
+                const int li = order[st];
+                if (li == net->blocks[nb - 1].b || li == net->blocks[nb - 1].down)      // (gradient of the pooled head, broadcast over time)
+                    TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, li, dpool), c.s, bwd_partial_of(c, li)));
+                else if (c.sync_bn)
+                    TCR_TRY(launch_chan_sums(bwd_partial_of(c, li), bwd_rows_of(c, li, dpool), net->layers[li].cout,
+                                             reinterpret_cast<double*>(c.base + c.w.sums), c.s));
+            }
+            if (st == nu) TCR_TRY(reduce_slabs());
+            continue;
         }
         // Without cross-replica statistics the shortcut ("down") unit of a block is started EARLY on the side stream: its BN
         // backward and weight gradient depend only on the block-output gradient, which is ready when the block begins; only
@@ -1035,21 +1214,7 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
             }
             if (!(early && is_down(li))) TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, li, dpool), c.s, partial));
         }
-        if (st == nu) {         // every layer's split-K slabs -> dW, one launch (after the side stream has drained)
-            if (c.side != c.s && (hipEventRecord(net->ev_join, c.side) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join, 0) != hipSuccess)) {
-                set_error("tcr_net_backward: stream join failed");
-                return TCR_ERR_HIP;
-            }
-            WgradReduceMulti rm;
-            rm.n = 0;
-            for (int li : order) {
-                const ConvLayer& l = net->layers[li];
-                if (!conv_wgrad_deferrable(l.k, l.cin, l.cout)) continue;
-                if (rm.n == kMultiMax) { TCR_TRY(launch_wgrad_reduce_multi(rm, c.s)); rm.n = 0; }
-                rm.e[rm.n++] = conv_wgrad_entry(l.k, l.cin, l.cout, batch, c.base + c.w.wg[li], grads + l.w_off);
-            }
-            TCR_TRY(launch_wgrad_reduce_multi(rm, c.s));
-        }
+        if (st == nu) TCR_TRY(reduce_slabs());
     }
     return TCR_OK;
 }

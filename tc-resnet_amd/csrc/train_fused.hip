@@ -236,11 +236,13 @@ static bool configure_phase(TrainPhaseArgs& a, size_t* lds_out, int* grid_out) {
         cstat = max(cstat, (a.layer[i].cout + 15) / 16 * 16);
     }
     if ((int64_t)S.c * tp * 64 >= (1 << 22)) return false;      // (fast_div range of the staging index)
-    constexpr int NW = 8;
+    const int knob = tune_get(TCR_TUNE_PHASE_CFG);
+    const int NW = knob / 100 == 4 ? 4 : 8;
+    a.nw = NW;
     // Utterances per group: as many as keep the LDS footprint <= 40 KB (3-4 workgroups per CU), at most 8 -- and few enough
-    // that the grid still has >= 512 workgroups (one partial row each; bn_finalize sums at most 512 rows).
+    // that the grid still has >= 512 workgroups (one partial row each).
     const size_t stat_bytes = (size_t)NW * max(a.n_layers, 1) * 2 * cstat * sizeof(float);
-    int group = 8;
+    int group = knob % 100 > 0 ? knob % 100 : 8;
     while (group > 1 && ((size_t)group * in_sz + 64) * sizeof(float) + stat_bytes > 40 * 1024) --group;
     while (group > 1 && ceil_div(a.batch, group) < 512) --group;
     const size_t lds = ((size_t)group * in_sz + 64) * sizeof(float) + stat_bytes;
@@ -248,7 +250,7 @@ static bool configure_phase(TrainPhaseArgs& a, size_t* lds_out, int* grid_out) {
     a.group = group; a.n_groups = ceil_div(a.batch, group); a.in_sz = in_sz; a.cstat = cstat;
     a.stat_off = group * in_sz + 64;
     *lds_out = lds;
-    *grid_out = min(a.n_groups, 512);
+    *grid_out = min(a.n_groups, kPhaseMaxRows);
     return true;
 }
 
@@ -264,7 +266,7 @@ int launch_train_phase(TrainPhaseArgs a, int* rows_out, hipStream_t s) {
     int grid;
     if (!configure_phase(a, &lds, &grid)) return 1;
     if (rows_out) *rows_out = grid;
-    void (*kern)(const TrainPhaseArgs) = train_phase_kernel<8, 4>;
+    void (*kern)(const TrainPhaseArgs) = a.nw == 4 ? train_phase_kernel<4, 4> : train_phase_kernel<8, 4>;
 #if !defined(TCR_HOST_EMULATION)
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -273,7 +275,7 @@ int launch_train_phase(TrainPhaseArgs a, int* rows_out, hipStream_t s) {
         }
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(8 * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(a.nw * 64), lds, s, a);
     return check_launch("train_phase_kernel");
 }
 

@@ -121,3 +121,15 @@ def test_staged_sync_bn_api_is_bitwise_the_unstaged_path(emu_lib):
 def test_wide_net_training(emu_lib):
     """width_multiplier 2.0: 96 output channels take the non-deferrable weight-gradient branch."""
     Cm.check_small_batch(emu_lib, 3, name="TCResNet8", width=2.0, seeds=range(100, 103))
+
+
+def test_backward_phases_opt_in(emu_lib):
+    """TCR_TUNE_TRAIN_BWD = 1: the group-resident backward phases (an alternative kept behind the knob) against the fixtures, and
+    through the staged sync-BN API bitwise like the unstaged run."""
+    try:
+        emu_lib.tcr_tune(9, 1)
+        Cm.check_train(emu_lib, "tcresnet8_1.0_4020.npz", "TCResNet8", 1.0, steps=1)
+        Cm.check_train(emu_lib, "tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, steps=1)
+        Cm.check_staged_equals_unstaged(emu_lib, "TCResNet8", 1.0, batch=5)
+    finally:
+        emu_lib.tcr_tune(9, 0)

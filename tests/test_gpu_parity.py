@@ -329,3 +329,32 @@ def test_wide_net_training(hip_lib):
         net.forward_train(feat, lab, keep_prob=0.5, seed=1)
         grads.append(net.backward().clone())
     assert all(torch.equal(grads[0], g) for g in grads[1:])
+
+
+def test_train_paths_agree(hip_lib):
+    """Train-mode forward as group-resident phases (default) vs per-layer kernels (TCR_TUNE_TRAIN_FWD = 1), backward per-layer (default)
+    vs group-resident phases (TCR_TUNE_TRAIN_BWD = 1): same logits / gradients up to f32 re-association, each path against the oracle
+    fixture, each bitwise reproducible."""
+    fx = Cm.load("tcresnet8_1.0_4020.npz")
+    arch, p, s = Cm.fixture_params(fx, "TCResNet8", 1.0)
+    fe = Cm.make_frontend(hip_lib, fx["win"], fx["hop"])
+    feat = fe(Cm.to_dev(hip_lib, np.tile(fx["wav"], (256, 1))))
+    labels = Cm.to_dev(hip_lib, np.tile(fx["labels"], (256, 1)))
+    outs = {}
+    try:
+        for fwd, bwd in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            hip_lib.tcr_tune(8, fwd); hip_lib.tcr_tune(9, bwd)
+            Cm.check_train(hip_lib, "tcresnet8_1.0_4020.npz", "TCResNet8", 1.0, steps=1)
+            Cm.check_train(hip_lib, "tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, steps=1)
+            runs = []
+            for _ in range(2):
+                net = Cm.make_net(hip_lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+                lg, _, loss = net.forward_train(feat, labels, keep_prob=0.5, seed=4)
+                runs.append((lg.clone(), net.backward().clone(), net.stats.clone()))
+            assert all(torch.equal(a, b) for a, b in zip(*runs)), (fwd, bwd)
+            outs[(fwd, bwd)] = runs[0]
+    finally:
+        hip_lib.tcr_tune(8, 0); hip_lib.tcr_tune(9, 0)
+    ref = outs[(0, 0)]
+    for k, o in outs.items():
+        assert (o[0] - ref[0]).abs().max() < 1e-4 and (o[1] - ref[1]).abs().max() < 2e-4 * max(1.0, float(ref[1].abs().max())), k
