@@ -111,8 +111,8 @@ SIZES = {"emu": {"res": (12, 10, 2), "res2d": (12, 10, 2), "res2dpool": (40, 24,
 @pytest.mark.parametrize("variant", ["Res8", "Res15", "Res8Narrow", "Res15Narrow"])
 def test_res(rt, variant):
     from tcresnet_amd.audio_nets import res
-    if rt.kind == "emu" and variant in ("Res8Narrow",):
-        pytest.skip("covered by Res8 on the emulator (same topology, 19 channels); runs on the GPU")
+    if rt.kind == "emu" and variant in ("Res8Narrow", "Res15"):
+        pytest.skip("the emulator runs Res8 (45 channels, pool) and Res15Narrow (19 channels, dilation); all four run on the GPU")
     layers, ch, pool, dil = res._VARIANTS[variant]
     # GPU: a 20 x 12 plane first (no ReLU input near the kink: gradients to 3e-4), then the reference's 98 x 40
     for t, f, b in ([SIZES["emu"]["res"]] if rt.kind == "emu" else [(20, 12, 3), SIZES["hip"]["res"]]):
@@ -141,6 +141,8 @@ def test_resnet2d8(rt, pool):
 def test_kws(rt, arch):
     from tcresnet_amd.audio_nets import kws
     t, f, b = SIZES[rt.kind]["kws"]
+    if rt.kind == "emu" and arch == "conv":
+        t, f = 16, 10                    # (two SAME 64-channel convs: the heaviest graph for the emulator)
     ms = {"spectrogram_length": t, "fingerprint_width": f, "label_count": 12, "fingerprint_size": t * f}
     eng = kws.get_engine(ms, arch)
     nodes = eng.dropout_nodes
