@@ -235,6 +235,16 @@ int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params, float* st
  * pointwise biases feed a train-mode BN, so their gradient is identically zero and is written as 0. */
 int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, const float* feat, int batch,
                        void* workspace, size_t workspace_bytes, float* grads, void* stream);
+/* Cross-replica (sync) BN for DS-CNN, as tcr_net_*_stage: stage u of the forward ends with unit u's {sum y, sum y^2} (2*C float64) in
+ * the hand-off buffer, stage k of the backward with {sum dz, sum dz*xhat} of unit (units-1-k); the host all-reduces them between stages.
+ * tcr_dscnn_num_stages() stages each way; with one replica the staged run is bitwise the unstaged one. */
+int tcr_dscnn_num_stages(const tcr_dscnn* net);
+int tcr_dscnn_stage_sums(const tcr_dscnn* net, int backward, int stage, void* workspace, int batch, double** sums_dev, int64_t* n_doubles);
+int tcr_dscnn_forward_train_stage(const tcr_dscnn* net, const float* params, float* stats, const float* feat, const float* labels,
+                                  int batch, int global_batch, float label_smoothing, void* workspace, size_t workspace_bytes,
+                                  float* logits, float* probs, float* loss_out, int stage, void* stream);
+int tcr_dscnn_backward_stage(const tcr_dscnn* net, const float* params, const float* feat, int batch, int global_batch,
+                             void* workspace, size_t workspace_bytes, float* grads, int stage, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Generic 2-D layer graph: the other model families behind the factory        */

@@ -7,7 +7,7 @@ A TF `reshape(x, [-1, H*W*C]) @ W[H*W*C, N]` is the VALID convolution of the [H,
 [H, W, C, N] -- the flatten order of NHWC and the HWIO weight layout coincide -- so every matmul is a conv node.
 
 `low_latency_svdf` is not built: its graph keeps a [num_filters, batch = 1, time] runtime-memory variable and only runs at
-batch 1 (kws.py:488-560); none of the reference's scripts uses it."""
+batch 1 (kws.py:490-680; `runtime_settings` is None at :576, so the reference cannot build it for evaluation); none of the reference's scripts uses it."""
 from __future__ import annotations
 
 import math
@@ -58,7 +58,7 @@ def build_model(g: Graph2D, model_settings, model_architecture: str) -> int:
         net = drop(g.conv(-1, (10, 8), 8, "first_weights", stride=(2, 2), padding="SAME", relu=True, biases_name="first_bias", init=TN))
         return _fc(g, net, nc, "final_fc_weights", True)
     if model_architecture == "low_latency_svdf":
-        raise NotImplementedError("low_latency_svdf keeps a batch-1 runtime-memory variable (kws.py:488-560) and is not built")
+        raise NotImplementedError("low_latency_svdf keeps a batch-1 runtime-memory variable (kws.py:490-680; `runtime_settings` is None at :576, so the reference cannot build it for evaluation) and is not built")
     raise Exception('model_architecture argument "' + model_architecture + '" not recognized, should be one of "single_fc", "conv",'
                     ' "low_latency_conv, "one_fstride4", "trad_fpool3", "low_latency_svdf" or "tiny_conv"')
 

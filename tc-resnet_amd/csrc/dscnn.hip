@@ -709,7 +709,7 @@ static std::vector<DsUnit> ds_units(const tcr_dscnn& net) {
 }
 
 struct DsTrainWs {
-    int64_t ss, kcoef, partial, pooled, dropped, dscale, dlogits, loss_utt, dpool, fc_partial, scratch, wt, ga, dz, dz2, total;
+    int64_t ss, kcoef, partial, sums, pooled, dropped, dscale, dlogits, loss_utt, dpool, fc_partial, scratch, wt, ga, dz, dz2, total;
     std::vector<int64_t> raw, act, mean, invstd;
 };
 
@@ -722,6 +722,7 @@ static DsTrainWs ds_carve(const tcr_dscnn& net, int batch) {
     const int cl = net.layers.back().cout;
     w.ss = take(net.ss_floats);
     w.kcoef = take(3 * (int64_t)cp);
+    w.sums = take(2 * 2 * (int64_t)cp);         // doubles: cross-replica BN hand-off
     int maxpos = 0;
     int64_t max_act = 0, scratch = 0;
     for (const DsUnit& u : units) {
@@ -763,9 +764,12 @@ extern "C" size_t tcr_dscnn_train_workspace_bytes(const tcr_dscnn* net, int batc
     return (size_t)ds_carve(*net, batch).total * sizeof(float);
 }
 
-extern "C" int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params, float* stats, const float* feat, const float* labels,
-                                       int batch, int global_batch, float label_smoothing, void* workspace, size_t workspace_bytes,
-                                       float* logits, float* probs, float* loss_out, void* stream) {
+// Stages [stage_begin, stage_end) of the train-mode forward.  Stage u (u < units): finalize + normalise unit u-1, then conv + statistics
+// of unit u; the last stage finalizes the last unit and runs the head.  sync != 0 (cross-replica BN): a stage ends with the unit's
+// 2*C float64 sums in the hand-off buffer, which the host all-reduces before the next stage, and statistics span global_batch.
+static int ds_forward_train_stages(const tcr_dscnn* net, const float* params, float* stats, const float* feat, const float* labels,
+                                   int batch, int global_batch, int sync, float label_smoothing, void* workspace, size_t workspace_bytes,
+                                   float* logits, float* probs, float* loss_out, int stage_begin, int stage_end, void* stream) {
     TCR_REQUIRE(net && params && stats && feat && labels && workspace && logits && probs && loss_out, "tcr_dscnn_forward_train: null argument");
     TCR_REQUIRE(batch > 0 && global_batch >= batch, "tcr_dscnn_forward_train: batch %d / global_batch %d", batch, global_batch);
     const DsTrainWs w = ds_carve(*net, batch);
@@ -777,8 +781,30 @@ extern "C" int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params
     float* base = static_cast<float*>(workspace);
     const std::vector<DsUnit> units = ds_units(*net);
     const int cp = net->c_pad;
-    const float* x = nullptr;               // activation feeding the current unit (nullptr: the features)
-    for (size_t ui = 0; ui < units.size(); ++ui) {
+    const int nu = (int)units.size();
+    TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_dscnn_forward_train: bad stage range [%d, %d)", stage_begin, stage_end);
+    const double bn_batch = sync ? (double)global_batch : (double)batch;
+    // finalize + normalise of unit ui (its partial rows / cross-replica sums are ready)
+    auto post = [&](int ui) -> int {
+        const DsUnit& u = units[ui];
+        const int pp = tcr_padded_len(u.P);
+        float* ss = base + w.ss + u.ss_off;
+        BnFinalizeArgs f;
+        f.partial = base + w.partial; f.nchunk = sync ? 0 : chan_reduce_launch_chunks(batch * u.P);
+        f.sums = reinterpret_cast<const double*>(base + w.sums);
+        f.gamma = nullptr; f.beta = params + u.beta_off;
+        f.moving_mean = stats + u.mean_off; f.moving_var = stats + u.var_off;
+        f.scale = ss; f.shift = ss + cp; f.mean = base + w.mean[ui]; f.invstd = base + w.invstd[ui];
+        f.c = u.c; f.count = bn_batch * (double)u.P; f.decay = net->cfg.bn_decay; f.eps = net->cfg.bn_eps;
+        TCR_TRY(launch_bn_finalize(f, s));
+        BnApplyArgs ap;
+        ap.y = base + w.raw[ui]; ap.scale = ss; ap.shift = ss + cp; ap.res = nullptr; ap.out = base + w.act[ui];
+        ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.relu = 1;
+        return launch_bn_apply(ap, s);
+    };
+    for (int ui = stage_begin; ui < stage_end && ui < nu; ++ui) {
+        if (ui > 0) TCR_TRY(post(ui - 1));
+        const float* x = ui > 0 ? base + w.act[ui - 1] : nullptr;      // activation feeding the unit (nullptr: the features)
         const DsUnit& u = units[ui];
         const DsLayer& l = net->layers[u.layer];
         const int pp = tcr_padded_len(u.P);
@@ -802,26 +828,17 @@ extern "C" int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params
             c1.npos = batch * u.P; c1.cin = l.cin; c1.cout = l.cout; c1.tpi = pp; c1.tout = u.P; c1.tpo = pp; c1.stride = 1; c1.relu = 0;
             TCR_TRY(launch_conv1x1(c1, MF_AFFINE, s));
         }
-        // batch statistics -> scale/shift (+ moving averages), normalise + ReLU
+        // batch statistics of the raw output (the finalize + normalise run at the start of the next stage)
         ChanReduceArgs r;
         std::memset(&r, 0, sizeof(r));
         r.y = raw; r.partial = base + w.partial; r.npos = batch * u.P; r.c = u.c; r.t = u.P; r.tp = pp;
         int nchunk = 0;
         TCR_TRY(launch_chan_reduce(0, r, &nchunk, s));
-        float* ss = base + w.ss + u.ss_off;
-        BnFinalizeArgs f;
-        f.partial = base + w.partial; f.nchunk = nchunk; f.sums = nullptr;
-        f.gamma = nullptr; f.beta = params + u.beta_off;
-        f.moving_mean = stats + u.mean_off; f.moving_var = stats + u.var_off;
-        f.scale = ss; f.shift = ss + cp; f.mean = base + w.mean[ui]; f.invstd = base + w.invstd[ui];
-        f.c = u.c; f.count = (double)batch * (double)u.P; f.decay = net->cfg.bn_decay; f.eps = net->cfg.bn_eps;
-        TCR_TRY(launch_bn_finalize(f, s));
-        BnApplyArgs ap;
-        ap.y = raw; ap.scale = ss; ap.shift = ss + cp; ap.res = nullptr; ap.out = base + w.act[ui];
-        ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.relu = 1;
-        TCR_TRY(launch_bn_apply(ap, s));
-        x = base + w.act[ui];
+        if (sync) TCR_TRY(launch_chan_sums(base + w.partial, nchunk, u.c, reinterpret_cast<double*>(base + w.sums), s));
     }
+    if (stage_end <= nu) return TCR_OK;
+    TCR_TRY(post(nu - 1));
+    const float* x = base + w.act[nu - 1];
     const DsLayer& last = net->layers.back();
     const int P = last.oh * last.ow;
     const int64_t rows = (int64_t)batch * last.cout;
@@ -840,10 +857,41 @@ extern "C" int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params
     return launch_sum_vector(base + w.loss_utt, batch, loss_out, s);
 }
 
-extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, const float* feat, int batch,
-                                  void* workspace, size_t workspace_bytes, float* grads, void* stream) {
+extern "C" int tcr_dscnn_forward_train(const tcr_dscnn* net, const float* params, float* stats, const float* feat, const float* labels,
+                                       int batch, int global_batch, float label_smoothing, void* workspace, size_t workspace_bytes,
+                                       float* logits, float* probs, float* loss_out, void* stream) {
+    const int nu = net ? (int)ds_units(*net).size() : 0;
+    return ds_forward_train_stages(net, params, stats, feat, labels, batch, global_batch, 0, label_smoothing, workspace, workspace_bytes,
+                                   logits, probs, loss_out, 0, nu + 1, stream);
+}
+
+extern "C" int tcr_dscnn_num_stages(const tcr_dscnn* net) { return net ? (int)ds_units(*net).size() + 1 : 0; }
+
+extern "C" int tcr_dscnn_forward_train_stage(const tcr_dscnn* net, const float* params, float* stats, const float* feat, const float* labels,
+                                             int batch, int global_batch, float label_smoothing, void* workspace, size_t workspace_bytes,
+                                             float* logits, float* probs, float* loss_out, int stage, void* stream) {
+    return ds_forward_train_stages(net, params, stats, feat, labels, batch, global_batch, 1, label_smoothing, workspace, workspace_bytes,
+                                   logits, probs, loss_out, stage, stage + 1, stream);
+}
+
+extern "C" int tcr_dscnn_stage_sums(const tcr_dscnn* net, int backward, int stage, void* workspace, int batch, double** sums_dev,
+                                    int64_t* n_doubles) {
+    TCR_REQUIRE(net && workspace && sums_dev && n_doubles, "tcr_dscnn_stage_sums: null argument");
+    const std::vector<DsUnit> units = ds_units(*net);
+    const int nu = (int)units.size();
+    TCR_REQUIRE(stage >= 0 && stage < nu, "tcr_dscnn_stage_sums: stage %d has no BN hand-off", stage);
+    const DsTrainWs w = ds_carve(*net, batch);
+    *sums_dev = reinterpret_cast<double*>(static_cast<float*>(workspace) + w.sums);
+    *n_doubles = 2 * (int64_t)units[backward ? nu - 1 - stage : stage].c;
+    return TCR_OK;
+}
+
+// Stages of backward: stage k handles unit nu-1-k: stage 0 = head + the last unit's sums; stage k > 0 = BN backward / filter + data
+// gradients of unit nu-k, then the sums of unit nu-1-k; the last stage (k = nu) finishes unit 0.
+static int ds_backward_stages(const tcr_dscnn* net, const float* params, const float* feat, int batch, int global_batch, int sync,
+                              void* workspace, size_t workspace_bytes, float* grads, int stage_begin, int stage_end, void* stream) {
     TCR_REQUIRE(net && params && feat && workspace && grads, "tcr_dscnn_backward: null argument");
-    TCR_REQUIRE(batch > 0, "tcr_dscnn_backward: batch must be positive (got %d)", batch);
+    TCR_REQUIRE(batch > 0 && global_batch >= batch, "tcr_dscnn_backward: batch %d / global_batch %d", batch, global_batch);
     const DsTrainWs w = ds_carve(*net, batch);
     if ((size_t)w.total * sizeof(float) > workspace_bytes) {
         set_error("tcr_dscnn_backward: workspace %zu bytes < required %zu", workspace_bytes, (size_t)w.total * sizeof(float));
@@ -854,14 +902,19 @@ extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, con
     const std::vector<DsUnit> units = ds_units(*net);
     const int cp = net->c_pad, nc = net->cfg.num_classes;
     const int cl = net->layers.back().cout;
-    // zero the arena: padding and the conv biases (exactly-zero gradient, see above)
-    if (hipMemsetAsync(grads, 0, (size_t)net->param_floats * sizeof(float), s) != hipSuccess) {
-        set_error("tcr_dscnn_backward: hipMemsetAsync failed");
-        return TCR_ERR_HIP;
+    const int nu = (int)units.size();
+    TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_dscnn_backward: bad stage range [%d, %d)", stage_begin, stage_end);
+    const double bn_batch = sync ? (double)global_batch : (double)batch;
+    if (stage_begin == 0) {
+        // zero the arena: padding and the conv biases (exactly-zero gradient, see above)
+        if (hipMemsetAsync(grads, 0, (size_t)net->param_floats * sizeof(float), s) != hipSuccess) {
+            set_error("tcr_dscnn_backward: hipMemsetAsync failed");
+            return TCR_ERR_HIP;
+        }
+        TCR_TRY(launch_fc_wgrad(base + w.dropped, base + w.dlogits, base + w.fc_partial, grads + net->fcw_off, batch, cl, nc, s));
+        TCR_TRY(launch_bias_grad(base + w.dlogits, batch, nc, grads + net->fcb_off, s));
+        TCR_TRY(launch_head_bwd(base + w.dlogits, params + net->fcw_off, base + w.dscale, base + w.dpool, batch, cl, nc, s));
     }
-    TCR_TRY(launch_fc_wgrad(base + w.dropped, base + w.dlogits, base + w.fc_partial, grads + net->fcw_off, batch, cl, nc, s));
-    TCR_TRY(launch_bias_grad(base + w.dlogits, batch, nc, grads + net->fcb_off, s));
-    TCR_TRY(launch_head_bwd(base + w.dlogits, params + net->fcw_off, base + w.dscale, base + w.dpool, batch, cl, nc, s));
 
     // Filter gradients run on a second stream, overlapped with the (HBM-bound) BN-backward / data-gradient chain of the units
     // below.  They read dz, so dz alternates between two buffers and a buffer is rewritten only after the filter-gradient
@@ -877,14 +930,31 @@ extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, con
         }
         side = net->side;
     }
-    const float* da = base + w.dpool;       // gradient wrt the current unit's activation
-    int bcast = 1;                          // ([B][C] broadcast over the map for the last unit: average-pool backward)
     float* ga = base + w.ga;
     float* kc = base + w.kcoef;
-    int flip = 0, used[2] = {0, 0};
-    for (int ui = (int)units.size() - 1; ui >= 0; --ui, flip ^= 1) {
+    // per-channel sums of unit ui's BN backward (da: the gradient wrt its activation -- the pooled head's for the last unit, else
+    // the data gradient the previous stage left in `ga`)
+    auto pre = [&](int ui) -> int {
+        const DsUnit& u = units[ui];
+        const int pp = tcr_padded_len(u.P);
+        ChanReduceArgs r;
+        std::memset(&r, 0, sizeof(r));
+        r.y = base + w.raw[ui]; r.da = ui == nu - 1 ? base + w.dpool : ga; r.m1 = base + w.act[ui]; r.m2 = nullptr;
+        r.mean = base + w.mean[ui]; r.invstd = base + w.invstd[ui];
+        r.partial = base + w.partial; r.npos = batch * u.P; r.c = u.c; r.t = u.P; r.tp = pp; r.bcast = ui == nu - 1 ? 1 : 0;
+        int nchunk = 0;
+        TCR_TRY(launch_chan_reduce(1, r, &nchunk, s));
+        if (sync) TCR_TRY(launch_chan_sums(base + w.partial, nchunk, u.c, reinterpret_cast<double*>(base + w.sums), s));
+        return TCR_OK;
+    };
+    if (stage_begin == 0) TCR_TRY(pre(nu - 1));
+    for (int st = stage_begin > 0 ? stage_begin : 1; st < stage_end; ++st) {
+        const int ui = nu - st;                     // the unit whose sums the previous stage produced
+        const int flip = (st - 1) & 1;
+        // dz alternates between two buffers; a buffer is rewritten only after the filter-gradient kernel that read it two units ago
+        // has finished.  (Staged runs return to the host between stages: the event of the SAME parity is the one to wait for.)
         float* dz = base + (flip ? w.dz2 : w.dz);
-        if (side != s && used[flip] && hipStreamWaitEvent(s, net->ev_done[flip], 0) != hipSuccess) {
+        if (side != s && st >= 3 && hipStreamWaitEvent(s, net->ev_done[flip], 0) != hipSuccess) {
             set_error("tcr_dscnn_backward: stream wait failed");
             return TCR_ERR_HIP;
         }
@@ -893,17 +963,14 @@ extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, con
         const int pp = tcr_padded_len(u.P);
         const float* raw = base + w.raw[ui];
         const float* act = base + w.act[ui];
-        ChanReduceArgs r;
-        std::memset(&r, 0, sizeof(r));
-        r.y = raw; r.da = da; r.m1 = act; r.m2 = nullptr; r.mean = base + w.mean[ui]; r.invstd = base + w.invstd[ui];
-        r.partial = base + w.partial; r.npos = batch * u.P; r.c = u.c; r.t = u.P; r.tp = pp; r.bcast = bcast;
-        int nchunk = 0;
-        TCR_TRY(launch_chan_reduce(1, r, &nchunk, s));
+        const float* da = ui == nu - 1 ? base + w.dpool : ga;
+        const int bcast = ui == nu - 1 ? 1 : 0;
         BnBwdFinalizeArgs f;
-        f.partial = base + w.partial; f.nchunk = nchunk; f.sums = nullptr; f.gamma = nullptr; f.invstd = base + w.invstd[ui];
+        f.partial = base + w.partial; f.nchunk = sync ? 0 : chan_reduce_launch_chunks(batch * u.P);
+        f.sums = reinterpret_cast<const double*>(base + w.sums); f.gamma = nullptr; f.invstd = base + w.invstd[ui];
         f.dgamma = nullptr; f.dbeta = grads + u.beta_off;
         f.k1 = kc; f.k2 = kc + cp; f.k3 = kc + 2 * cp;
-        f.c = u.c; f.count = (double)batch * (double)u.P; f.grad_scale = 1.0f;
+        f.c = u.c; f.count = bn_batch * (double)u.P; f.grad_scale = (float)((double)batch / bn_batch);
         TCR_TRY(launch_bn_bwd_finalize(f, s));
         BnBwdApplyArgs ap;
         ap.accumulate = 0;
@@ -941,16 +1008,23 @@ extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, con
             g.kh = l.kh; g.sh = l.sh; g.sw = l.sw; g.pad_t = l.pad_t; g.pad_l = l.pad_l;
             TCR_TRY(launch_dscnn_conv1_wgrad(g, grads + u.w_off, side));
         }
-        if (side != s) {
-            if (hipEventRecord(net->ev_done[flip], side) != hipSuccess) { set_error("tcr_dscnn_backward: event record failed"); return TCR_ERR_HIP; }
-            used[flip] = 1;
-        }
-        da = ga;
-        bcast = 0;
+        if (side != s && hipEventRecord(net->ev_done[flip], side) != hipSuccess) { set_error("tcr_dscnn_backward: event record failed"); return TCR_ERR_HIP; }
+        if (ui > 0) TCR_TRY(pre(ui - 1));
     }
-    if (side != s && (hipEventRecord(net->ev_join, side) != hipSuccess || hipStreamWaitEvent(s, net->ev_join, 0) != hipSuccess)) {
+    if (stage_end == nu + 1 && side != s && (hipEventRecord(net->ev_join, side) != hipSuccess || hipStreamWaitEvent(s, net->ev_join, 0) != hipSuccess)) {
         set_error("tcr_dscnn_backward: stream join failed");
         return TCR_ERR_HIP;
     }
     return TCR_OK;
+}
+
+extern "C" int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, const float* feat, int batch,
+                                  void* workspace, size_t workspace_bytes, float* grads, void* stream) {
+    const int nu = net ? (int)ds_units(*net).size() : 0;
+    return ds_backward_stages(net, params, feat, batch, batch, 0, workspace, workspace_bytes, grads, 0, nu + 1, stream);
+}
+
+extern "C" int tcr_dscnn_backward_stage(const tcr_dscnn* net, const float* params, const float* feat, int batch, int global_batch,
+                                        void* workspace, size_t workspace_bytes, float* grads, int stage, void* stream) {
+    return ds_backward_stages(net, params, feat, batch, global_batch, 1, workspace, workspace_bytes, grads, stage, stage + 1, stream);
 }

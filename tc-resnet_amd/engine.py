@@ -483,28 +483,50 @@ class DSCNN(_Base):
                       label_smoothing: float = 0.0, **_unused):
         """Train-mode forward (batch statistics, moving averages updated).  Returns (logits, probs, loss_sum) like
         TCResNet.forward_train; the graph applies no dropout (ds_cnn.py:89-101), so keep_prob / seed are ignored."""
-        if _unused.get("sync_hook") is not None:
-            raise NotImplementedError("cross-replica BN statistics are built for TC-ResNet only; DS-CNN replicas use per-replica BN")
+        sync_hook = _unused.get("sync_hook")
         self._check_feat(feat)
         self._check_tensor(labels, "labels")
         b = feat.shape[0]
+        gb = int(global_batch or b)
         ws = self.train_workspace(b)
         logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
         probs = torch.empty_like(logits)
         loss = torch.zeros(2, dtype=torch.float32, device=self.device)
-        self.lib.check(self.lib.tcr_dscnn_forward_train(self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(),
-                                                        labels.data_ptr(), b, int(global_batch or b), float(label_smoothing),
-                                                        ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(),
-                                                        loss.data_ptr(), self._stream()), "tcr_dscnn_forward_train")
-        self._last = (feat, b)
+        common = (self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(), labels.data_ptr(), b, gb, float(label_smoothing),
+                  ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), loss.data_ptr())
+        if sync_hook is None:
+            self.lib.check(self.lib.tcr_dscnn_forward_train(*common, self._stream()), "tcr_dscnn_forward_train")
+        else:               # cross-replica BN: the host all-reduces each unit's float64 sums between stages
+            ns = self.lib.tcr_dscnn_num_stages(self._h)
+            for st in range(ns):
+                self.lib.check(self.lib.tcr_dscnn_forward_train_stage(*common, st, self._stream()), "tcr_dscnn_forward_train_stage")
+                if st < ns - 1:
+                    sync_hook(self._stage_sums(0, st, ws, b))
+        self._last = (feat, b, gb, sync_hook)
         return logits, probs, loss[0]
+
+    def _stage_sums(self, backward: int, stage: int, ws: torch.Tensor, batch: int) -> torch.Tensor:
+        ptr, n = C.c_void_p(), C.c_int64()
+        self.lib.check(self.lib.tcr_dscnn_stage_sums(self._h, backward, stage, ws.data_ptr(), batch, C.byref(ptr), C.byref(n)),
+                       "tcr_dscnn_stage_sums")
+        off = (ptr.value - ws.data_ptr()) // 4
+        return ws[off:off + 2 * n.value].view(torch.float64)
 
     def backward(self) -> torch.Tensor:
         """Gradient of the mean cross-entropy wrt every trainable, into self.grads."""
-        feat, b = self._last
+        feat, b, gb, sync_hook = self._last
         ws = self.train_workspace(b)
-        self.lib.check(self.lib.tcr_dscnn_backward(self._h, self.params.data_ptr(), feat.data_ptr(), b, ws.data_ptr(),
-                                                   ws.numel() * 4, self.grads.data_ptr(), self._stream()), "tcr_dscnn_backward")
+        if sync_hook is None:
+            self.lib.check(self.lib.tcr_dscnn_backward(self._h, self.params.data_ptr(), feat.data_ptr(), b, ws.data_ptr(),
+                                                       ws.numel() * 4, self.grads.data_ptr(), self._stream()), "tcr_dscnn_backward")
+        else:
+            ns = self.lib.tcr_dscnn_num_stages(self._h)
+            for st in range(ns):
+                self.lib.check(self.lib.tcr_dscnn_backward_stage(self._h, self.params.data_ptr(), feat.data_ptr(), b, gb, ws.data_ptr(),
+                                                                 ws.numel() * 4, self.grads.data_ptr(), st, self._stream()),
+                               "tcr_dscnn_backward_stage")
+                if st < ns - 1:
+                    sync_hook(self._stage_sums(1, st, ws, b))
         return self.grads
 
     def forward_infer(self, feat: torch.Tensor):

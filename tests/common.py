@@ -378,3 +378,24 @@ def check_staged_equals_unstaged(lib, name, width, batch, tag="4020", keep_prob=
     for a, b, what in zip(outs[0], outs[1], ("logits", "probs", "loss", "grads", "moving stats")):
         assert torch.equal(a, b), f"staged {what} differ from the unstaged run (max |d| {float((a - b).abs().max())})"
     assert torch.isfinite(outs[0][3]).all()
+
+
+def check_dscnn_staged_equals_unstaged(lib, size, batch):
+    """DS-CNN through the staged sync-BN API with an identity hook: bitwise the unstaged run (logits, loss, gradients, moving stats)."""
+    from oracle import dscnn_ref as D
+    p, s = D.init_params(D.net_def(size), seed=4)
+    fe = make_frontend(lib, 640, 320, num_mfccs=10)
+    base = R.synth_waveforms(min(batch, 32), seed=8)
+    reps = max(batch // base.shape[0], 1)
+    feat = fe(to_dev(lib, np.tile(base, (reps, 1))))
+    labels = to_dev(lib, np.tile(R.synth_labels(base.shape[0]), (reps, 1)))
+    outs, seen = [], []
+    for hook in (None, lambda sums: seen.append(sums.dtype)):
+        net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
+        sd = dict(p); sd.update(s); net.load_state_dict(sd)
+        logits, probs, loss = net.forward_train(feat, labels, sync_hook=hook)
+        g = net.backward().clone()
+        outs.append((logits.clone(), loss.clone(), g, net.stats.clone()))
+    assert len(seen) == 2 * (net.lib.tcr_dscnn_num_stages(net._h) - 1) and all(dt == torch.float64 for dt in seen)
+    for a, b, what in zip(outs[0], outs[1], ("logits", "loss", "grads", "moving stats")):
+        assert torch.equal(a, b), f"DS-CNN-{size}: staged {what} differ from the unstaged run"

@@ -38,6 +38,18 @@ def _setup(lib, name="TCResNet8", width=1.0):
     return fe, net
 
 
+def _setup_dscnn(lib, size="S"):
+    import tcresnet_amd as T
+    from oracle import dscnn_ref as D
+    p, s = D.init_params(D.net_def(size), seed=2)
+    dev = "cuda" if lib.kind == "hip" else None
+    fe = T.Frontend(window_size_samples=640, window_stride_samples=320, num_mfccs=10, lib=lib, device=dev)
+    net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=dev)
+    sd = dict(p); sd.update(s)
+    net.load_state_dict(sd)
+    return fe, net
+
+
 def _worker(rank, world, port, sync_bn, out_dir, kind, name, width, b):
     import sys
     sys.path.insert(0, ROOT)
@@ -45,7 +57,7 @@ def _worker(rank, world, port, sync_bn, out_dir, kind, name, width, b):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = _lib_of(kind)
-    fe, net = _setup(lib, name, width)
+    fe, net = _setup_dscnn(lib, width) if name == "DSCNN" else _setup(lib, name, width)
     wav = torch.from_numpy(R.synth_waveforms(b, seed=77, start=rank * b)).to(fe.device)
     lab = torch.from_numpy(R.synth_labels(b, start=rank * b)).to(fe.device)
     dp = DataParallel(net, sync_bn=sync_bn)
@@ -54,6 +66,7 @@ def _worker(rank, world, port, sync_bn, out_dir, kind, name, width, b):
     g = dp.backward()
     mean_loss = dp.mean_loss(loss_sum, b)
     net.sgd_momentum_step(0.1, 0.9, 0.001)
+    torch.cuda.synchronize() if fe.device.type == "cuda" else None
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), grads=g.cpu().numpy(), logits=logits.cpu().numpy(), loss=float(mean_loss),
              params=net.params.cpu().numpy(), stats=net.stats.cpu().numpy())
     dist.destroy_process_group()
@@ -75,7 +88,7 @@ def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b):
     if sync_bn:
         assert np.array_equal(r[0]["stats"], r[1]["stats"])
     # single process, global batch of 2b, same dropout stream (masks are indexed by global sample id)
-    fe, net = _setup(lib, name, width)
+    fe, net = _setup_dscnn(lib, width) if name == "DSCNN" else _setup(lib, name, width)
     wav = torch.from_numpy(R.synth_waveforms(2 * b, seed=77)).to(fe.device)
     lab = torch.from_numpy(R.synth_labels(2 * b)).to(fe.device)
     logits, probs, loss_sum = net.forward_train(fe(wav), lab, keep_prob=0.5, seed=3)
@@ -96,6 +109,16 @@ def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b):
 @pytest.mark.parametrize("sync_bn", [True, False])
 def test_two_replicas_match_global_batch(emu_lib, tmp_path, sync_bn):
     _two_replicas(emu_lib, "emu", tmp_path, sync_bn, "TCResNet8", 1.0, 3)
+
+
+def test_two_replicas_match_global_batch_dscnn(emu_lib, tmp_path):
+    """DS-CNN with cross-replica BN statistics (tcr_dscnn_*_stage): two replicas == the single-device global batch."""
+    _two_replicas(emu_lib, "emu", tmp_path, True, "DSCNN", "S", 2)
+
+
+@pytest.mark.gpu
+def test_two_replicas_match_global_batch_dscnn_hip(hip_lib, tmp_path):
+    _two_replicas(hip_lib, "hip", tmp_path, True, "DSCNN", "L", 8)
 
 
 @pytest.mark.gpu

@@ -133,3 +133,7 @@ def test_backward_phases_opt_in(emu_lib):
         Cm.check_staged_equals_unstaged(emu_lib, "TCResNet8", 1.0, batch=5)
     finally:
         emu_lib.tcr_tune(9, 0)
+
+
+def test_dscnn_staged_sync_bn_api(emu_lib):
+    Cm.check_dscnn_staged_equals_unstaged(emu_lib, "S", 3)

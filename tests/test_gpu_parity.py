@@ -358,3 +358,8 @@ def test_train_paths_agree(hip_lib):
     ref = outs[(0, 0)]
     for k, o in outs.items():
         assert (o[0] - ref[0]).abs().max() < 1e-4 and (o[1] - ref[1]).abs().max() < 2e-4 * max(1.0, float(ref[1].abs().max())), k
+
+
+@pytest.mark.parametrize("size,batch", [("S", 96), ("L", 1024)])
+def test_dscnn_staged_sync_bn_api(hip_lib, size, batch):
+    Cm.check_dscnn_staged_equals_unstaged(hip_lib, size, batch)
