@@ -271,6 +271,9 @@ int tcr_g2d_pool(tcr_g2d* g, int in, int is_max, int kh, int kw, int sh, int sw,
 int tcr_g2d_add(tcr_g2d* g, int a, int b, int relu);                 /* net += layer_in [; relu] */
 int tcr_g2d_dropout(tcr_g2d* g, int in, float keep_prob);            /* tf.nn.dropout / slim.dropout; identity in eval mode */
 int tcr_g2d_node_shape(const tcr_g2d* g, int node, int* c, int* h, int* w);
+/* A node's activation inside the workspace of a forward call at (batch, train): [batch][C][plane_floats], the H*W values of a
+ * plane start `halo` floats in.  What the reference exposes as `endpoints` (audio_nets/res.py:66, tc_resnet.py:95). */
+int tcr_g2d_node_output(const tcr_g2d* g, int node, int batch, int train, int64_t* offset_floats, int64_t* plane_floats, int* halo);
 int tcr_g2d_finalize(tcr_g2d* g, int logits_node);                   /* logits node: [num_classes] x 1 x 1 */
 int64_t tcr_g2d_param_floats(const tcr_g2d* g);
 int64_t tcr_g2d_decay_floats(const tcr_g2d* g);

@@ -26,13 +26,28 @@ DT = torch.float64
 
 # ReLU-kink bookkeeping for the tests: with `KINK_LOG["on"]` every ReLU input is scanned for elements within `tau` of zero -- an
 # f32 implementation cannot be expected to land on the same side of such an input, and each flipped mask moves the gradients.
-KINK_LOG = {"on": False, "tau": 1e-5, "near": 0, "total": 0}
+# `KINK_LOG["decide"]`: optional list, one entry per ReLU in call order, of boolean tensors "the implementation under test kept
+# this element" -- consulted ONLY for the elements within `tau` of zero, so that the float64 gradient is taken on the same side of
+# those kinks as the implementation's (every other element keeps its own sign; a wrong mask elsewhere is still caught).
+KINK_LOG = {"on": False, "tau": 1e-5, "near": 0, "total": 0, "decide": None, "idx": 0, "followed": 0}
 
 
 def _relu(x):
     if KINK_LOG["on"]:
-        KINK_LOG["near"] += int((x.detach().abs() < KINK_LOG["tau"]).sum())
+        near = x.detach().abs() < KINK_LOG["tau"]
+        n_near = int(near.sum())
+        KINK_LOG["near"] += n_near
         KINK_LOG["total"] += x.numel()
+        dec = KINK_LOG["decide"]
+        if dec is not None:
+            kept = dec[KINK_LOG["idx"]]
+            KINK_LOG["idx"] += 1
+            if kept.numel() != x.numel():
+                raise ValueError(f"ReLU #{KINK_LOG['idx'] - 1}: mask of {tuple(kept.shape)} for an input of {tuple(x.shape)}")
+            if n_near:
+                mask = torch.where(near, kept.reshape(x.shape), x.detach() > 0)
+                KINK_LOG["followed"] += int((mask != (x.detach() > 0)).sum())
+                return x * mask.to(x.dtype)
     return F.relu(x)
 
 

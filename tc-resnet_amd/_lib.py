@@ -107,6 +107,7 @@ _PROTOTYPES = {
     "tcr_g2d_add": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "tcr_g2d_dropout": (C.c_int, [_P, C.c_int, C.c_float]),
     "tcr_g2d_node_shape": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tcr_g2d_node_output": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "tcr_g2d_finalize": (C.c_int, [_P, C.c_int]),
     "tcr_g2d_param_floats": (C.c_int64, [_P]),
     "tcr_g2d_decay_floats": (C.c_int64, [_P]),

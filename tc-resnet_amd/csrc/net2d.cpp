@@ -288,6 +288,25 @@ extern "C" size_t tcr_g2d_workspace_bytes(const tcr_g2d* g, int batch, int train
     return (size_t)carve2d(*g, batch, train != 0).total * sizeof(float);
 }
 
+// Where a node's output lives in the workspace of a forward call of this (batch, train): [batch, C, H*W + 2*halo] floats, `halo`
+// floats in before the first element of every plane.  The reference keeps every layer's activation in `endpoints`
+// (audio_nets/res.py:66, tc_resnet.py:95 `collect_named_outputs`); this is the same view onto the kernels' buffers.
+extern "C" int tcr_g2d_node_output(const tcr_g2d* g, int node, int batch, int train, int64_t* offset_floats, int64_t* plane_floats,
+                                   int* halo) {
+    TCR_REQUIRE(g && g->finalized && offset_floats && plane_floats && halo && batch > 0 && node >= 0 && node < (int)g->nodes.size(),
+                "tcr_g2d_node_output: bad argument");
+    const G2dWorkspace w = carve2d(*g, batch, train != 0);
+    int id = node;
+    while (w.out[id] < 0) {                                  // eval-mode dropout aliases its input
+        id = g->nodes[id].in0;
+        TCR_REQUIRE(id >= 0, "tcr_g2d_node_output: node %d aliases the network input", node);
+    }
+    *offset_floats = w.out[id];
+    *plane_floats = pp_of(g->nodes[id].h, g->nodes[id].w);
+    *halo = kHalo;
+    return TCR_OK;
+}
+
 extern "C" int tcr_g2d_input_from_features(const float* feat, int batch, int t, int f, float* plane, void* stream) {
     TCR_REQUIRE(feat && plane && batch > 0 && t > 0 && f > 0, "tcr_g2d_input_from_features: bad argument");
     return launch_features_to_plane(feat, plane, batch, t, f, static_cast<hipStream_t>(stream));

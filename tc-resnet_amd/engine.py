@@ -563,6 +563,7 @@ class Graph2D(_Base):
         self._h, self.scope = handle, scope
         self.h_in, self.w_in, self.c_in = int(h), int(w), int(c)
         self.initializers: Dict[str, object] = {}           # variable name -> "xavier" | ("truncated_normal", stddev) | "zeros"
+        self.relu_nodes: List[int] = []                      # nodes whose output went through a ReLU, in build order
         self.dropout_nodes: List[int] = []                  # node ids of the dropout layers (each mask is keyed by its node id)
         self.finalized = False
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -592,13 +593,13 @@ class Graph2D(_Base):
         self.initializers[weights_name] = init
         if biases_name:
             self.initializers[biases_name] = "zeros"
-        return self._node(self.lib.tcr_g2d_conv(self._h, inp, kh, kw, int(cout), sh, sw, dh, dw, int(padding == "VALID"), int(relu),
-                                                weights_name.encode(), (biases_name or "").encode()), "tcr_g2d_conv")
+        return self._relu(relu, self._node(self.lib.tcr_g2d_conv(self._h, inp, kh, kw, int(cout), sh, sw, dh, dw, int(padding == "VALID"),
+                                                                 int(relu), weights_name.encode(), (biases_name or "").encode()), "tcr_g2d_conv"))
 
     def batch_norm(self, inp: int, prefix: str, center: bool = True, scale: bool = True, relu: bool = False, decay: float = 0.997,
                    eps: float = 0.001) -> int:
-        return self._node(self.lib.tcr_g2d_batch_norm(self._h, inp, int(center), int(scale), int(relu), float(decay), float(eps),
-                                                      prefix.encode()), "tcr_g2d_batch_norm")
+        return self._relu(relu, self._node(self.lib.tcr_g2d_batch_norm(self._h, inp, int(center), int(scale), int(relu), float(decay),
+                                                                       float(eps), prefix.encode()), "tcr_g2d_batch_norm"))
 
     def pool(self, inp: int, kind: str, kernel=None, stride=(1, 1), padding: str = "VALID") -> int:
         kh, kw = (0, 0) if kernel is None else ((kernel, kernel) if isinstance(kernel, int) else kernel)
@@ -606,12 +607,26 @@ class Graph2D(_Base):
         return self._node(self.lib.tcr_g2d_pool(self._h, inp, int(kind == "max"), kh, kw, sh, sw, int(padding == "VALID")), "tcr_g2d_pool")
 
     def add(self, a: int, b: int, relu: bool = False) -> int:
-        return self._node(self.lib.tcr_g2d_add(self._h, a, b, int(relu)), "tcr_g2d_add")
+        return self._relu(relu, self._node(self.lib.tcr_g2d_add(self._h, a, b, int(relu)), "tcr_g2d_add"))
 
     def dropout(self, inp: int, keep_prob: float) -> int:
         node = self._node(self.lib.tcr_g2d_dropout(self._h, inp, float(keep_prob)), "tcr_g2d_dropout")
         self.dropout_nodes.append(node)
         return node
+
+    def _relu(self, relu: bool, node: int) -> int:
+        if relu:
+            self.relu_nodes.append(node)
+        return node
+
+    def node_output(self, node: int, batch: int, train: bool) -> torch.Tensor:
+        """[B, C, H, W] view of a node's activation after a forward call at (batch, train) -- the reference's `endpoints`."""
+        off, plane, halo = C.c_int64(), C.c_int64(), C.c_int()
+        self.lib.check(self.lib.tcr_g2d_node_output(self._h, int(node), int(batch), int(train), C.byref(off), C.byref(plane), C.byref(halo)),
+                       "tcr_g2d_node_output")
+        c, h, w = self.shape(node)
+        buf = self.workspace(batch, train)[off.value: off.value + batch * c * plane.value].view(batch, c, plane.value)
+        return buf[:, :, halo.value: halo.value + h * w].reshape(batch, c, h, w)
 
     def shape(self, node: int) -> Tuple[int, int, int]:
         c, h, w = C.c_int(), C.c_int(), C.c_int()
