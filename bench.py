@@ -187,8 +187,8 @@ def main():
         def train_step():
             step_no[0] += 1
             f = pf.get()
-            pf.submit(wav)
             dp.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
+            pf.submit(wav)       # issued behind the forward: its LDS-resident phases cannot share a CU with the front-end, the backward can
             dp.backward()
             net.sgd_momentum_step(0.1, 0.9, 0.001)
 
@@ -205,8 +205,8 @@ def main():
         def train14_step():
             step_no[0] += 1
             f = pf.get()
-            pf.submit(wav)
             dp14.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
+            pf.submit(wav)
             dp14.backward()
             net14.sgd_momentum_step(0.1, 0.9, 0.001)
 
@@ -270,8 +270,8 @@ def main():
         def train2_step():
             step_no[0] += 1
             f = pf2.get()
-            pf2.submit(wav)
             dp2.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
+            pf2.submit(wav)
             dp2.backward()
             net2.sgd_momentum_step(0.1, 0.9, 0.001)
 

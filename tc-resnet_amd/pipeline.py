@@ -64,8 +64,9 @@ class FeaturePrefetcher:
         pf.submit(first_wavs)
         for step in ...:
             feat = pf.get()                 # features of this step (ready on the caller's stream)
-            pf.submit(next_wavs)            # next step's features, overlapped with the step below
-            net.forward_train(feat, ...); net.backward(); net.sgd_momentum_step(...)
+            net.forward_train(feat, ...)
+            pf.submit(next_wavs)            # next step's features, overlapped with the backward below (measured best point,
+            net.backward(); net.sgd_momentum_step(...)      # scripts/ab_prefetch_point.py: the forward's phases hold the LDS)
     """
 
     def __init__(self, frontend, batch: int, overlap: bool = True):
