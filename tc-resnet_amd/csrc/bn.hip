@@ -302,4 +302,101 @@ int launch_bn_bwd_apply(const BnBwdApplyArgs& a0, hipStream_t s) {
     return check_launch("bn_bwd_apply_kernel");
 }
 
+// BN backward, finalize folded into the apply pass (one launch instead of two in the backward's dependency chain): a workgroup
+// owns (kFG consecutive channels, a slab of utterances); it first adds up ITS channels' partial rows -- same channel blocks, same
+// slice order as reduce_partials(), so dgamma / dbeta / k1..k3 are bitwise those of bn_bwd_finalize_kernel -- and then streams
+// its [slab][kFG][Tp] block (contiguous per utterance).  Slab 0 of every channel group writes dgamma / dbeta.
+constexpr int kFG = 8;                  // channels per workgroup (divides kBnCB: a group never straddles a finalize block)
+constexpr int kFusedMaxParts = 64;
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFinalizeArgs f, const BnBwdApplyArgs a, int utt_per_slab, int batch) {
+    __shared__ double s_slices[kFusedMaxParts * 2 * kFG];
+    __shared__ float s_k[3][kFG];
+    const int g0 = blockIdx.y * kFG, gw = min(kFG, a.c - g0);
+    {
+        const int c0 = g0 / kBnCB * kBnCB, cb = min(kBnCB, a.c - c0);
+        const int nparts = 512 / (2 * cb);                      // reduce_partials' slicing of this channel block (512-thread finalize)
+        const int col = threadIdx.x & (2 * kFG - 1);            // which * kFG + channel
+        const int which = col / kFG, ch = g0 + col % kFG;
+        if (ch < a.c) {
+            const float* src = f.partial + (size_t)which * a.c + ch;
+            const size_t rstride = (size_t)2 * a.c;
+            for (int part = threadIdx.x / (2 * kFG); part < nparts; part += 256 / (2 * kFG)) {
+                double acc = 0.0;
+                int k = part;
+                for (; k + 7 * nparts < f.nchunk; k += 8 * nparts) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u * nparts) * rstride];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += (double)v[u];
+                }
+                for (; k < f.nchunk; k += nparts) acc += (double)src[(size_t)k * rstride];
+                s_slices[part * 2 * kFG + col] = acc;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < gw) {
+            const int c = g0 + threadIdx.x;
+            double db = 0.0, dg = 0.0;
+            for (int p = 0; p < nparts; ++p) { db += s_slices[p * 2 * kFG + threadIdx.x]; dg += s_slices[p * 2 * kFG + kFG + threadIdx.x]; }
+            const float dbf = (float)db, dgf = (float)dg;
+            if (blockIdx.x == 0) {
+                f.dbeta[c] = dbf * f.grad_scale;
+                if (f.dgamma) f.dgamma[c] = dgf * f.grad_scale;
+                f.k1[c] = f.gamma ? f.gamma[c] * f.invstd[c] : f.invstd[c];
+                f.k2[c] = (float)((double)dbf / f.count);
+                f.k3[c] = (float)((double)f.invstd[c] * (double)dgf / f.count);
+            }
+            s_k[0][threadIdx.x] = f.gamma ? f.gamma[c] * f.invstd[c] : f.invstd[c];
+            s_k[1][threadIdx.x] = (float)((double)dbf / f.count);
+            s_k[2][threadIdx.x] = (float)((double)f.invstd[c] * (double)dgf / f.count);
+        }
+        __syncthreads();
+    }
+    const int n0 = blockIdx.x * utt_per_slab, n1 = min(n0 + utt_per_slab, batch);
+    const int e_per = gw * a.tp;                                // this group's floats of one utterance (contiguous)
+    const float inv_e = 1.0f / (float)e_per;
+    const int total = (n1 - n0) * e_per;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        int nl = (int)(((float)idx + 0.5f) * inv_e);
+        nl += (nl + 1) * e_per <= idx ? 1 : (nl * e_per > idx ? -1 : 0);
+        const int e = idx - nl * e_per;
+        int cl = (int)(((float)e + 0.5f) * a.inv_tp);
+        cl += (cl + 1) * a.tp <= e ? 1 : (cl * a.tp > e ? -1 : 0);
+        const int tt = e - cl * a.tp - kHalo;
+        const int n = n0 + nl;
+        const size_t i = ((size_t)n * a.c + g0) * a.tp + e;
+        float v = 0.f;
+        if (tt >= 0 && tt < a.t) {
+            float dz = a.bcast ? a.da[(size_t)n * a.c + g0 + cl] : a.da[i];
+            if (a.m1 && !(a.m1[i] > 0.f)) dz = 0.f;
+            if (a.m2 && !(a.m2[i] > 0.f)) dz = 0.f;
+            v = s_k[0][cl] * (dz - s_k[1][cl] - (a.y[i] - a.mean[g0 + cl]) * s_k[2][cl]);
+        }
+        a.dy[i] = v;
+    }
+}
+
+// returns 1 (nothing launched) where the pair of kernels is needed: pre-reduced sums (sync BN), accumulate mode, odd channel blocks
+int launch_bn_bwd_apply_fused(const BnBwdFinalizeArgs& f, const BnBwdApplyArgs& a0, hipStream_t s) {
+    if (f.nchunk <= 0 || a0.accumulate || tune_get(TCR_TUNE_BWD_BN_FUSED) == 1) return 1;
+    if (a0.c > 48 && tune_get(TCR_TUNE_BWD_BN_FUSED) == 0) return 1;       // measured (scripts/ab_bwd_bn.py): -1.6 % / -2.5 % per TCResNet8 step
+                                                                            // (49 / 98 frames), but +1.5 % with the 72-channel layers of TCResNet14-1.5
+    for (int c0 = 0; c0 < a0.c; c0 += kBnCB)
+        if (512 / (2 * min(kBnCB, a0.c - c0)) > kFusedMaxParts) return 1;
+    BnBwdApplyArgs a = a0;
+    a.inv_tp = 1.0f / (float)a.tp;
+    const int per_utt = a.c * a.tp;
+    const int batch = (int)(a.total / per_utt);
+    if (kFG * a.tp >= (1 << 20) || batch >= (1 << 20)) return 1;
+    const int groups = ceil_div(a.c, kFG);
+    int want = tune_get(TCR_TUNE_BWD_BN_FUSED) >= 2 ? tune_get(TCR_TUNE_BWD_BN_FUSED) : 1024;       // workgroups aimed at
+    int nslab = max(1, min(batch, want / groups));
+    const int ups = ceil_div(batch, nslab);
+    nslab = ceil_div(batch, ups);
+    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(nslab, groups), dim3(256), 0, s, f, a, ups, batch);
+    return check_launch("bn_bwd_apply_fused_kernel");
+}
+
 }  // namespace tcr

@@ -315,6 +315,7 @@ int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 int launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s);
+int launch_bn_bwd_apply_fused(const BnBwdFinalizeArgs& f, const BnBwdApplyArgs& a, hipStream_t s);     // 1: not applicable, launch the pair
 
 // ---- head.hip -------------------------------------------------------------------------------
 struct HeadArgs {

@@ -881,13 +881,17 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
         f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
         f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
         f.grad_scale = (float)((double)c.batch / c.bn_batch);
-        TCR_TRY(launch_bn_bwd_finalize(f, bn_stream));
         BnBwdApplyArgs a;
         a.accumulate = 0;
         a.y = c.base + c.w.raw[u.li]; a.da = u.da; a.m1 = u.m1; a.m2 = u.m2; a.mean = c.base + c.w.mean[u.li];
         a.k1 = f.k1; a.k2 = f.k2; a.k3 = f.k3; a.dy = dy;
         a.total = (int64_t)c.batch * l.cout * tp; a.c = l.cout; a.t = l.tout; a.tp = tp; a.bcast = u.da_bcast;
-        TCR_TRY(launch_bn_bwd_apply(a, bn_stream));
+        const int rc = launch_bn_bwd_apply_fused(f, a, bn_stream);      // finalize inside the apply pass where that applies
+        if (rc != TCR_OK && rc != 1) return rc;
+        if (rc == 1) {
+            TCR_TRY(launch_bn_bwd_finalize(f, bn_stream));
+            TCR_TRY(launch_bn_bwd_apply(a, bn_stream));
+        }
     }
     // weight gradient
     const float* x = layer_input(net, c.w, c.base, c.feat, l);

@@ -399,3 +399,28 @@ def check_dscnn_staged_equals_unstaged(lib, size, batch):
     assert len(seen) == 2 * (net.lib.tcr_dscnn_num_stages(net._h) - 1) and all(dt == torch.float64 for dt in seen)
     for a, b, what in zip(outs[0], outs[1], ("logits", "loss", "grads", "moving stats")):
         assert torch.equal(a, b), f"DS-CNN-{size}: staged {what} differ from the unstaged run"
+
+
+def check_bn_backward_fused_equals_pair(lib, name, width, batch, seed=3):
+    """BN backward with the finalize folded into the apply pass (default) is BITWISE the finalize + apply pair (TCR_TUNE_BWD_BN_FUSED
+    = 1): same channel blocks, same slice order of the partial rows -- so also bitwise the staged (sync BN) path at one replica."""
+    import tcresnet_amd as T
+    dev = device_of(lib)
+    rng = np.random.RandomState(seed)
+    t, f = 25, 40
+    x = torch.from_numpy(rng.uniform(-2, 2, (batch, t, f)).astype(np.float32)).to(dev)
+    feat = T.features_to_planar(x, lib=lib)
+    labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
+    ch = R.tcresnet_channels(name, float(width))
+    grads = []
+    try:
+        for knob in (0, 1, 96):
+            lib.tcr_tune(11, knob)
+            net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)
+            net.init_xavier(1)
+            net.forward_train(feat, labels, keep_prob=0.5, seed=9)
+            grads.append(net.backward().clone())
+    finally:
+        lib.tcr_tune(11, 0)
+    assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
+    assert torch.equal(grads[0], grads[2])

@@ -135,5 +135,10 @@ def test_backward_phases_opt_in(emu_lib):
         emu_lib.tcr_tune(9, 0)
 
 
+def test_bn_backward_fused_equals_pair(emu_lib):
+    Cm.check_bn_backward_fused_equals_pair(emu_lib, "TCResNet8", 1.0, 5)
+    Cm.check_bn_backward_fused_equals_pair(emu_lib, "TCResNet14", 1.5, 3)       # 36 / 72 channels: channel blocks of 4 and 8
+
+
 def test_dscnn_staged_sync_bn_api(emu_lib):
     Cm.check_dscnn_staged_equals_unstaged(emu_lib, "S", 3)

@@ -360,6 +360,12 @@ def test_train_paths_agree(hip_lib):
         assert (o[0] - ref[0]).abs().max() < 1e-4 and (o[1] - ref[1]).abs().max() < 2e-4 * max(1.0, float(ref[1].abs().max())), k
 
 
+def test_bn_backward_fused_equals_pair(hip_lib):
+    Cm.check_bn_backward_fused_equals_pair(hip_lib, "TCResNet8", 1.0, 1024)
+    Cm.check_bn_backward_fused_equals_pair(hip_lib, "TCResNet14", 1.5, 300)
+    Cm.check_bn_backward_fused_equals_pair(hip_lib, "TCResNet8", 2.0, 64)       # 96 channels: the non-deferrable weight-gradient branch
+
+
 @pytest.mark.parametrize("size,batch", [("S", 96), ("L", 1024)])
 def test_dscnn_staged_sync_bn_api(hip_lib, size, batch):
     Cm.check_dscnn_staged_equals_unstaged(hip_lib, size, batch)
