@@ -32,7 +32,7 @@ def main(src, dst, marker="sgd_momentum_kernel"):
             tot += d
             x = agg.setdefault(names[i], [0, 0])
             x[0] += d; x[1] += 1
-        lines.append("# one TCResNet8-1.0 training step (batch 4096, features precomputed) under rocprofv3 --kernel-trace: the median step of the run")
+        lines.append(f"# one training step (batch 4096, features precomputed; step = launches up to and including {marker}) under rocprofv3 --kernel-trace: the median step of the run")
         lines.append(f"step wall {wall / 1e3:.1f} us, kernel time {tot / 1e3:.1f} us, {b - a} launches")
         for k, (d, n) in sorted(agg.items(), key=lambda x: -x[1][0]):
             lines.append(f"{k:56s} {n:3d} {d / 1e3:9.1f}")
@@ -68,4 +68,4 @@ def main(src, dst, marker="sgd_momentum_kernel"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "sgd_momentum_kernel")

@@ -45,13 +45,16 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
     float q1[CT], q2[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) { q1[c] = 0.f; q2[c] = 0.f; }
-    float mu[CT], is[CT];
+    float mu[CT], is[CT], ssc[CT], ssh[CT];
+    const bool self = MODE == 1 && a.self_scale != nullptr;
     if (MODE == 1) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const int cc = min(c0 + c, a.c - 1);
             mu[c] = a.mean[cc];
             is[c] = a.invstd[cc];
+            ssc[c] = self ? a.self_scale[cc] : 0.f;
+            ssh[c] = self ? a.self_shift[cc] : 1.f;
         }
     }
     const int blk0 = blockIdx.x * a.pos_per_block;
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
                 float dz = a.bcast ? a.da[(size_t)n * a.c + c0 + c] : a.da[o];
                 if (a.m1 && !(a.m1[o] > 0.f)) dz = 0.f;
                 if (a.m2 && !(a.m2[o] > 0.f)) dz = 0.f;
+                if (self && !(fmaf(yv, ssc[c], ssh[c]) > 0.f)) dz = 0.f;
                 q1[c] += dz;
                 q2[c] = fmaf(dz, (yv - mu[c]) * is[c], q2[c]);
             }
@@ -284,7 +288,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
         float dz = a.bcast ? a.da[(size_t)blockIdx.y * a.c + c] : a.da[i];
         if (a.m1 && !(a.m1[i] > 0.f)) dz = 0.f;
         if (a.m2 && !(a.m2[i] > 0.f)) dz = 0.f;
-        v = a.k1[c] * (dz - a.k2[c] - (a.y[i] - a.mean[c]) * a.k3[c]);
+        const float yv = a.y[i];
+        if (a.self_scale && !(fmaf(yv, a.self_scale[c], a.self_shift[c]) > 0.f)) dz = 0.f;
+        v = a.k1[c] * (dz - a.k2[c] - (yv - a.mean[c]) * a.k3[c]);
         if (a.accumulate) v += a.dy[i];
     } else if (a.accumulate) {
         return;
@@ -372,7 +378,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFina
             float dz = a.bcast ? a.da[(size_t)n * a.c + g0 + cl] : a.da[i];
             if (a.m1 && !(a.m1[i] > 0.f)) dz = 0.f;
             if (a.m2 && !(a.m2[i] > 0.f)) dz = 0.f;
-            v = s_k[0][cl] * (dz - s_k[1][cl] - (a.y[i] - a.mean[g0 + cl]) * s_k[2][cl]);
+            const float yv = a.y[i];
+            if (a.self_scale && !(fmaf(yv, a.self_scale[g0 + cl], a.self_shift[g0 + cl]) > 0.f)) dz = 0.f;
+            v = s_k[0][cl] * (dz - s_k[1][cl] - (yv - a.mean[g0 + cl]) * s_k[2][cl]);
         }
         a.dy[i] = v;
     }

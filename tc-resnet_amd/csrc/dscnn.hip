@@ -940,6 +940,9 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         ChanReduceArgs r;
         std::memset(&r, 0, sizeof(r));
         r.y = base + w.raw[ui]; r.da = ui == nu - 1 ? base + w.dpool : ga; r.m1 = base + w.act[ui]; r.m2 = nullptr;
+        if (tune_get(TCR_TUNE_BWD_MASK) == 0) {     // the unit's own ReLU mask from its raw output (one tensor read less)
+            r.m1 = nullptr; r.self_scale = base + w.ss + u.ss_off; r.self_shift = r.self_scale + cp;
+        }
         r.mean = base + w.mean[ui]; r.invstd = base + w.invstd[ui];
         r.partial = base + w.partial; r.npos = batch * u.P; r.c = u.c; r.t = u.P; r.tp = pp; r.bcast = ui == nu - 1 ? 1 : 0;
         int nchunk = 0;
@@ -975,6 +978,7 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         BnBwdApplyArgs ap;
         ap.accumulate = 0;
         ap.y = raw; ap.da = da; ap.m1 = act; ap.m2 = nullptr; ap.mean = base + w.mean[ui];
+        if (tune_get(TCR_TUNE_BWD_MASK) == 0) { ap.m1 = nullptr; ap.self_scale = base + w.ss + u.ss_off; ap.self_shift = ap.self_scale + cp; }
         ap.k1 = f.k1; ap.k2 = f.k2; ap.k3 = f.k3; ap.dy = dz;
         ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.bcast = bcast;
         TCR_TRY(launch_bn_bwd_apply(ap, s));

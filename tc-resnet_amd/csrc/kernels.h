@@ -243,6 +243,10 @@ struct ChanReduceArgs {
     int npos, c, t, tp;
     int pos_per_block;
     int bcast;              // da is [B][C] broadcast over time
+    // MODE 1: the unit's OWN ReLU mask recomputed from y instead of read from its activation: [fmaf(y, scale, shift) > 0] -- the
+    // expression the forward's bn_apply / staging uses, so the mask is bitwise the activation's (one tensor read less per pass)
+    const float* self_scale;
+    const float* self_shift;
 };
 
 struct BnFinalizeArgs {
@@ -304,6 +308,8 @@ struct BnBwdApplyArgs {
     int c, t, tp, bcast;
     float inv_tp;           // (set by the launcher)
     int accumulate;         // dy += ... (interior positions only) instead of dy = ...: gradient buffers with several producers (net2d)
+    const float* self_scale = nullptr;      // as in ChanReduceArgs
+    const float* self_shift = nullptr;
 };
 
 int launch_bn_fold(const BnFoldArgs& a, hipStream_t s);

@@ -815,15 +815,23 @@ struct BwdUnit {
     int li;                 // conv layer
     const float* da;        // gradient wrt the unit's (post-activation) output
     int da_bcast;           // da is [B][C] (pooled gradient broadcast over time)
-    const float* m1;        // ReLU masks applied to da
+    const float* m1;        // ReLU masks applied to da (activations read back) ...
     const float* m2;
+    const float* self_ss;   // ... and / or the unit's own mask recomputed from its raw output: [fmaf(y, scale, shift) > 0]
+    int self_cpad;
 };
 
-static BwdUnit bwd_unit_of(const TrainCtx& c, int li, const float* dpool) {
+static BwdUnit bwd_unit_of(const TrainCtx& c, int li, const float* dpool, bool masks_from_raw = true) {
     const tcr_net& net = *c.net;
     BwdUnit u;
-    u.li = li; u.da = nullptr; u.da_bcast = 0; u.m1 = nullptr; u.m2 = nullptr;
+    u.li = li; u.da = nullptr; u.da_bcast = 0; u.m1 = nullptr; u.m2 = nullptr; u.self_ss = nullptr; u.self_cpad = 0;
     const int last = net.blocks.back().b;
+    const bool recompute = masks_from_raw && tune_get(TCR_TUNE_BWD_MASK) == 0;      // (the group-resident phases read the activations)
+    auto own = [&](const float** m) {       // the unit's own activation is relu(bn(raw)): its mask needs no second tensor
+        if (!recompute) return;
+        *m = nullptr;
+        u.self_ss = c.base + c.w.ss + net.layers[li].ss_off; u.self_cpad = net.layers[li].c_pad;
+    };
     // gradient wrt the OUTPUT activation of block-output layer `b`
     auto grad_of_block_out = [&](int b, const float** g, int* bc) {
         if (b == last) { *g = dpool; *bc = 1; }
@@ -831,6 +839,7 @@ static BwdUnit bwd_unit_of(const TrainCtx& c, int li, const float* dpool) {
     };
     if (li == 0) {          // conv0: da = gradient wrt act[conv0], own ReLU
         u.da = c.base + c.w.gact[0]; u.m1 = c.base + c.w.act[0];
+        own(&u.m1);
         return u;
     }
     for (const Block& b : net.blocks) {
@@ -839,9 +848,11 @@ static BwdUnit bwd_unit_of(const TrainCtx& c, int li, const float* dpool) {
             u.m1 = c.base + c.w.act[b.b];
         } else if (li == b.a) {     // da = dgrad of conv_b, own ReLU
             u.da = c.base + c.w.gact[b.a]; u.m1 = c.base + c.w.act[b.a];
+            own(&u.m1);
         } else if (li == b.down) {  // shortcut: dOut * [out > 0] * [down > 0]
             grad_of_block_out(b.b, &u.da, &u.da_bcast);
             u.m1 = c.base + c.w.act[b.b]; u.m2 = c.base + c.w.act[b.down];
+            own(&u.m2);
         }
     }
     return u;
@@ -853,6 +864,7 @@ static int bwd_unit_pre(const TrainCtx& c, const BwdUnit& u, hipStream_t st, flo
     std::memset(&r, 0, sizeof(r));
     r.y = c.base + c.w.raw[u.li]; r.da = u.da; r.m1 = u.m1; r.m2 = u.m2;
     r.mean = c.base + c.w.mean[u.li]; r.invstd = c.base + c.w.invstd[u.li];
+    if (u.self_ss) { r.self_scale = u.self_ss; r.self_shift = u.self_ss + u.self_cpad; }
     r.partial = partial;
     r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout); r.bcast = u.da_bcast;
     int nchunk = 0;
@@ -886,6 +898,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
         a.y = c.base + c.w.raw[u.li]; a.da = u.da; a.m1 = u.m1; a.m2 = u.m2; a.mean = c.base + c.w.mean[u.li];
         a.k1 = f.k1; a.k2 = f.k2; a.k3 = f.k3; a.dy = dy;
         a.total = (int64_t)c.batch * l.cout * tp; a.c = l.cout; a.t = l.tout; a.tp = tp; a.bcast = u.da_bcast;
+        if (u.self_ss) { a.self_scale = u.self_ss; a.self_shift = u.self_ss + u.self_cpad; }
         const int rc = launch_bn_bwd_apply_fused(f, a, bn_stream);      // finalize inside the apply pass where that applies
         if (rc != TCR_OK && rc != 1) return rc;
         if (rc == 1) {
@@ -966,7 +979,7 @@ static std::vector<int> backward_order(const tcr_net& net) {
 // dy of unit `li`, built while a phase stages it (kc: the unit's k1 / k2 / k3 rows left by bn_bwd_finalize)
 static BwdSrc bwd_src_of_unit(const TrainCtx& c, int li, const float* dpool, const float* kc) {
     const ConvLayer& l = c.net->layers[li];
-    const BwdUnit u = bwd_unit_of(c, li, dpool);
+    const BwdUnit u = bwd_unit_of(c, li, dpool, false);
     const int64_t ks = align_up(l.cout, 64);
     BwdSrc s;
     std::memset(&s, 0, sizeof(s));
@@ -986,7 +999,7 @@ static BwdLayer bwd_layer_of(const TrainCtx& c, int li, int src) {
 }
 
 static BwdStat bwd_stat_of(const TrainCtx& c, int li, const float* dpool, float* partial) {
-    const BwdUnit u = bwd_unit_of(c, li, dpool);
+    const BwdUnit u = bwd_unit_of(c, li, dpool, false);
     BwdStat t;
     t.on = 1; t.m1 = u.m1; t.m2 = u.m2; t.raw = c.base + c.w.raw[li]; t.mean = c.base + c.w.mean[li]; t.invstd = c.base + c.w.invstd[li];
     t.partial = partial;
@@ -1022,7 +1035,7 @@ static TrainBwdPhaseArgs bwd_phase_d2(const TrainCtx& c, int bi, const float* dp
         a.src[1] = bwd_src_of_unit(c, b.down, dpool, c.base + c.w.kcoef2);
         a.n_layers = 2; a.layer[1] = bwd_layer_of(c, b.down, 1);
     } else {                    // identity shortcut: + dOut [out > 0]
-        const BwdUnit ub = bwd_unit_of(c, b.b, dpool);
+        const BwdUnit ub = bwd_unit_of(c, b.b, dpool, false);
         a.add = ub.da; a.add_bcast = ub.da_bcast; a.add_mask = c.base + c.w.act[b.b];
     }
     const int in_act = la.in_act;               // conv0 (bi == 0) or the previous block's conv_b

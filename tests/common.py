@@ -414,13 +414,36 @@ def check_bn_backward_fused_equals_pair(lib, name, width, batch, seed=3):
     ch = R.tcresnet_channels(name, float(width))
     grads = []
     try:
-        for knob in (0, 1, 96):
+        for knob, mask in ((0, 0), (1, 0), (96, 0), (0, 1), (1, 1)):
             lib.tcr_tune(11, knob)
+            lib.tcr_tune(12, mask)          # 1: ReLU masks read back from the activations instead of recomputed from the raw outputs
             net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)
             net.init_xavier(1)
             net.forward_train(feat, labels, keep_prob=0.5, seed=9)
             grads.append(net.backward().clone())
     finally:
         lib.tcr_tune(11, 0)
+        lib.tcr_tune(12, 0)
+    for g in grads[1:]:
+        assert torch.equal(grads[0], g), float((grads[0] - g).abs().max())
+
+
+def check_dscnn_mask_paths_agree(lib, size, batch, seed=5):
+    """DS-CNN backward with the ReLU masks recomputed from the raw BN inputs (default) is BITWISE the run that reads the activations."""
+    import tcresnet_amd as T
+    dev = device_of(lib)
+    rng = np.random.RandomState(seed)
+    t, f = 49, 10
+    feat = T.features_to_planar(torch.from_numpy(rng.uniform(-2, 2, (batch, t, f)).astype(np.float32)).to(dev), lib=lib)
+    labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
+    grads = []
+    try:
+        for mask in (0, 1):
+            lib.tcr_tune(12, mask)
+            ds = T.DSCNN(size, t, f, 12, lib=lib, device=dev)
+            ds.init_xavier(2)
+            ds.forward_train(feat, labels)
+            grads.append(ds.backward().clone())
+    finally:
+        lib.tcr_tune(12, 0)
     assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
-    assert torch.equal(grads[0], grads[2])

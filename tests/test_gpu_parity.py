@@ -364,6 +364,8 @@ def test_bn_backward_fused_equals_pair(hip_lib):
     Cm.check_bn_backward_fused_equals_pair(hip_lib, "TCResNet8", 1.0, 1024)
     Cm.check_bn_backward_fused_equals_pair(hip_lib, "TCResNet14", 1.5, 300)
     Cm.check_bn_backward_fused_equals_pair(hip_lib, "TCResNet8", 2.0, 64)       # 96 channels: the non-deferrable weight-gradient branch
+    Cm.check_dscnn_mask_paths_agree(hip_lib, "S", 200)
+    Cm.check_dscnn_mask_paths_agree(hip_lib, "L", 256)
 
 
 @pytest.mark.parametrize("size,batch", [("S", 96), ("L", 1024)])
