@@ -338,6 +338,9 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     a.seg_start = reinterpret_cast<const int*>(p + L.seg_start);
     a.wud = reinterpret_cast<const float2*>(p + L.wud);
     a.dcth = p + L.dcth;
+    a.mel_items = reinterpret_cast<const int*>(p + L.mel_items);
+    a.mel_ifirst = reinterpret_cast<const int*>(p + L.mel_ifirst);
+    a.dct_tab = p + L.dct_tab;
     a.n_samples = cfg->n_samples;
     a.win = cfg->win;
     a.hop = cfg->hop;

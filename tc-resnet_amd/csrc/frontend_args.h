@@ -14,6 +14,9 @@ struct FrontendArgs {
     const int* seg_start;
     const float2* wud;
     const float* dcth;
+    const int* mel_items;   // load-balanced sparse mel (frontend_plan.h)
+    const int* mel_ifirst;
+    const float* dct_tab;
     int n_samples, win, hop, n_frames, n_coef, tp;
     int total_frames;
     int magnitude;      // 1: the mel filterbank takes |S| instead of |S|^2

@@ -9,12 +9,20 @@
 //   a +- conj(b)      1
 // The 0.5 factors of the real-FFT split are not applied: the spectrum is 4x (power) / 2x (magnitude) too large and
 // the mel slopes are pre-scaled by the inverse power of two when they are staged in LDS (exact).
+//
+// Mel filterbank: sparse (two slopes per bin), load-balanced -- the plan cuts every mel-edge segment into items of <= 8 bins and a
+// lane takes one item per trip with all 16 LDS reads of the trip in flight (one lane per SEGMENT meant data-dependent loops of
+// 2 .. 20 bins with the wave waiting for the longest: 20 % of the kernel by a timing what-if).  DCT-II: on the matrix cores
+// (exact-f32 v_mfma_f32_16x16x4_f32, otherwise idle here), A fragments from a coalesced plan table (the VALU form cost 7 %).
+// Tried and dropped: the filterbank as banded MFMA work shared by the four waves (127 k-steps per round) -- needs two workgroup
+// barriers per round and partial-tile sums through LDS: 325 us vs 261 us.
 #include "frontend_plan.h"
 #include "frontend_args.h"
 
 namespace tcr {
 
 typedef float v2 __attribute__((ext_vector_type(2)));
+typedef float v4 __attribute__((ext_vector_type(4)));
 
 #if defined(TCR_HOST_EMULATION)
 #define TCR_PK_ASM 0
@@ -158,14 +166,16 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     constexpr int XLD = 17;                 // padded row of the 16x16 transpose tile
     constexpr int UNIT = 16 * XLD;
     constexpr int PLD = NBINS + 31;         // row stride = 32 (mod 64) banks: the two frames of a wave never collide
+    constexpr int kMelItemBins = mel_item_bins(NC);
+    constexpr int LMS = 80;                 // log-mel row stride, = 16 (mod 32): the DCT's MFMA B fragment reads 32 distinct banks
 
-    __shared__ v2 s_x[16 * UNIT];                   // transpose tiles, then the FFT output of each unit
+    __shared__ v2 s_x[16 * UNIT];                   // transpose tiles, then the FFT output of each unit; after the real-FFT split the
+                                                    // frame's first unit holds its mel items' (up, down) partial sums (wave-local reuse)
     __shared__ float s_p[FPR * PLD];                // 4 x power (or 2 x magnitude) spectrum
-    constexpr int ULD = NSEG + 1;                   // (a bank-friendlier 80 pushes NC = 256 past 80 KB of LDS: 1 workgroup / CU)
-    __shared__ v2 s_ud[FPR * ULD];                  // per-segment (up, down) partial sums
-    __shared__ float s_lm[NMEL * 65];               // log-mel [mel][frame], 64 frames
+    __shared__ float s_lm[NMEL * LMS];              // log-mel [mel][frame], 64 frames
     __shared__ v2 s_wud[NBINS];                     // mel slopes per bin, pre-scaled by 1/4 (1/2)
-    __shared__ int s_seg[NSEG + 1];
+    __shared__ int s_items[kMelItemsMax];           // first bin | bins << 10 | segment << 14
+    static_assert(kMelItemsMax <= UNIT, "the item sums of a frame live in one transpose unit");
 
     const int tid = threadIdx.x;
     const int f = tid / LPF;                // frame slot in the round
@@ -197,8 +207,20 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
         const float fold = MAG ? 0.5f : 0.25f;
         const v2* wud = reinterpret_cast<const v2*>(a.wud);
         for (int i = threadIdx.x; i < NBINS; i += 256) s_wud[i] = wud[i] * fold;
-        for (int i = threadIdx.x; i <= NSEG; i += 256) s_seg[i] = a.seg_start[i];
+        for (int i = threadIdx.x; i < kMelItemsMax; i += 256) s_items[i] = a.mel_items[i];
     }
+    const int nitems = a.mel_ifirst[NSEG];
+    // round-invariant: the items this lane takes (one per trip) and the item ranges of the bands it finishes
+    constexpr int TRIPS = NC == 512 ? 3 : 5;
+    int item_d[TRIPS], band_i[NMEL / LPF];
+#pragma unroll
+    for (int tr = 0; tr < TRIPS; ++tr) item_d[tr] = a.mel_items[min(lf + LPF * tr, kMelItemsMax - 1)];
+#pragma unroll
+    for (int i = 0; i < NMEL / LPF; ++i) {
+        const int m = lf + LPF * i;
+        band_i[i] = a.mel_ifirst[m] | (a.mel_ifirst[m + 1] << 8) | (a.mel_ifirst[m + 2] << 16);
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const v2 wm = tw_real[NC / 2];
     const v2 twmid = (v2){wm.y, -wm.x};
     __syncthreads();
@@ -207,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     const int rounds = a.rounds;            // <= ROUNDS; chosen by the launcher so that the grid fills whole dispatch waves
     const int fpw = rounds * FPR;           // frames per workgroup
     v2 xa[QV];
-    auto load_frame = [&](int rr, v2 (&dst)[QV]) {
-        int g = blockIdx.x * fpw + rr * FPR + f;
+    auto load_frame = [&](int chunk, int rr, v2 (&dst)[QV]) {
+        int g = chunk * fpw + rr * FPR + f;
         g = min(g, a.total_frames - 1);
         int n = (int)(((float)g + 0.5f) * inv_frames);          // g / n_frames: float multiply + one-step fix-up
         n += (n + 1) * a.n_frames <= g ? 1 : (n * a.n_frames > g ? -1 : 0);
@@ -217,14 +239,25 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
 #pragma unroll
         for (int q = 0; q < QV; ++q) dst[q] = *reinterpret_cast<const v2*>(src + 2 * (SUB * (l + 16 * q) + u));     // (8-byte aligned: launcher)
     };
+    // DCT A fragments of the first kDctPre coefficient tiles: round-invariant, loaded once (their latency would otherwise be paid
+    // at the end of every chunk)
+    constexpr int kDctPre = 3;
+    float dcta[kDctPre][NMEL / 4];
+    if (!a.no_dct) {
+#pragma unroll
+        for (int ct = 0; ct < kDctPre; ++ct)
+#pragma unroll
+            for (int st = 0; st < NMEL / 4; ++st) dcta[ct][st] = a.dct_tab[(ct * (NMEL / 4) + st) * 64 + (tid & 63)];
+    }
+    const int chunk = blockIdx.x;
+    load_frame(chunk, 0, xa);
     // (A frame's lanes never straddle a wavefront: the phases of a round are ordered by wave-local sync points.)
     for (int r = 0; r < rounds; ++r) {
         // ---------------- load (+ prefetch of the next round) + window + first radix-16 pass ----------------
         v2 v[16];
-        if (r == 0) load_frame(r, xa);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = q < QV ? xa[q] * wnd[q] : (v2){0.f, 0.f};
-        if (r + 1 < rounds) load_frame(r + 1, xa);
+        if (r + 1 < rounds) load_frame(chunk, r + 1, xa);
         pk_dft16(v);
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) s_x[unit * UNIT + k2 * XLD + l] = c_mul(v[k2], tw[k2]);
@@ -271,81 +304,120 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
             }
         }
         wave_sync();
-        // ---------------- sparse mel: per-segment (up, down) sums, one packed FMA per bin ----------------
+        // ---------------- sparse mel: one item (<= 8 bins of one segment) per lane and trip, one packed FMA per bin ----------------
+        v2* UD = s_x + (f * SUB) * UNIT;                    // (this frame's first unit: dead until the next round's first pass)
         {
             const float* P = s_p + f * PLD;
-            v2* UD = s_ud + f * ULD;
-            for (int i = 0;; ++i) {
-                const int j = (i & 1) ? (i + 1) * LPF - 1 - lf : i * LPF + lf;
-                if (i * LPF >= NSEG) break;
-                if (j < NSEG) {
-                    const int k0 = s_seg[j], k1 = s_seg[j + 1];
+            const int skew = (lf / (32 / kMelItemBins)) & (kMelItemBins - 1);   // lanes a bank period apart start 1 bin apart
+#pragma unroll 1
+            for (int tr = 0; tr < TRIPS; ++tr) {            // (rolled: one trip's 16 reads in flight, not all trips' -- register budget)
+                const int it = lf + LPF * tr;
+                if (it < nitems) {
+                    int d = item_d[0];
+#pragma unroll
+                    for (int q = 1; q < TRIPS; ++q) d = tr == q ? item_d[q] : d;
+                    const int k0 = d & 1023, nb = (d >> 10) & 15;
+                    float p[kMelItemBins];
+                    v2 wv[kMelItemBins];
+#pragma unroll
+                    for (int b = 0; b < kMelItemBins; ++b) {    // all reads of the item in flight
+                        const int bb = (b + skew) & (kMelItemBins - 1);
+                        const int k = min(k0 + bb, NBINS - 1);
+                        p[b] = P[k];
+                        wv[b] = s_wud[k];
+                        if (bb >= nb) wv[b] = (v2){0.f, 0.f};
+                    }
                     v2 ud = (v2){0.f, 0.f};
-                    int k = k0;
-                    for (; k + 4 <= k1; k += 4) {           // 4 bins per trip: the 8 LDS reads are independent
-                        const float p0 = P[k], p1 = P[k + 1], p2 = P[k + 2], p3 = P[k + 3];
-                        const v2 w0 = s_wud[k], w1 = s_wud[k + 1], w2 = s_wud[k + 2], w3 = s_wud[k + 3];
-                        ud = __builtin_elementwise_fma(w0, (v2){p0, p0}, ud);
-                        ud = __builtin_elementwise_fma(w1, (v2){p1, p1}, ud);
-                        ud = __builtin_elementwise_fma(w2, (v2){p2, p2}, ud);
-                        ud = __builtin_elementwise_fma(w3, (v2){p3, p3}, ud);
-                    }
-                    for (; k < k1; ++k) {
-                        const float p = P[k];
-                        ud = __builtin_elementwise_fma(s_wud[k], (v2){p, p}, ud);
-                    }
-                    UD[j] = ud;
+#pragma unroll
+                    for (int b = 0; b < kMelItemBins; ++b) ud = __builtin_elementwise_fma(wv[b], (v2){p[b], p[b]}, ud);
+                    UD[it] = ud;
                 }
+            }
+            for (int it = lf + LPF * TRIPS; it < nitems; it += LPF) {       // (filterbanks with more items than TRIPS trips cover)
+                const int d = s_items[it];
+                const int k0 = d & 1023, nb = (d >> 10) & 15;
+                v2 ud = (v2){0.f, 0.f};
+                for (int b = 0; b < nb; ++b) ud = __builtin_elementwise_fma(s_wud[k0 + b], (v2){P[k0 + b], P[k0 + b]}, ud);
+                UD[it] = ud;
             }
         }
         wave_sync();
-        // ---------------- log(mel + 1e-6) -> [mel][frame] ----------------
+        // ---------------- log(mel + 1e-6) -> [mel][frame]: up-slope items of segment m + down-slope items of segment m + 1 ----------------
         {
-            const v2* UD = s_ud + f * ULD;
 #pragma unroll
             for (int i = 0; i < NMEL / LPF; ++i) {
                 const int m = lf + LPF * i;
-                const float mel = UD[m].x + UD[m + 1].y;    // up-slope of segment m + down-slope of segment m+1
-                s_lm[m * 65 + r * FPR + f] = a.log_floor ? logf(fmaxf(mel, 1e-12f)) : logf(mel + 1e-6f);
+                const int i0 = band_i[i] & 255, i1 = (band_i[i] >> 8) & 255, i2 = band_i[i] >> 16;
+                float mel = 0.f;
+                for (int it = i0; it < i1; ++it) mel += UD[it].x;
+                for (int it = i1; it < i2; ++it) mel += UD[it].y;
+                s_lm[m * LMS + r * FPR + f] = a.log_floor ? logf(fmaxf(mel, 1e-12f)) : logf(mel + 1e-6f);
             }
         }
+        wave_sync();            // the item sums live in the unit the next round's first pass overwrites
     }
     __syncthreads();
 
-    // ---------------- DCT-II (lane == frame, wave-uniform coefficients) + store ----------------
-    const int fr = tid & 63;
-    const int w = tid >> 6;
-    const int g = blockIdx.x * fpw + fr;
-    const bool valid = fr < fpw && g < a.total_frames;
-    const int gg = valid ? g : a.total_frames - 1;
-    const int n = gg / a.n_frames;
-    const int t = gg - n * a.n_frames;
-    float* dst = a.out + (size_t)n * a.n_coef * a.tp + kHalo + t;
+    // ---------------- DCT-II on the matrix cores: wave w owns frames 16 w .. 16 w + 15, all coefficient tiles ----------------
     if (a.no_dct) {
+        const int fr = tid & 63;
+        const int w = tid >> 6;
+        const int g = chunk * fpw + fr;
+        const bool valid = fr < fpw && g < a.total_frames;
+        const int gg = valid ? g : a.total_frames - 1;
+        const int n = gg / a.n_frames;
+        const int t = gg - n * a.n_frames;
+        float* dst = a.out + (size_t)n * a.n_coef * a.tp + kHalo + t;
         for (int m = w; m < a.n_coef; m += 4) {
             if (valid) {
                 float* row = dst + (size_t)m * a.tp;
-                row[0] = s_lm[m * 65 + fr];
+                row[0] = s_lm[m * LMS + fr];
                 if (t == 0) { row[-4] = 0.f; row[-3] = 0.f; row[-2] = 0.f; row[-1] = 0.f; }
                 if (t == a.n_frames - 1) { row[1] = 0.f; row[2] = 0.f; row[3] = 0.f; row[4] = 0.f; }
             }
         }
-        return;
-    }
-    float h[NMEL / 2];
-    const float sgn = (w & 1) ? -1.f : 1.f;     // odd coefficients use l[n] - l[N-1-n]
+    } else {
+        const int lane = tid & 63;
+        const int kq = lane >> 4, col = lane & 15;
+        const int fr = 16 * wave + col;
+        const int g = chunk * fpw + fr;
+        const bool valid = fr < fpw && g < a.total_frames;
+        const int gg = valid ? g : a.total_frames - 1;
+        const int n = gg / a.n_frames;
+        const int t = gg - n * a.n_frames;
+        float* dst = a.out + (size_t)n * a.n_coef * a.tp + kHalo + t;
+        constexpr int CT = NMEL / 16;                                   // coefficient tiles (n_coef <= NMEL)
+        v4 acc[CT];
 #pragma unroll
-    for (int i = 0; i < NMEL / 2; ++i) h[i] = fmaf(sgn, s_lm[(NMEL - 1 - i) * 65 + fr], s_lm[i * 65 + fr]);
-    for (int c = w; c < a.n_coef; c += 4) {
-        const float* d = a.dcth + c * (NMEL / 2);
-        float acc = 0.f;
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = (v4){0.f, 0.f, 0.f, 0.f};
+        const int ntile = (a.n_coef + 15) >> 4;
 #pragma unroll
-        for (int i = 0; i < NMEL / 2; ++i) acc = fmaf(d[i], h[i], acc);
+        for (int ct = 0; ct < CT; ++ct) {
+            if (ct < ntile ) {                        // (wave-uniform)
+                float av[NMEL / 4], bv[NMEL / 4];
+#pragma unroll
+                for (int st = 0; st < NMEL / 4; ++st) {                 // all fragments of the tile in flight, then the MFMA chain
+                    av[st] = ct < kDctPre ? dcta[ct < kDctPre ? ct : 0][st] : a.dct_tab[(ct * (NMEL / 4) + st) * 64 + lane];
+                    bv[st] = s_lm[(4 * st + kq) * LMS + fr];
+                }
+#pragma unroll
+                for (int st = 0; st < NMEL / 4; ++st) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st], acc[ct], 0, 0, 0);
+            }
+        }
         if (valid) {
-            float* row = dst + (size_t)c * a.tp;
-            row[0] = acc;
-            if (t == 0) { row[-4] = 0.f; row[-3] = 0.f; row[-2] = 0.f; row[-1] = 0.f; }
-            if (t == a.n_frames - 1) { row[1] = 0.f; row[2] = 0.f; row[3] = 0.f; row[4] = 0.f; }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int c = 16 * ct + 4 * kq + rr;
+                    if (c < a.n_coef) {
+                        float* row = dst + (size_t)c * a.tp;
+                        row[0] = acc[ct][rr];
+                        if (t == 0) { row[-4] = 0.f; row[-3] = 0.f; row[-2] = 0.f; row[-1] = 0.f; }
+                        if (t == a.n_frames - 1) { row[1] = 0.f; row[2] = 0.f; row[3] = 0.f; row[4] = 0.f; }
+                    }
+                }
+            }
         }
     }
 }

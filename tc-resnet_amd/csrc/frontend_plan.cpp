@@ -6,6 +6,7 @@
 //   mfccs_from_log_mel_spectrograms (x 1/sqrt(2N)).
 // The mel matrix is stored in its sparse form: every spectrogram bin lies in exactly one
 // mel-edge segment j and contributes to at most two filters (up-slope of j, down-slope of j-1).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -184,6 +185,35 @@ extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_pl
     for (int c = 0; c < nm; ++c)
         for (int n = 0; n < half; ++n)
             w[L.dcth + (size_t)c * half + n] = (float)(2.0 * std::cos(kPi * c * (2.0 * n + 1.0) / (2.0 * nm)) / std::sqrt(2.0 * nm));
+
+    // The segments cut into items of <= mel_item_bins() bins (frontend_pk.hip: one lane per item)
+    {
+        const int kMelItemBins = mel_item_bins(L.nc);
+        const int32_t* seg = reinterpret_cast<const int32_t*>(w + L.seg_start);
+        int32_t* items = reinterpret_cast<int32_t*>(w + L.mel_items);
+        int32_t* ifirst = reinterpret_cast<int32_t*>(w + L.mel_ifirst);
+        int n = 0;
+        for (int j = 0; j < L.nseg; ++j) {
+            ifirst[j] = n;
+            for (int k = seg[j]; k < seg[j + 1]; k += kMelItemBins) {
+                TCR_REQUIRE(n < kMelItemsMax, "front-end: mel filterbank needs more than %d work items", kMelItemsMax);
+                items[n++] = k | (std::min(kMelItemBins, seg[j + 1] - k) << 10) | (j << 14);
+            }
+        }
+        ifirst[L.nseg] = n; ifirst[L.nseg + 1] = n;
+    }
+    // DCT-II as MFMA A fragments (coefficient tile ct, k-step s over the mel index)
+    for (int ct = 0; ct < nm / 16; ++ct)
+        for (int s = 0; s < nm / 4; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int c = 16 * ct + (l & 15), n = 4 * s + (l >> 4);
+                float v = 0.f;
+                if (c < cfg->n_coef) {
+                    v = w[L.dcth + (size_t)c * half + (n < half ? n : nm - 1 - n)];
+                    if (n >= half && (c & 1)) v = -v;
+                }
+                w[L.dct_tab + ((size_t)ct * (nm / 4) + s) * 64 + l] = v;
+            }
     return TCR_OK;
 }
 

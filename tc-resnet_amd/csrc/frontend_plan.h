@@ -17,8 +17,17 @@ struct FrontendPlanLayout {
     size_t seg_start;  // int32  [nseg + 1]      first spectrogram bin of each mel-edge segment
     size_t wud;        // float2 [nbins]         (up-slope weight into filter j, down-slope weight into filter j-1)
     size_t dcth;       // float  [n_coef][n_mel/2]   DCT-II rows folded by the even/odd symmetry
+    // Sparse mel for the packed kernel, load-balanced: every mel-edge segment is cut into items of <= mel_item_bins(nc) bins, one
+    // lane per item (a segment's bins used to be one lane's loop: 2 .. 20 bins, the wave waited for the longest).
+    size_t mel_items;  // int32  [kMelItemsMax]   first bin | bins << 10 | segment << 14
+    size_t mel_ifirst; // int32  [nseg + 2]       first item of segment j; [nseg] = [nseg + 1] = number of items
+    size_t dct_tab;    // float  [n_mel/16][n_mel/4][64]  DCT A fragments: tile ct, step s, lane l -> D[16 ct + (l & 15)][4 s + (l >> 4)] (0 past n_coef)
     size_t words;      // total size in words
 };
+
+constexpr int kMelItemsMax = 192;
+// bins per item: segments are 2 .. 20 bins long at nfft 1024, 1 .. 10 at nfft 512
+constexpr int mel_item_bins(int nc) { return nc == 512 ? 8 : 4; }
 
 inline FrontendPlanLayout frontend_plan_layout(const tcr_frontend_cfg& c) {
     FrontendPlanLayout l{};
@@ -34,6 +43,9 @@ inline FrontendPlanLayout frontend_plan_layout(const tcr_frontend_cfg& c) {
     l.seg_start = take((size_t)l.nseg + 1);
     l.wud = take(2 * (size_t)l.nbins);
     l.dcth = take((size_t)c.n_mel * (size_t)(c.n_mel / 2));   // sized for n_coef == n_mel
+    l.mel_items = take(kMelItemsMax);
+    l.mel_ifirst = take((size_t)l.nseg + 2);
+    l.dct_tab = take((size_t)(c.n_mel / 16) * (size_t)(c.n_mel / 4) * 64);
     l.words = o;
     return l;
 }
