@@ -335,7 +335,8 @@ def profile_avg_us(kernel: str):
     roofline's `kernel_ms` can be recomputed from."""
     import csv
     import glob
-    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_fwd_kernel_stats.csv")), reverse=True):
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_fwd_kernel_stats.csv")), reverse=True)
+    for path in sorted(paths, key=lambda q: "_final_" not in os.path.basename(q)):      # the round's final profile first (stable sort)
         for r in csv.DictReader(open(path)):
             if r["kernel"].startswith(kernel):
                 return round(float(r["avg_ns"]) / 1e3, 2), os.path.join("profiles", os.path.basename(path))

@@ -78,7 +78,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b):
+def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b, grad_tol=2e-5):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), sync_bn, str(tmp_path), kind, name, width, b), nprocs=world, join=True)
     r = [dict(np.load(tmp_path / f"rank{i}.npz")) for i in range(world)]
@@ -97,9 +97,9 @@ def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b):
         # cross-replica statistics == the reference's single-device global-batch BN: everything matches
         assert np.abs(np.concatenate([r[0]["logits"], r[1]["logits"]]) - logits.cpu().numpy()).max() < 2e-5
         assert abs(float(r[0]["loss"]) - float(loss_sum) / (2 * b)) < 1e-5
-        assert np.abs(r[0]["grads"] - g).max() < 2e-5 * max(1.0, np.abs(g).max())
+        assert np.abs(r[0]["grads"] - g).max() < grad_tol * max(1.0, np.abs(g).max())
         net.sgd_momentum_step(0.1, 0.9, 0.001)
-        assert np.abs(r[0]["params"] - net.params.cpu().numpy()).max() < 1e-5
+        assert np.abs(r[0]["params"] - net.params.cpu().numpy()).max() < max(1e-5, 0.1 * grad_tol * max(1.0, np.abs(g).max()))
         assert np.abs(r[0]["stats"] - net.stats.cpu().numpy()).max() < 1e-5
     else:
         # per-replica BN is the documented deviation: finite, but not the global-batch statistics
@@ -117,8 +117,13 @@ def test_two_replicas_match_global_batch_dscnn(emu_lib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_two_replicas_match_global_batch_dscnn_hip(hip_lib, tmp_path):
-    _two_replicas(hip_lib, "hip", tmp_path, True, "DSCNN", "L", 8)
+@pytest.mark.parametrize("size", ["S", "L"])
+def test_two_replicas_match_global_batch_dscnn_hip(hip_lib, tmp_path, size):
+    # The replicas add up the same partial rows in a different grouping than the single process, so scale / shift differ in the last
+    # bit and a ReLU input within ~1e-7 of zero can land on the other side: DS-CNN-L has 6 M ReLU inputs at this batch and statistics
+    # over 2 000 positions, so ONE such flip moves gradient entries by ~5e-4 of the largest (seen: 3.5e-4).  S (0.6 M inputs) is held to
+    # the tight bound; L to 2e-3 with tight logits / loss.  (Staged == unstaged at one replica is bitwise for both: test_gpu_parity.)
+    _two_replicas(hip_lib, "hip", tmp_path, True, "DSCNN", size, 8, grad_tol=2e-5 if size == "S" else 2e-3)
 
 
 @pytest.mark.gpu
