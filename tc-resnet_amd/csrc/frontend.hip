@@ -340,6 +340,7 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     a.dcth = p + L.dcth;
     a.mel_items = reinterpret_cast<const int*>(p + L.mel_items);
     a.mel_ifirst = reinterpret_cast<const int*>(p + L.mel_ifirst);
+    a.mel_wit = reinterpret_cast<const float2*>(p + L.mel_wit);
     a.dct_tab = p + L.dct_tab;
     a.n_samples = cfg->n_samples;
     a.win = cfg->win;

@@ -16,6 +16,7 @@ struct FrontendArgs {
     const float* dcth;
     const int* mel_items;   // load-balanced sparse mel (frontend_plan.h)
     const int* mel_ifirst;
+    const float2* mel_wit;
     const float* dct_tab;
     int n_samples, win, hop, n_frames, n_coef, tp;
     int total_frames;

@@ -173,9 +173,9 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
                                                     // frame's first unit holds its mel items' (up, down) partial sums (wave-local reuse)
     __shared__ float s_p[FPR * PLD];                // 4 x power (or 2 x magnitude) spectrum
     __shared__ float s_lm[NMEL * LMS];              // log-mel [mel][frame], 64 frames
-    __shared__ v2 s_wud[NBINS];                     // mel slopes per bin, pre-scaled by 1/4 (1/2)
-    __shared__ int s_items[kMelItemsMax];           // first bin | bins << 10 | segment << 14
-    static_assert(kMelItemsMax <= UNIT, "the item sums of a frame live in one transpose unit");
+    constexpr int NIT = mel_items_fast(NC);         // items of the unrolled trips
+    __shared__ v2 s_wit[kMelItemBins * NIT];        // mel slopes [bin of the item][item], pre-scaled by 1/4 (1/2), zero past an item's end
+    static_assert(kMelItemsMax <= UNIT && NIT <= UNIT, "the item sums of a frame live in one transpose unit");
 
     const int tid = threadIdx.x;
     const int f = tid / LPF;                // frame slot in the round
@@ -206,12 +206,15 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     {
         const float fold = MAG ? 0.5f : 0.25f;
         const v2* wud = reinterpret_cast<const v2*>(a.wud);
-        for (int i = threadIdx.x; i < NBINS; i += 256) s_wud[i] = wud[i] * fold;
-        for (int i = threadIdx.x; i < kMelItemsMax; i += 256) s_items[i] = a.mel_items[i];
+        const v2* wit = reinterpret_cast<const v2*>(a.mel_wit);
+        for (int i = threadIdx.x; i < kMelItemBins * NIT; i += 256) s_wit[i] = wit[i] * fold;
+        for (int i = threadIdx.x; i < FPR * (PLD - NBINS); i += 256)       // row pads: read (times a zero slope) past an item's end
+            s_p[(i / (PLD - NBINS)) * PLD + NBINS + i % (PLD - NBINS)] = 0.f;
+        (void)wud;
     }
     const int nitems = a.mel_ifirst[NSEG];
     // round-invariant: the items this lane takes (one per trip) and the item ranges of the bands it finishes
-    constexpr int TRIPS = NC == 512 ? 3 : 5;
+    constexpr int TRIPS = mel_trips(NC);
     int item_d[TRIPS], band_i[NMEL / LPF];
 #pragma unroll
     for (int tr = 0; tr < TRIPS; ++tr) item_d[tr] = a.mel_items[min(lf + LPF * tr, kMelItemsMax - 1)];
@@ -308,37 +311,36 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
         v2* UD = s_x + (f * SUB) * UNIT;                    // (this frame's first unit: dead until the next round's first pass)
         {
             const float* P = s_p + f * PLD;
-            const int skew = (lf / (32 / kMelItemBins)) & (kMelItemBins - 1);   // lanes a bank period apart start 1 bin apart
 #pragma unroll 1
             for (int tr = 0; tr < TRIPS; ++tr) {            // (rolled: one trip's 16 reads in flight, not all trips' -- register budget)
                 const int it = lf + LPF * tr;
-                if (it < nitems) {
-                    int d = item_d[0];
+                int d = item_d[0];
 #pragma unroll
-                    for (int q = 1; q < TRIPS; ++q) d = tr == q ? item_d[q] : d;
+                for (int q = 1; q < TRIPS; ++q) d = tr == q ? item_d[q] : d;
+                const float* pk = P + (d & 1023);            // (items past the filterbank's last: bin 0 with zero slopes)
+                const v2* wk = s_wit + it;
+                float p[kMelItemBins];
+                v2 wv[kMelItemBins];
+#pragma unroll
+                for (int b = 0; b < kMelItemBins; ++b) {    // constant offsets from two per-lane bases: no per-bin address arithmetic,
+                    p[b] = pk[b];                           // no masks (slopes past the item's end are zero, the row pad is zero)
+                    wv[b] = wk[b * NIT];
+                }
+                v2 ud = (v2){0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < kMelItemBins; ++b) ud = __builtin_elementwise_fma(wv[b], (v2){p[b], p[b]}, ud);
+                UD[it] = ud;
+            }
+            if (nitems > NIT) {                             // (filterbanks with more items than the trips cover: slow path)
+                const float fold = MAG ? 0.5f : 0.25f;
+                const v2* wud = reinterpret_cast<const v2*>(a.wud);
+                for (int it = lf + NIT; it < nitems; it += LPF) {
+                    const int d = a.mel_items[it];
                     const int k0 = d & 1023, nb = (d >> 10) & 15;
-                    float p[kMelItemBins];
-                    v2 wv[kMelItemBins];
-#pragma unroll
-                    for (int b = 0; b < kMelItemBins; ++b) {    // all reads of the item in flight
-                        const int bb = (b + skew) & (kMelItemBins - 1);
-                        const int k = min(k0 + bb, NBINS - 1);
-                        p[b] = P[k];
-                        wv[b] = s_wud[k];
-                        if (bb >= nb) wv[b] = (v2){0.f, 0.f};
-                    }
                     v2 ud = (v2){0.f, 0.f};
-#pragma unroll
-                    for (int b = 0; b < kMelItemBins; ++b) ud = __builtin_elementwise_fma(wv[b], (v2){p[b], p[b]}, ud);
+                    for (int b = 0; b < nb; ++b) ud = __builtin_elementwise_fma(wud[k0 + b] * fold, (v2){P[k0 + b], P[k0 + b]}, ud);
                     UD[it] = ud;
                 }
-            }
-            for (int it = lf + LPF * TRIPS; it < nitems; it += LPF) {       // (filterbanks with more items than TRIPS trips cover)
-                const int d = s_items[it];
-                const int k0 = d & 1023, nb = (d >> 10) & 15;
-                v2 ud = (v2){0.f, 0.f};
-                for (int b = 0; b < nb; ++b) ud = __builtin_elementwise_fma(s_wud[k0 + b], (v2){P[k0 + b], P[k0 + b]}, ud);
-                UD[it] = ud;
             }
         }
         wave_sync();
@@ -348,9 +350,20 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
             for (int i = 0; i < NMEL / LPF; ++i) {
                 const int m = lf + LPF * i;
                 const int i0 = band_i[i] & 255, i1 = (band_i[i] >> 8) & 255, i2 = band_i[i] >> 16;
+                constexpr int MAXC = NC == 512 ? 3 : 2;     // items per segment read unconditionally (segments: <= 20 bins / 8, <= 10 bins / 4 mostly <= 8)
+                float up[MAXC], dn[MAXC];
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {            // all reads in flight
+                    up[c] = UD[min(i0 + c, UNIT - 1)].x;
+                    dn[c] = UD[min(i1 + c, UNIT - 1)].y;
+                }
                 float mel = 0.f;
-                for (int it = i0; it < i1; ++it) mel += UD[it].x;
-                for (int it = i1; it < i2; ++it) mel += UD[it].y;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) mel += i0 + c < i1 ? up[c] : 0.f;
+                for (int it = i0 + MAXC; it < i1; ++it) mel += UD[it].x;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) mel += i1 + c < i2 ? dn[c] : 0.f;
+                for (int it = i1 + MAXC; it < i2; ++it) mel += UD[it].y;
                 s_lm[m * LMS + r * FPR + f] = a.log_floor ? logf(fmaxf(mel, 1e-12f)) : logf(mel + 1e-6f);
             }
         }

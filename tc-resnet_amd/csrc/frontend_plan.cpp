@@ -201,6 +201,14 @@ extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_pl
             }
         }
         ifirst[L.nseg] = n; ifirst[L.nseg + 1] = n;
+        const int nfast = mel_items_fast(L.nc);
+        for (int i = 0; i < n && i < nfast; ++i) {
+            const int k0 = items[i] & 1023, nb = (items[i] >> 10) & 15;
+            for (int b = 0; b < nb; ++b) {
+                w[L.mel_wit + 2 * ((size_t)b * nfast + i)] = w[L.wud + 2 * (k0 + b)];
+                w[L.mel_wit + 2 * ((size_t)b * nfast + i) + 1] = w[L.wud + 2 * (k0 + b) + 1];
+            }
+        }
     }
     // DCT-II as MFMA A fragments (coefficient tile ct, k-step s over the mel index)
     for (int ct = 0; ct < nm / 16; ++ct)

@@ -21,6 +21,9 @@ struct FrontendPlanLayout {
     // lane per item (a segment's bins used to be one lane's loop: 2 .. 20 bins, the wave waited for the longest).
     size_t mel_items;  // int32  [kMelItemsMax]   first bin | bins << 10 | segment << 14
     size_t mel_ifirst; // int32  [nseg + 2]       first item of segment j; [nseg] = [nseg + 1] = number of items
+    size_t mel_wit;    // float2 [mel_item_bins][mel_items_fast]  (up, down) slopes of bin b of item i, zero past the item's end and for
+                       //                        items the filterbank does not have: the kernel's LDS copy (bin-major: a trip's lanes read
+                       //                        consecutive items -> consecutive addresses), pre-scaled like `wud` is NOT (the kernel folds)
     size_t dct_tab;    // float  [n_mel/16][n_mel/4][64]  DCT A fragments: tile ct, step s, lane l -> D[16 ct + (l & 15)][4 s + (l >> 4)] (0 past n_coef)
     size_t words;      // total size in words
 };
@@ -28,6 +31,9 @@ struct FrontendPlanLayout {
 constexpr int kMelItemsMax = 192;
 // bins per item: segments are 2 .. 20 bins long at nfft 1024, 1 .. 10 at nfft 512
 constexpr int mel_item_bins(int nc) { return nc == 512 ? 8 : 4; }
+// items the packed kernel handles with its unrolled trips (trips x lanes per frame); a filterbank with more items runs the rest in a slow loop
+constexpr int mel_trips(int nc) { return nc == 512 ? 3 : 5; }
+constexpr int mel_items_fast(int nc) { return mel_trips(nc) * (nc / 16); }
 
 inline FrontendPlanLayout frontend_plan_layout(const tcr_frontend_cfg& c) {
     FrontendPlanLayout l{};
@@ -45,6 +51,7 @@ inline FrontendPlanLayout frontend_plan_layout(const tcr_frontend_cfg& c) {
     l.dcth = take((size_t)c.n_mel * (size_t)(c.n_mel / 2));   // sized for n_coef == n_mel
     l.mel_items = take(kMelItemsMax);
     l.mel_ifirst = take((size_t)l.nseg + 2);
+    l.mel_wit = take(2 * (size_t)mel_item_bins(l.nc) * (size_t)mel_items_fast(l.nc));
     l.dct_tab = take((size_t)(c.n_mel / 16) * (size_t)(c.n_mel / 4) * 64);
     l.words = o;
     return l;
