@@ -105,6 +105,32 @@ __device__ __forceinline__ v2 c_mulc(v2 a, v2 b) {
 #endif
 }
 
+// Cross-lane moves of the real-FFT split (no LDS round trip):
+//   row_swap: the odd 16-lane rows of `a` trade places with the even rows of `b` (v_permlane16_swap_b32) -- a frame's two
+//             256-point units sit in adjacent rows, so one swap per register pair hands every lane E[k] and O[k] of ITS bins;
+//   lane_gather: value of an arbitrary lane (ds_bpermute_b32: the LDS crossbar, no memory, no bank conflicts).
+__device__ __forceinline__ void row_swap(float& a, float& b, int lane) {
+#if TCR_PK_ASM
+    (void)lane;
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+#else
+    const float ax = __shfl_xor(a, 16), bx = __shfl_xor(b, 16);
+    const bool odd = (lane >> 4) & 1;
+    const float na = odd ? bx : a, nb = odd ? b : ax;
+    a = na;
+    b = nb;
+#endif
+}
+__device__ __forceinline__ float lane_gather(float v, int src_lane) {
+#if TCR_PK_ASM
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+#else
+    return __shfl(v, src_lane);
+#endif
+}
+
 // 4-point forward DFT (W4 = -i), in place: 8 packed instructions.
 __device__ __forceinline__ void pk_dft4(v2& a, v2& b, v2& c, v2& d) {
     const v2 t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
@@ -268,27 +294,40 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
         // ---------------- transpose + second radix-16 pass ----------------
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = s_x[unit * UNIT + l * XLD + n1];
-        pk_dft16(v);
-        wave_sync();
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) s_x[unit * UNIT + 16 * k1 + l] = v[k1];     // bin 16 k1 + l
-        wave_sync();
-        // ---------------- real-FFT split -> 4 x power spectrum ----------------
+        pk_dft16(v);                                                                // v[k1] = bin 16 k1 + l of this lane's unit
+        // ---------------- real-FFT split -> 4 x power spectrum, operands moved between lanes in registers ----------------
+        // Lane (h, l) of a frame (h: its 256-point unit, l: lane in the unit) finishes bins k_i = lf + LPF i, i < 8:
+        //   nfft 1024: k_i = 16 (2 i + h) + l -- E[k_i], O[k_i] are registers 2 i + h of lanes (0, l), (1, l): one row swap per pair
+        //              hands both to the lane; Z[k] = E + W^k O and Z[k + 256] = E - W^k O (the butterfly's other output);
+        //              Z[512 - k_i] = Z[k' + 256] with k' = 256 - k_i, finished by lane (1 - h, 16 - l) as its bin 7 - i;
+        //   nfft  512: k_i = 16 i + l is register i; Z[256 - k_i] is register 15 - i of lane 16 - l.
+        // Lanes with l = 0 pair with themselves (a gather from self), except lane 0 of the frame, whose partner registers are
+        // one further along (bins 16 * even) and whose bin 0 pairs with itself.
         {
-            const v2* E = s_x + (f * SUB) * UNIT;
-            const v2* O = s_x + (f * SUB + SUB - 1) * UNIT;
             float* P = s_p + f * PLD;
+            const int lane = tid & 63;
+            const int partner = (lane & ~(LPF - 1)) | (SUB == 2 ? (l ? (16 * (1 - u) + 16 - l) : 16 * u) : ((16 - l) & 15));
+            if (SUB == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float ex = v[2 * i].x, ey = v[2 * i].y, ox = v[2 * i + 1].x, oy = v[2 * i + 1].y;
+                    row_swap(ex, ox, lane);
+                    row_swap(ey, oy, lane);
+                    const v2 t = c_mul((v2){ox, oy}, twc[i]);
+                    const v2 e = (v2){ex, ey};
+                    v[2 * i] = e + t;                       // Z[k_i]
+                    v[2 * i + 1] = e - t;                   // Z[k_i + 256]
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int k = lf + LPF * i;                 // 0 .. NC/2-1
-                const int kn = (SUB == 2) ? ((256 - k) & 255) : ((NC - k) & (NC - 1));
-                v2 zk, zn;
-                if (SUB == 2) {
-                    zk = E[k] + c_mul(O[k], twc[i]);        // Z[k]      = E[k] + W512^k O[k]
-                    zn = E[kn] + c_mulc(O[kn], twc[i]);     // Z[512-k]  = E[256-k] + conj(W512^k) O[256-k]
-                } else {
-                    zk = E[k];
-                    zn = E[kn];
+                const v2 zk = SUB == 2 ? v[2 * i] : v[i];
+                const v2 src = SUB == 2 ? v[15 - 2 * i] : v[15 - i];
+                v2 zn = (v2){lane_gather(src.x, partner), lane_gather(src.y, partner)};
+                if (lf == 0) {
+                    if (SUB == 2) zn = i == 0 ? v[0] : v[17 - 2 * i > 15 ? 15 : 17 - 2 * i];
+                    else zn = i == 0 ? v[0] : v[16 - i > 15 ? 15 : 16 - i];
                 }
                 float plo, phi;
                 pk_real_pair_power(zk, zn, twr[i], plo, phi);
@@ -297,9 +336,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
                 P[NC - k] = phi;
             }
             if (lf == 0) {                                  // the self-paired middle bin k = NC/2
-                v2 z;
-                if (SUB == 2) z = E[0] - O[0];              // Z[256] = E[0] - O[0]
-                else z = E[NC / 2];
+                const v2 z = SUB == 2 ? v[1] : v[8];        // Z[256] = E[0] - O[0]; nfft 512: bin 128 = register 8
                 float plo, phi;
                 pk_real_pair_power(z, z, twmid, plo, phi);
                 if (MAG) plo = sqrtf(plo);
