@@ -173,9 +173,19 @@ __device__ __forceinline__ void pk_dft16(v2 (&v)[16]) {
 __device__ __forceinline__ void pk_real_pair_power(v2 zk, v2 zn, v2 wmi, float& p_lo, float& p_hi) {
     const v2 A = c_addc(zk, zn), D = c_subc(zk, zn);
     const v2 C = c_mul(D, wmi);
+#if TCR_PK_ASM
+    // (X.x, Y.x) and (X.y, Y.y) packed side by side: both squared magnitudes in one pk_mul + one pk_fma
+    v2 xs, ys;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(xs) : "v"(A), "v"(C));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(ys) : "v"(A), "v"(C));
+    const v2 p = __builtin_elementwise_fma(xs, xs, ys * ys);
+    p_lo = p.x;
+    p_hi = p.y;
+#else
     const v2 X = A + C, Y = A - C;
     p_lo = fmaf(X.x, X.x, X.y * X.y);
     p_hi = fmaf(Y.x, Y.x, Y.y * Y.y);
+#endif
 }
 
 // QV: number of leading radix-16 inputs per lane that fall inside the analysis window -- identical for every lane when
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const v2 wm = tw_real[NC / 2];
     const v2 twmid = (v2){wm.y, -wm.x};
-    __syncthreads();
+    // (no barrier here: the LDS tables staged above are first read by round 0's mel phase -- the barrier sits there, behind the FFT)
 
     const float inv_frames = 1.0f / (float)a.n_frames;
     const int rounds = a.rounds;            // <= ROUNDS; chosen by the launcher so that the grid fills whole dispatch waves
@@ -319,16 +329,15 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
                     v[2 * i + 1] = e - t;                   // Z[k_i + 256]
                 }
             }
-#pragma unroll
+            v2 prev = v[0];                                 // lane 0 of the frame: bin 0 pairs with itself, and its partner register
+#pragma unroll                                              // of step i is the one its self-gather of step i - 1 returned
             for (int i = 0; i < 8; ++i) {
                 const int k = lf + LPF * i;                 // 0 .. NC/2-1
                 const v2 zk = SUB == 2 ? v[2 * i] : v[i];
                 const v2 src = SUB == 2 ? v[15 - 2 * i] : v[15 - i];
-                v2 zn = (v2){lane_gather(src.x, partner), lane_gather(src.y, partner)};
-                if (lf == 0) {
-                    if (SUB == 2) zn = i == 0 ? v[0] : v[17 - 2 * i > 15 ? 15 : 17 - 2 * i];
-                    else zn = i == 0 ? v[0] : v[16 - i > 15 ? 15 : 16 - i];
-                }
+                const v2 g = (v2){lane_gather(src.x, partner), lane_gather(src.y, partner)};
+                const v2 zn = lf == 0 ? prev : g;
+                prev = g;
                 float plo, phi;
                 pk_real_pair_power(zk, zn, twr[i], plo, phi);
                 if (MAG) { plo = sqrtf(plo); phi = sqrtf(phi); }
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
             }
         }
         wave_sync();
+        if (r == 0) __syncthreads();                        // the slope table / zeroed row pads staged in the prologue
         // ---------------- sparse mel: one item (<= 8 bins of one segment) per lane and trip, one packed FMA per bin ----------------
         v2* UD = s_x + (f * SUB) * UNIT;                    // (this frame's first unit: dead until the next round's first pass)
         {
