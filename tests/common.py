@@ -401,7 +401,7 @@ def check_dscnn_staged_equals_unstaged(lib, size, batch):
         assert torch.equal(a, b), f"DS-CNN-{size}: staged {what} differ from the unstaged run"
 
 
-def check_bn_backward_fused_equals_pair(lib, name, width, batch, seed=3):
+def check_bn_backward_fused_equals_pair(lib, name, width, batch, seed=3, combos=((0, 0), (1, 0), (96, 0), (0, 1), (1, 1))):
     """BN backward with the finalize folded into the apply pass (default) is BITWISE the finalize + apply pair (TCR_TUNE_BWD_BN_FUSED
     = 1): same channel blocks, same slice order of the partial rows -- so also bitwise the staged (sync BN) path at one replica."""
     import tcresnet_amd as T
@@ -414,7 +414,7 @@ def check_bn_backward_fused_equals_pair(lib, name, width, batch, seed=3):
     ch = R.tcresnet_channels(name, float(width))
     grads = []
     try:
-        for knob, mask in ((0, 0), (1, 0), (96, 0), (0, 1), (1, 1)):
+        for knob, mask in combos:
             lib.tcr_tune(11, knob)
             lib.tcr_tune(12, mask)          # 1: ReLU masks read back from the activations instead of recomputed from the raw outputs
             net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)

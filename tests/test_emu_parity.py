@@ -136,8 +136,8 @@ def test_backward_phases_opt_in(emu_lib):
 
 
 def test_bn_backward_fused_equals_pair(emu_lib):
-    Cm.check_bn_backward_fused_equals_pair(emu_lib, "TCResNet8", 1.0, 5)
-    Cm.check_bn_backward_fused_equals_pair(emu_lib, "TCResNet14", 1.5, 3)       # 36 / 72 channels: channel blocks of 4 and 8
+    Cm.check_bn_backward_fused_equals_pair(emu_lib, "TCResNet8", 1.0, 3, combos=((0, 0), (1, 1), (96, 0)))
+    Cm.check_bn_backward_fused_equals_pair(emu_lib, "TCResNet14", 1.5, 2, combos=((96, 0), (1, 1)))    # 36 / 72 channels: channel blocks of 4 and 8
     Cm.check_dscnn_mask_paths_agree(emu_lib, "S", 3)
 
 
