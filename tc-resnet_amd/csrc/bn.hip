@@ -242,12 +242,53 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
     a.out[i] = v;
 }
 
+// Four consecutive elements per thread (one 16-byte load / store per tensor): the elementwise BN passes of the big-activation
+// nets (DS-CNN-L: 600 MB tensors) are pure HBM streams.  The four elements may straddle a channel row: channel and frame index
+// are per element (same expressions as the scalar kernel -> bitwise the same results).
+typedef float bn_f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const BnApplyArgs a) {
+    const int per_utt = a.c * a.tp;
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j0 >= per_utt) return;
+    const size_t i0 = (size_t)blockIdx.y * per_utt + j0;
+    const bn_f4 y4 = *reinterpret_cast<const bn_f4*>(a.y + i0);
+    bn_f4 r4 = (bn_f4){0.f, 0.f, 0.f, 0.f};
+    if (a.res) r4 = *reinterpret_cast<const bn_f4*>(a.res + i0);
+    int c = (int)(((float)j0 + 0.5f) * a.inv_tp);
+    c += (c + 1) * a.tp <= j0 ? 1 : (c * a.tp > j0 ? -1 : 0);
+    bn_f4 o4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + e;
+        const int ce = c + (j >= (c + 1) * a.tp ? 1 : 0);        // (tp >= 9: at most one row boundary inside the four)
+        const int tt = j - ce * a.tp - kHalo;
+        float v = 0.f;
+        if (tt >= 0 && tt < a.t) {
+            v = fmaf(y4[e], a.scale[ce], a.shift[ce]);
+            if (a.res) v = fmaxf(v + r4[e], 0.f);
+            else if (a.relu) v = fmaxf(v, 0.f);
+        }
+        o4[e] = v;
+    }
+    *reinterpret_cast<bn_f4*>(a.out + i0) = o4;
+}
+
+static bool bn_vec4_ok(const void* p0, const void* p1, const void* p2, const void* p3, int per_utt) {
+    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return per_utt % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3) && tune_get(TCR_TUNE_BWD_MASK) != 2;
+}
+
 int launch_bn_apply(const BnApplyArgs& a0, hipStream_t s) {
     BnApplyArgs a = a0;
     a.inv_tp = 1.0f / (float)a.tp;
     const int per_utt = a.c * a.tp;
     const int batch = (int)(a.total / per_utt);
     if (per_utt >= (1 << 22) || batch > 65535) { set_error("bn_apply: %d x %d exceeds the launch geometry", batch, per_utt); return TCR_ERR_ARG; }
+    if (bn_vec4_ok(a.y, a.res, a.out, nullptr, per_utt)) {
+        hipLaunchKernelGGL(bn_apply4_kernel, dim3(ceil_div(per_utt / 4, 256), batch), dim3(256), 0, s, a);
+        return check_launch("bn_apply4_kernel");
+    }
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ceil_div(per_utt, 256), batch), dim3(256), 0, s, a);
     return check_launch("bn_apply_kernel");
 }
@@ -298,12 +339,48 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
     a.dy[i] = v;
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const BnBwdApplyArgs a) {        // (see bn_apply4_kernel)
+    const int per_utt = a.c * a.tp;
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j0 >= per_utt) return;
+    const size_t i0 = (size_t)blockIdx.y * per_utt + j0;
+    const bn_f4 y4 = *reinterpret_cast<const bn_f4*>(a.y + i0);
+    bn_f4 d4 = (bn_f4){0.f, 0.f, 0.f, 0.f}, m14 = (bn_f4){1.f, 1.f, 1.f, 1.f}, m24 = m14;
+    if (!a.bcast) d4 = *reinterpret_cast<const bn_f4*>(a.da + i0);
+    if (a.m1) m14 = *reinterpret_cast<const bn_f4*>(a.m1 + i0);
+    if (a.m2) m24 = *reinterpret_cast<const bn_f4*>(a.m2 + i0);
+    int c = (int)(((float)j0 + 0.5f) * a.inv_tp);
+    c += (c + 1) * a.tp <= j0 ? 1 : (c * a.tp > j0 ? -1 : 0);
+    bn_f4 o4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + e;
+        const int ce = c + (j >= (c + 1) * a.tp ? 1 : 0);
+        const int tt = j - ce * a.tp - kHalo;
+        float v = 0.f;
+        if (tt >= 0 && tt < a.t) {
+            float dz = a.bcast ? a.da[(size_t)blockIdx.y * a.c + ce] : d4[e];
+            if (a.m1 && !(m14[e] > 0.f)) dz = 0.f;
+            if (a.m2 && !(m24[e] > 0.f)) dz = 0.f;
+            const float yv = y4[e];
+            if (a.self_scale && !(fmaf(yv, a.self_scale[ce], a.self_shift[ce]) > 0.f)) dz = 0.f;
+            v = a.k1[ce] * (dz - a.k2[ce] - (yv - a.mean[ce]) * a.k3[ce]);
+        }
+        o4[e] = v;
+    }
+    *reinterpret_cast<bn_f4*>(a.dy + i0) = o4;
+}
+
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a0, hipStream_t s) {
     BnBwdApplyArgs a = a0;
     a.inv_tp = 1.0f / (float)a.tp;
     const int per_utt = a.c * a.tp;
     const int batch = (int)(a.total / per_utt);
     if (per_utt >= (1 << 22) || batch > 65535) { set_error("bn_bwd_apply: %d x %d exceeds the launch geometry", batch, per_utt); return TCR_ERR_ARG; }
+    if (!a.accumulate && bn_vec4_ok(a.y, a.bcast ? nullptr : a.da, a.m1, a.m2, per_utt) && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) {
+        hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(ceil_div(per_utt / 4, 256), batch), dim3(256), 0, s, a);
+        return check_launch("bn_bwd_apply4_kernel");
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(per_utt, 256), batch), dim3(256), 0, s, a);
     return check_launch("bn_bwd_apply_kernel");
 }

@@ -940,7 +940,7 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         ChanReduceArgs r;
         std::memset(&r, 0, sizeof(r));
         r.y = base + w.raw[ui]; r.da = ui == nu - 1 ? base + w.dpool : ga; r.m1 = base + w.act[ui]; r.m2 = nullptr;
-        if (tune_get(TCR_TUNE_BWD_MASK) == 0) {     // the unit's own ReLU mask from its raw output (one tensor read less)
+        if (tune_get(TCR_TUNE_BWD_MASK) != 1) {     // the unit's own ReLU mask from its raw output (one tensor read less)
             r.m1 = nullptr; r.self_scale = base + w.ss + u.ss_off; r.self_shift = r.self_scale + cp;
         }
         r.mean = base + w.mean[ui]; r.invstd = base + w.invstd[ui];
@@ -978,7 +978,7 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         BnBwdApplyArgs ap;
         ap.accumulate = 0;
         ap.y = raw; ap.da = da; ap.m1 = act; ap.m2 = nullptr; ap.mean = base + w.mean[ui];
-        if (tune_get(TCR_TUNE_BWD_MASK) == 0) { ap.m1 = nullptr; ap.self_scale = base + w.ss + u.ss_off; ap.self_shift = ap.self_scale + cp; }
+        if (tune_get(TCR_TUNE_BWD_MASK) != 1) { ap.m1 = nullptr; ap.self_scale = base + w.ss + u.ss_off; ap.self_shift = ap.self_scale + cp; }
         ap.k1 = f.k1; ap.k2 = f.k2; ap.k3 = f.k3; ap.dy = dz;
         ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.bcast = bcast;
         TCR_TRY(launch_bn_bwd_apply(ap, s));

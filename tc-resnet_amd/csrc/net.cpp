@@ -826,7 +826,7 @@ static BwdUnit bwd_unit_of(const TrainCtx& c, int li, const float* dpool, bool m
     BwdUnit u;
     u.li = li; u.da = nullptr; u.da_bcast = 0; u.m1 = nullptr; u.m2 = nullptr; u.self_ss = nullptr; u.self_cpad = 0;
     const int last = net.blocks.back().b;
-    const bool recompute = masks_from_raw && tune_get(TCR_TUNE_BWD_MASK) == 0;      // (the group-resident phases read the activations)
+    const bool recompute = masks_from_raw && tune_get(TCR_TUNE_BWD_MASK) != 1;      // (the group-resident phases read the activations)
     auto own = [&](const float** m) {       // the unit's own activation is relu(bn(raw)): its mask needs no second tensor
         if (!recompute) return;
         *m = nullptr;

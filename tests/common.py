@@ -438,7 +438,7 @@ def check_dscnn_mask_paths_agree(lib, size, batch, seed=5):
     labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
     grads = []
     try:
-        for mask in (0, 1):
+        for mask in (0, 1, 2):              # 2: the scalar (one element per thread) elementwise BN kernels instead of the 4-wide ones
             lib.tcr_tune(12, mask)
             ds = T.DSCNN(size, t, f, 12, lib=lib, device=dev)
             ds.init_xavier(2)
@@ -447,3 +447,4 @@ def check_dscnn_mask_paths_agree(lib, size, batch, seed=5):
     finally:
         lib.tcr_tune(12, 0)
     assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
+    assert torch.equal(grads[0], grads[2]), float((grads[0] - grads[2]).abs().max())
