@@ -392,7 +392,7 @@ int launch_bn_bwd_apply(const BnBwdApplyArgs& a0, hipStream_t s) {
 constexpr int kFG = 8;                  // channels per workgroup (divides kBnCB: a group never straddles a finalize block)
 constexpr int kFusedMaxParts = 64;
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFinalizeArgs f, const BnBwdApplyArgs a, int utt_per_slab, int batch) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFinalizeArgs f, const BnBwdApplyArgs a, int utt_per_slab, int batch, int vec4) {
     __shared__ double s_slices[kFusedMaxParts * 2 * kFG];
     __shared__ float s_k[3][kFG];
     const int g0 = blockIdx.y * kFG, gw = min(kFG, a.c - g0);
@@ -441,6 +441,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFina
     const int e_per = gw * a.tp;                                // this group's floats of one utterance (contiguous)
     const float inv_e = 1.0f / (float)e_per;
     const int total = (n1 - n0) * e_per;
+    if (vec4) {                                                 // four consecutive elements per thread and trip (see bn_apply4_kernel)
+        for (int idx = threadIdx.x * 4; idx < total; idx += 1024) {
+            int nl = (int)(((float)idx + 0.5f) * inv_e);
+            nl += (nl + 1) * e_per <= idx ? 1 : (nl * e_per > idx ? -1 : 0);
+            const int e0 = idx - nl * e_per;                    // (e_per % 4 == 0: the four stay inside one utterance)
+            int c0 = (int)(((float)e0 + 0.5f) * a.inv_tp);
+            c0 += (c0 + 1) * a.tp <= e0 ? 1 : (c0 * a.tp > e0 ? -1 : 0);
+            const int n = n0 + nl;
+            const size_t i0 = ((size_t)n * a.c + g0) * a.tp + e0;
+            const bn_f4 y4 = *reinterpret_cast<const bn_f4*>(a.y + i0);
+            bn_f4 d4 = (bn_f4){0.f, 0.f, 0.f, 0.f}, m14 = (bn_f4){1.f, 1.f, 1.f, 1.f}, m24 = m14;
+            if (!a.bcast) d4 = *reinterpret_cast<const bn_f4*>(a.da + i0);
+            if (a.m1) m14 = *reinterpret_cast<const bn_f4*>(a.m1 + i0);
+            if (a.m2) m24 = *reinterpret_cast<const bn_f4*>(a.m2 + i0);
+            bn_f4 o4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q;
+                const int cl = c0 + (e >= (c0 + 1) * a.tp ? 1 : 0);
+                const int tt = e - cl * a.tp - kHalo;
+                float v = 0.f;
+                if (tt >= 0 && tt < a.t) {
+                    float dz = a.bcast ? a.da[(size_t)n * a.c + g0 + cl] : d4[q];
+                    if (a.m1 && !(m14[q] > 0.f)) dz = 0.f;
+                    if (a.m2 && !(m24[q] > 0.f)) dz = 0.f;
+                    const float yv = y4[q];
+                    if (a.self_scale && !(fmaf(yv, a.self_scale[g0 + cl], a.self_shift[g0 + cl]) > 0.f)) dz = 0.f;
+                    v = s_k[0][cl] * (dz - s_k[1][cl] - (yv - a.mean[g0 + cl]) * s_k[2][cl]);
+                }
+                o4[q] = v;
+            }
+            *reinterpret_cast<bn_f4*>(a.dy + i0) = o4;
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         int nl = (int)(((float)idx + 0.5f) * inv_e);
         nl += (nl + 1) * e_per <= idx ? 1 : (nl * e_per > idx ? -1 : 0);
@@ -480,7 +515,10 @@ int launch_bn_bwd_apply_fused(const BnBwdFinalizeArgs& f, const BnBwdApplyArgs& 
     int nslab = max(1, min(batch, want / groups));
     const int ups = ceil_div(batch, nslab);
     nslab = ceil_div(batch, ups);
-    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(nslab, groups), dim3(256), 0, s, f, a, ups, batch);
+    // 16-byte accesses: every channel group's block of an utterance is a multiple of four floats and starts on one
+    const int vec4 = ((kFG * a.tp) % 4 == 0 && (a.c * a.tp) % 4 == 0 && ((a.c % kFG) * a.tp) % 4 == 0 &&
+                      bn_vec4_ok(a.y, a.bcast ? nullptr : a.da, a.m1, a.m2, per_utt) && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(nslab, groups), dim3(256), 0, s, f, a, ups, batch, vec4);
     return check_launch("bn_bwd_apply_fused_kernel");
 }
 
