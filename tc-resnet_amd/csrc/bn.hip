@@ -31,6 +31,16 @@ int launch_bn_fold(const BnFoldArgs& a, hipStream_t s) {
     return check_launch("bn_fold_kernel");
 }
 
+typedef float bn_f4 __attribute__((ext_vector_type(4)));
+
+// 16-byte (four elements per thread) variants apply: pointers aligned, rows of an utterance a multiple of four floats
+// (TCR_TUNE_BWD_MASK = 2: scalar elementwise kernels, bitwise the same; 3: also the scalar reduction kernel, another summation order)
+static bool bn_vec4_ok(const void* p0, const void* p1, const void* p2, const void* p3, int per_utt, bool reduction = false) {
+    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int knob = tune_get(TCR_TUNE_BWD_MASK);
+    return per_utt % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3) && knob != 3 && (reduction || knob != 2);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic per-channel reduction of up to two quantities over [B][C][Tp].
 //   MODE 0 (forward stats):   q1 = y, q2 = y*y
@@ -102,24 +112,121 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
     }
 }
 
-int chan_reduce_chunks(int npos) {
+int chan_reduce_chunks(int npos) {      // upper bound of the partial rows (workspace sizing)
     int n = ceil_div(npos, 512);        // >= 2 positions per thread; many short workgroups hide the load latency
     if (n > 512) n = 512;
     if (n < 1) n = 1;
     return n;
 }
 
-// number of partial rows launch_chan_reduce() writes for npos positions (grid.x)
-int chan_reduce_launch_chunks(int npos) {
-    const int nchunk = chan_reduce_chunks(npos);
-    return ceil_div(npos, ceil_div(npos, nchunk));
+// positions per workgroup: whole utterances where an utterance fits (the 16-byte kernel below needs that)
+static int chan_reduce_ppb(int npos, int t) {
+    int ppb = ceil_div(npos, chan_reduce_chunks(npos));
+    if (t > 0 && t <= ppb && npos % t == 0) ppb = ceil_div(ppb, t) * t;
+    return ppb;
+}
+
+// number of partial rows launch_chan_reduce() writes for npos positions of t-frame utterances (grid.x)
+int chan_reduce_launch_chunks(int npos, int t) { return ceil_div(npos, chan_reduce_ppb(npos, t)); }
+
+// Same sums with 16-byte loads: a workgroup owns 8 channels x a run of whole utterances; the 8 channel rows of an utterance are
+// one contiguous block of 8 * Tp floats and thread f always takes floats 4 f .. 4 f + 3 of it, so the channel / frame of each of
+// its four elements is fixed: four accumulator pairs per thread, no per-element index arithmetic in the loop.  Afterwards the
+// threads of a channel (a contiguous range of f) are added in thread order, element order 0..3 (fixed: bitwise reproducible).
+template <int MODE>
+__global__ __launch_bounds__(512) void chan_reduce4_kernel(const ChanReduceArgs a) {
+    constexpr int CT = 8;
+    __shared__ float s_q[2][4][512];
+    const int c0 = blockIdx.y * CT, gw = min(CT, a.c - c0);
+    const int nt = blockDim.x;
+    const int e0 = threadIdx.x * 4, e_per = gw * a.tp;
+    const bool active = e0 < e_per;
+    int ce[4];
+    bool ok[4];
+    float mu[4], is[4], ssc[4], ssh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q;
+        int c = e / a.tp;
+        const int tt = e - c * a.tp - kHalo;
+        ok[q] = active && e < e_per && tt >= 0 && tt < a.t;
+        c = min(c, gw - 1);
+        ce[q] = c;
+        mu[q] = MODE == 1 ? a.mean[c0 + c] : 0.f;
+        is[q] = MODE == 1 ? a.invstd[c0 + c] : 0.f;
+        ssc[q] = (MODE == 1 && a.self_scale) ? a.self_scale[c0 + c] : 0.f;
+        ssh[q] = (MODE == 1 && a.self_scale) ? a.self_shift[c0 + c] : 1.f;
+    }
+    float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int upb = a.pos_per_block / a.t;                      // utterances per workgroup
+    const int n0 = blockIdx.x * upb, n1 = min(n0 + upb, a.npos / a.t);
+    if (active) {
+        const size_t ustride = (size_t)a.c * a.tp;
+        const size_t base = (size_t)c0 * a.tp + e0;
+        for (int n = n0; n < n1; ++n) {
+            const size_t i0 = n * ustride + base;
+            const bn_f4 y4 = *reinterpret_cast<const bn_f4*>(a.y + i0);
+            if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float yv = ok[q] ? y4[q] : 0.f;
+                    q1[q] += yv;
+                    q2[q] = fmaf(yv, yv, q2[q]);
+                }
+            } else {
+                bn_f4 d4 = (bn_f4){0.f, 0.f, 0.f, 0.f}, m14 = (bn_f4){1.f, 1.f, 1.f, 1.f}, m24 = m14;
+                if (!a.bcast) d4 = *reinterpret_cast<const bn_f4*>(a.da + i0);
+                if (a.m1) m14 = *reinterpret_cast<const bn_f4*>(a.m1 + i0);
+                if (a.m2) m24 = *reinterpret_cast<const bn_f4*>(a.m2 + i0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float yv = ok[q] ? y4[q] : 0.f;       // (halos of raw train-mode tensors are never written: may hold anything)
+                    float dz = a.bcast ? a.da[(size_t)n * a.c + c0 + ce[q]] : d4[q];
+                    if (!ok[q]) dz = 0.f;
+                    if (a.m1 && !(m14[q] > 0.f)) dz = 0.f;
+                    if (a.m2 && !(m24[q] > 0.f)) dz = 0.f;
+                    if (a.self_scale && !(fmaf(yv, ssc[q], ssh[q]) > 0.f)) dz = 0.f;
+                    q1[q] += dz;
+                    q2[q] = fmaf(dz, (yv - mu[q]) * is[q], q2[q]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s_q[0][q][threadIdx.x] = q1[q]; s_q[1][q][threadIdx.x] = q2[q]; }
+    __syncthreads();
+    if (threadIdx.x < 2 * CT) {
+        const int c = threadIdx.x % CT, which = threadIdx.x / CT;
+        if (c < gw) {
+            // elements of channel c: floats [c Tp, (c + 1) Tp) of the block = threads c Tp / 4 .. ((c + 1) Tp - 1) / 4
+            const int f0 = (c * a.tp) >> 2, f1 = min(((c + 1) * a.tp - 1) >> 2, nt - 1);
+            float v = 0.f;
+            for (int f = f0; f <= f1; ++f)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = 4 * f + q;
+                    if (e >= c * a.tp && e < (c + 1) * a.tp) v += s_q[which][q][f];
+                }
+            a.partial[((size_t)blockIdx.x * 2 + which) * a.c + c0 + c] = v;
+        }
+    }
 }
 
 int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t s) {
-    const int nchunk = chan_reduce_chunks(a.npos);
-    a.pos_per_block = ceil_div(a.npos, nchunk);
+    a.pos_per_block = chan_reduce_ppb(a.npos, a.t);
     const dim3 grid(ceil_div(a.npos, a.pos_per_block), ceil_div(a.c, 8));
     *nchunk_out = (int)grid.x;
+    // 16-byte kernel: whole utterances per workgroup, every 8-channel block of an utterance 16-byte aligned and a multiple of 4 floats
+    const int nt4 = ceil_div(ceil_div(8 * a.tp, 4), 64) * 64;
+    // (its workgroups are short -- (8 Tp / 4) threads walking a few utterances -- so it needs many of them: DS-CNN-L, 276 channels:
+    //  -3 % on the step; TC-ResNet's 16-48 channels leave it ~1500 waves for 256 CUs: +8 % on the TCResNet8 step -> scalar kernel there)
+    const bool vec = a.pos_per_block % a.t == 0 && nt4 <= 512 && ((int64_t)grid.x * grid.y * (nt4 / 64) >= 16 * 256 || tune_get(TCR_TUNE_BWD_MASK) == 4) && (8 * a.tp) % 4 == 0 && (a.c * a.tp) % 4 == 0 &&
+                     ((a.c % 8) * a.tp) % 4 == 0 && bn_vec4_ok(a.y, (mode == 1 && !a.bcast) ? a.da : nullptr, a.m1, a.m2, a.c * a.tp, true);
+    if (vec) {
+        if (mode == 0) hipLaunchKernelGGL((chan_reduce4_kernel<0>), grid, dim3(nt4), 0, s, a);
+        else hipLaunchKernelGGL((chan_reduce4_kernel<1>), grid, dim3(nt4), 0, s, a);
+        return check_launch("chan_reduce4_kernel");
+    }
     if (mode == 0) hipLaunchKernelGGL((chan_reduce_kernel<0>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((chan_reduce_kernel<1>), grid, dim3(256), 0, s, a);
     return check_launch("chan_reduce_kernel");
@@ -245,7 +352,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
 // Four consecutive elements per thread (one 16-byte load / store per tensor): the elementwise BN passes of the big-activation
 // nets (DS-CNN-L: 600 MB tensors) are pure HBM streams.  The four elements may straddle a channel row: channel and frame index
 // are per element (same expressions as the scalar kernel -> bitwise the same results).
-typedef float bn_f4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void bn_apply4_kernel(const BnApplyArgs a) {
     const int per_utt = a.c * a.tp;
@@ -272,11 +378,6 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const BnApplyArgs a) {
         o4[e] = v;
     }
     *reinterpret_cast<bn_f4*>(a.out + i0) = o4;
-}
-
-static bool bn_vec4_ok(const void* p0, const void* p1, const void* p2, const void* p3, int per_utt) {
-    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return per_utt % 4 == 0 && al(p0) && al(p1) && al(p2) && al(p3) && tune_get(TCR_TUNE_BWD_MASK) != 2;
 }
 
 int launch_bn_apply(const BnApplyArgs& a0, hipStream_t s) {

@@ -790,7 +790,7 @@ static int ds_forward_train_stages(const tcr_dscnn* net, const float* params, fl
         const int pp = tcr_padded_len(u.P);
         float* ss = base + w.ss + u.ss_off;
         BnFinalizeArgs f;
-        f.partial = base + w.partial; f.nchunk = sync ? 0 : chan_reduce_launch_chunks(batch * u.P);
+        f.partial = base + w.partial; f.nchunk = sync ? 0 : chan_reduce_launch_chunks(batch * u.P, u.P);
         f.sums = reinterpret_cast<const double*>(base + w.sums);
         f.gamma = nullptr; f.beta = params + u.beta_off;
         f.moving_mean = stats + u.mean_off; f.moving_var = stats + u.var_off;
@@ -969,7 +969,7 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         const float* da = ui == nu - 1 ? base + w.dpool : ga;
         const int bcast = ui == nu - 1 ? 1 : 0;
         BnBwdFinalizeArgs f;
-        f.partial = base + w.partial; f.nchunk = sync ? 0 : chan_reduce_launch_chunks(batch * u.P);
+        f.partial = base + w.partial; f.nchunk = sync ? 0 : chan_reduce_launch_chunks(batch * u.P, u.P);
         f.sums = reinterpret_cast<const double*>(base + w.sums); f.gamma = nullptr; f.invstd = base + w.invstd[ui];
         f.dgamma = nullptr; f.dbeta = grads + u.beta_off;
         f.k1 = kc; f.k2 = kc + cp; f.k3 = kc + 2 * cp;

@@ -314,7 +314,7 @@ struct BnBwdApplyArgs {
 
 int launch_bn_fold(const BnFoldArgs& a, hipStream_t s);
 int chan_reduce_chunks(int npos);
-int chan_reduce_launch_chunks(int npos);
+int chan_reduce_launch_chunks(int npos, int t);      // t: frames per utterance (chunks are whole utterances where one fits)
 int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t s);
 int launch_chan_sums(const float* partial, int nchunk, int c, double* sums, hipStream_t s);
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);

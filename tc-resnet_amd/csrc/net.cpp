@@ -561,7 +561,7 @@ static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* r
     float* ss = c.base + c.w.ss + l.ss_off;
     BnFinalizeArgs f;
     f.partial = partial;
-    f.nchunk = c.sync_bn ? 0 : (rows >= 0 ? rows : chan_reduce_launch_chunks(c.batch * l.tout));
+    f.nchunk = c.sync_bn ? 0 : (rows >= 0 ? rows : chan_reduce_launch_chunks(c.batch * l.tout, l.tout));
     f.sums = reinterpret_cast<const double*>(c.base + c.w.sums);
     f.gamma = c.params + l.gamma_off; f.beta = c.params + l.beta_off;
     f.moving_mean = stats + l.mean_off; f.moving_var = stats + l.var_off;
@@ -887,7 +887,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     if (parts & BWD_BN) {
         BnBwdFinalizeArgs f;
         f.partial = partial;
-        f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout);
+        f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout, l.tout);
         f.sums = reinterpret_cast<const double*>(c.base + c.w.sums); f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[u.li];
         f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
         f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
@@ -1079,7 +1079,7 @@ static float* bwd_partial_of(const TrainCtx& c, int li) {
 static int bwd_rows_of(const TrainCtx& c, int li, const float* dpool) {
     const tcr_net& net = *c.net;
     const int nb = (int)net.blocks.size();
-    if (li == net.blocks[nb - 1].b || li == net.blocks[nb - 1].down) return chan_reduce_launch_chunks(c.batch * net.layers[li].tout);
+    if (li == net.blocks[nb - 1].b || li == net.blocks[nb - 1].down) return chan_reduce_launch_chunks(c.batch * net.layers[li].tout, net.layers[li].tout);
     if (li == 0) return train_bwd_phase_rows(bwd_phase_d2(c, 0, dpool));
     for (int bi = 0; bi < nb; ++bi) {
         if (li == net.blocks[bi].a) return train_bwd_phase_rows(bwd_phase_d1(c, bi, dpool));

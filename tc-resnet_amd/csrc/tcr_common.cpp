@@ -56,7 +56,7 @@ extern "C" const char* tcr_kernel_name(int index) {
     static const char* names[] = {
         "frontend_pk_kernel", "net_fused_kernel", "augment_kernel", "frontend_kernel", "conv_fwd_kernel", "conv_mfma_kernel", "conv1x1_mfma_kernel", "head_fwd_kernel",
         "bn_finalize_kernel", "bn_apply_kernel", "head_bwd_kernel", "bn_bwd_reduce_kernel",
-        "bn_bwd_apply_kernel", "bn_bwd_apply4_kernel", "bn_apply4_kernel", "bn_bwd_apply_fused_kernel", "conv_dgrad_kernel", "conv_wgrad_mfma_kernel", "wgrad_reduce_kernel",
+        "bn_bwd_apply_kernel", "bn_bwd_apply4_kernel", "chan_reduce4_kernel", "bn_apply4_kernel", "bn_bwd_apply_fused_kernel", "conv_dgrad_kernel", "conv_wgrad_mfma_kernel", "wgrad_reduce_kernel",
         "sgd_momentum_kernel", "adam_kernel", "rmsprop_kernel", "ema_kernel", "l2_loss_kernel", "pw_wgrad_lds_kernel", "dscnn_conv1_kernel",
         "dscnn_depthwise_kernel", "dscnn_dw_dgrad_kernel", "dscnn_dw_wgrad_kernel", "dscnn_conv1_wgrad_kernel", "train_phase_kernel", "train_bwd_phase_kernel", "conv2d_mfma_kernel", "conv2d_wgrad_kernel", "pool2d_fwd_kernel",
         "pool2d_bwd_kernel", "eltwise2d_kernel", "head2d_kernel", "chan_sum2d_kernel", "features_to_plane_kernel",

@@ -436,15 +436,23 @@ def check_dscnn_mask_paths_agree(lib, size, batch, seed=5):
     t, f = 49, 10
     feat = T.features_to_planar(torch.from_numpy(rng.uniform(-2, 2, (batch, t, f)).astype(np.float32)).to(dev), lib=lib)
     labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
-    grads = []
+    grads, stats, logits = [], [], []
     try:
-        for mask in (0, 1, 2):              # 2: the scalar (one element per thread) elementwise BN kernels instead of the 4-wide ones
+        for mask in (0, 1, 2, 3, 4):        # 1: masks read back; 2: scalar elementwise BN kernels; 3: also the scalar reduction kernel;
+                                            # 4: default + the 16-byte reduction kernel at any grid size (small batches: the emulator's)
             lib.tcr_tune(12, mask)
             ds = T.DSCNN(size, t, f, 12, lib=lib, device=dev)
             ds.init_xavier(2)
-            ds.forward_train(feat, labels)
+            lg, _, _ = ds.forward_train(feat, labels)
+            logits.append(lg.clone()); stats.append(ds.stats.clone())
             grads.append(ds.backward().clone())
     finally:
         lib.tcr_tune(12, 0)
     assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
     assert torch.equal(grads[0], grads[2]), float((grads[0] - grads[2]).abs().max())
+    # The scalar reduction kernel adds the same terms in another order.  The forward is continuous in the statistics: moving
+    # statistics and logits agree to rounding.  The gradients go through ReLU masks taken from `fmaf(y, scale, shift) > 0`, so a last-bit
+    # change of scale / shift flips inputs within ~1e-7 of zero (DS-CNN-L: millions of ReLU inputs): bounded, not bitwise.
+    assert float((stats[4] - stats[3]).abs().max()) < 2e-6 * max(1.0, float(stats[3].abs().max()))
+    assert float((logits[4] - logits[3]).abs().max()) < 2e-5
+    assert float((grads[4] - grads[3]).abs().max()) < 5e-3 * max(1.0, float(grads[3].abs().max()))
