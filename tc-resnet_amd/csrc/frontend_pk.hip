@@ -288,8 +288,16 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
 #pragma unroll
             for (int st = 0; st < NMEL / 4; ++st) dcta[ct][st] = a.dct_tab[(ct * (NMEL / 4) + st) * 64 + (tid & 63)];
     }
-    const int chunk = blockIdx.x;
-    load_frame(chunk, 0, xa);
+    // Persistent workgroups: a workgroup walks chunks of `fpw` frames (tables, twiddles and DCT fragments are set up once; as one
+    // workgroup per chunk the set-up, DCT and drain cost 4.6 us per workgroup against 4.0 us per round).
+    const int nchunks = (a.total_frames + fpw - 1) / fpw;
+    load_frame(blockIdx.x, 0, xa);
+#pragma unroll 1
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    // lane geometry re-derived per chunk from an opaque zero: the address arithmetic of the unrolled round body must not be hoisted
+    // out of the chunk loop (it would stay live through the DCT section)
+    const int tid = (int)threadIdx.x + opaque_zero();
+    const int f = tid / LPF, lf = tid % LPF, u = lf >> 4, l = tid & 15, unit = tid >> 4;
     // (A frame's lanes never straddle a wavefront: the phases of a round are ordered by wave-local sync points.)
     for (int r = 0; r < rounds; ++r) {
         // ---------------- load (+ prefetch of the next round) + window + first radix-16 pass ----------------
@@ -297,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = q < QV ? xa[q] * wnd[q] : (v2){0.f, 0.f};
         if (r + 1 < rounds) load_frame(chunk, r + 1, xa);
+        else if (chunk + (int)gridDim.x < nchunks) load_frame(chunk + gridDim.x, 0, xa);
         pk_dft16(v);
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) s_x[unit * UNIT + k2 * XLD + l] = c_mul(v[k2], tw[k2]);
@@ -480,6 +489,8 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
             }
         }
     }
+    __syncthreads();            // s_lm is rewritten by the next chunk's rounds
+    }
 }
 
 // returns 1 (nothing launched) when the configuration needs the general kernel: unaligned frames, or a window whose
@@ -491,26 +502,26 @@ int launch_frontend_pk(int nc, const FrontendArgs& a0, hipStream_t s) {
     if (!a_in.aligned || (a_in.win & 1) || (a_in.win / 2) % (16 * sub) != 0) return 1;
     if (a_in.total_frames >= (1 << 23)) return 1;              // (the frame -> utterance split uses a float reciprocal)
     const int qv = a_in.win / (32 * sub);
-    // Frames per workgroup: rounds x (4096 / nc) frames, at most 64.  All workgroups cost the same (rounds + ~0.85 of a
-    // round for setup and the DCT), so the grid drains in dispatch waves of (2 workgroups x CUs); a last wave that leaves
-    // every CU with one workgroup runs ~1.6x faster.  Model fitted on MI355X at B = 1024 .. 16384 (scripts/fe_rounds.py,
-    // within 4 %); the round count that minimises it wins 4 % at B = 4096 and 8 % at B = 1024 over always using 64 frames.
+    // Persistent workgroups (2 per CU) walk chunks of rounds x (4096 / nc) frames, at most 64: tables, twiddles and DCT fragments are
+    // set up once per workgroup.  A chunk costs rounds + ~1.45 rounds (DCT, stores, barriers, the sample-prefetch bubble); the
+    // workgroups take ceil(chunks / slots) of them, a last generation that leaves every CU one workgroup runs ~1.6x faster.  The round
+    // count that minimises that model matched the measured best at B = 1024 (5), 4096 (7), 16384 (8) (scripts/fe_rounds_fit.py).
     FrontendArgs a = a0;
     {
         const int fpr = 4096 / nc, max_rounds = 64 / fpr, slots = 2 * device_cus();
         int best = max_rounds;
         float best_cost = 3.4e38f;
         for (int r = max_rounds; r >= (max_rounds + 1) / 2; --r) {
-            const int wgs = ceil_div(a.total_frames, r * fpr);
-            const int full = wgs / slots, rest = wgs % slots;
-            const float waves = (float)full + (rest == 0 ? 0.f : (2 * rest <= slots ? 0.6f : 1.f));
-            const float cost = waves * ((float)r + 0.85f);
+            const int chunks = ceil_div(a.total_frames, r * fpr);
+            const int full = chunks / slots, rest = chunks % slots;
+            const float gens = (float)full + (rest == 0 ? 0.f : (2 * rest <= slots ? 0.6f : 1.f));
+            const float cost = gens * ((float)r + 1.45f);
             if (cost < best_cost * 0.995f) { best_cost = cost; best = r; }
         }
         const int knob = tune_get(TCR_TUNE_FRONTEND);
         if (knob >= 10) best = min(max(knob - 10, 1), max_rounds);
         a.rounds = best;
-        grid = ceil_div(a.total_frames, best * fpr);
+        grid = min(ceil_div(a.total_frames, best * fpr), slots);
     }
 #define TCR_FPK(NC_, QV_)                                                                                           \
     if (nc == NC_ && qv == QV_) {                                                                                   \
