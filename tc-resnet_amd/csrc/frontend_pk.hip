@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
             }
         }
         wave_sync();
-        if (r == 0) __syncthreads();                        // the slope table / zeroed row pads staged in the prologue
+        if (r == 0) __syncthreads();                        // the slope table / zeroed row pads staged in the prologue; s_lm free again
         // ---------------- sparse mel: one item (<= 8 bins of one segment) per lane and trip, one packed FMA per bin ----------------
         v2* UD = s_x + (f * SUB) * UNIT;                    // (this frame's first unit: dead until the next round's first pass)
         {
@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
             }
         }
     }
-    __syncthreads();            // s_lm is rewritten by the next chunk's rounds
+    // (no barrier here: the next chunk's first write to s_lm sits behind round 0's barrier below, which every wave reaches only
+    //  after its DCT of this chunk)
     }
 }
 
