@@ -70,8 +70,8 @@ def timed(fn, steps: int, warmup: int, dist_on: bool):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)      # (0.34 ms each: the first ~50 launches run ~15 % slower while the clocks ramp)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU per step (BASELINE config: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the train / 3010 legs (profiling runs)")
