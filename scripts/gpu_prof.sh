@@ -10,7 +10,7 @@ rocprofv3 -L > $OUT/counters_list.txt 2>&1
 echo "== kernel trace"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1; echo rc=$?
 echo "== kernel trace, forward only (the roofline's kernel_ms is recomputable from this one)"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fwd -o t -- $CMD --no-extras --steps 30 --warmup 5 > $OUT/trace_fwd.log 2>&1; echo rc=$?
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fwd -o t -- $CMD --no-extras --steps 200 --warmup 50 > $OUT/trace_fwd.log 2>&1; echo rc=$?
 find $OUT/trace $OUT/trace_fwd -name "*kernel_trace.csv" -size +30M -delete
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" \
