@@ -32,7 +32,7 @@ constexpr int kMelItemsMax = 192;
 // bins per item: segments are 2 .. 20 bins long at nfft 1024, 1 .. 10 at nfft 512
 constexpr int mel_item_bins(int nc) { return nc == 512 ? 8 : 4; }
 // items the packed kernel handles with its unrolled trips (trips x lanes per frame); a filterbank with more items runs the rest in a slow loop
-constexpr int mel_trips(int nc) { return nc == 512 ? 3 : 5; }
+constexpr int mel_trips(int nc) { return nc == 512 ? 3 : 6; }      // (the reference filterbank: 91 items of 8 bins at nfft 1024, 89 of 4 at nfft 512)
 constexpr int mel_items_fast(int nc) { return mel_trips(nc) * (nc / 16); }
 
 inline FrontendPlanLayout frontend_plan_layout(const tcr_frontend_cfg& c) {
