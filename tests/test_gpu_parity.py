@@ -32,6 +32,25 @@ def test_frontend_deploy_path(hip_lib, tag):
         hip_lib.tcr_tune(1, 0)
 
 
+@pytest.mark.parametrize("win,hop", [(640, 320), (480, 160)])
+def test_frontend_persistent_chunks_are_position_independent(hip_lib, win, hop):
+    """The packed kernel's persistent workgroups walk chunks of 32-64 frames; an utterance's features must not depend on which
+    chunk / workgroup / round its frames land in: rows of a ragged large batch (more chunks than workgroups, last chunk partial) are
+    BITWISE the rows of small batches of the same waveforms, and the general scalar kernel agrees within the tolerance."""
+    b = 4099
+    wav = torch.from_numpy(R.synth_waveforms(64, seed=11)).to("cuda").repeat(65, 1)[:b].contiguous()
+    fe = Cm.make_frontend(hip_lib, win, hop)
+    big = fe(wav)
+    for lo, n in ((0, 7), (2048, 3), (b - 5, 5)):
+        assert torch.equal(big[lo:lo + n], fe(wav[lo:lo + n].contiguous())), (lo, n)
+    try:
+        hip_lib.tcr_tune(1, 4)
+        ref = fe(wav[:64].contiguous())
+    finally:
+        hip_lib.tcr_tune(1, 0)
+    assert float((big[:64] - ref).abs().max()) < Cm.MFCC_TOL
+
+
 def test_frontend_variants(hip_lib):
     fx = Cm.load("frontend_4020.npz")
     wav = Cm.to_dev(hip_lib, fx["wav"])
