@@ -355,7 +355,9 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_PHASE_CFG = 10,  /* training phases: waves per workgroup * 100 + utterances per group (0: default) */
        TCR_TUNE_BWD_BN_FUSED = 11, /* BN backward: 0 finalize folded into the apply pass for layers of <= 48 channels (one launch; default), 1 finalize + apply kernels, >= 2: folded everywhere, that many workgroups aimed at */
        TCR_TUNE_BWD_MASK = 12,   /* BN backward: 0 a unit's own ReLU mask recomputed from its raw conv output ([fmaf(y, scale, shift) > 0], bitwise the activation's; default), 1 read back from the stored activation, 2: as 0 with the scalar (one element per thread) elementwise BN kernels instead of the 16-byte ones (bitwise the same), 3: also the scalar per-channel reduction kernel (another summation order), 4: the 16-byte reduction kernel also where its grid would be small (tests) */
-       TCR_TUNE_COUNT = 13 };
+       TCR_TUNE_FE_GRID = 13,    /* front-end: cap on the number of persistent workgroups (0: two per CU). 256 = one per CU, which leaves half of every CU's LDS and registers to a co-resident network kernel on another stream */
+       TCR_TUNE_FUSED_GRID = 14, /* fused eval network: cap on the number of persistent workgroups (0: as many as the LDS allows per CU) */
+       TCR_TUNE_COUNT = 15 };
 int tcr_tune(int knob, int value);
 
 #ifdef __cplusplus

@@ -1,0 +1,29 @@
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import tcresnet_amd as T
+from bench import synth_batch
+dev = torch.device("cuda"); lib = T._lib.get(); B = 4096
+wav = synth_batch(B, dev, 1234)
+def wall(fn, n=200, warm=50):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+fe = T.Frontend(window_size_samples=640, window_stride_samples=320, device=dev)
+net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, fe.n_frames, 12, device=dev); net.init_xavier(0)
+feat = fe(wav); out = (torch.empty((B, 12), device=dev), torch.empty((B, 12), device=dev))
+for b in (8, 64, 512, 2048, 4096):
+    f = feat[:b].contiguous()
+    print(f"batch {b}: net {wall(lambda: net.forward_infer(f)):7.1f} us")
+for st in (0, 64, 128, 256, 512, 1024, 2048, 0):
+    lib.tcr_tune(14, -st)
+    print(f"stagger {st*64} cycles: net {wall(lambda: net.forward_infer(feat, out=out)):7.1f} us", flush=True)
+lib.tcr_tune(14, 0)
+for g in (2, 4, 6, 8):
+    for wv in (4, 8, 16):
+        lib.tcr_tune(4, g); lib.tcr_tune(5, wv)
+        try: print(f"group {g} waves {wv}: net {wall(lambda: net.forward_infer(feat, out=out)):7.1f} us", flush=True)
+        except Exception as e: print(g, wv, "failed", str(e)[:80])

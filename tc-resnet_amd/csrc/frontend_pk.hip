@@ -533,6 +533,8 @@ int launch_frontend_pk(int nc, const FrontendArgs& a0, hipStream_t s) {
         if (knob >= 10) best = min(max(knob - 10, 1), max_rounds);
         a.rounds = best;
         grid = min(ceil_div(a.total_frames, best * fpr), slots);
+        const int cap = tune_get(TCR_TUNE_FE_GRID);
+        if (cap > 0) grid = min(grid, cap);
     }
 #define TCR_FPK(NC_, QV_)                                                                                           \
     if (nc == NC_ && qv == QV_) {                                                                                   \

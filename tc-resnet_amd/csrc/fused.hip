@@ -16,6 +16,20 @@ namespace tcr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Timing what-ifs of the static-shape kernel (scripts/build_whatif.py compiles this file with -DTCR_FUSED_WHATIF=<mask> into
+// side libraries; WRONG results, never part of the product build): 1 no MFMAs, 2 weights of tap 0 only, 4 LDS operands of tap 0
+// only, 8 no barriers, 16 no head, 32 no epilogue stores, 64 no first conv.
+#ifndef TCR_FUSED_WHATIF
+#define TCR_FUSED_WHATIF 0
+#endif
+#define TCR_WHATIF(bit) ((TCR_FUSED_WHATIF & (bit)) != 0)
+#if TCR_FUSED_WHATIF & 1
+__device__ __forceinline__ f32x4 whatif_nomfma(float a, float b, f32x4 c) { c[0] += a; c[1] += b; return c; }
+#define TCR_MFMA(A, B, C) whatif_nomfma((A), (B), (C))
+#else
+#define TCR_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+#endif
+
 // NW: wavefronts per workgroup (jobs of a layer are dealt round-robin to them).  R: depth of the weight register ring.
 // One layer of the walk for the group's `ng` utterances.  xin: input rows (LDS buffer, or -- first layer -- the feature
 // rows in global memory, which then never occupy LDS), in_sz floats per utterance.
@@ -213,6 +227,272 @@ __device__ __forceinline__ void fused_layer_t(const FusedArgs& a, const FusedLay
     }
 }
 
+// Round 3: the static-shape layer with a branch-free epilogue.  The round-2 epilogue above spends ~60 instructions and six exec-mask
+// branches per output element (bounds tests, the residual read behind a branch, the halo zeros written by whichever lane owns a row's
+// first / last frame).  Here lanes past the group's last position / past Cout store into the pad behind the buffers, the residual
+// reads are issued together with clamped addresses, and the halo zeros of the output rows are written by `fused_zero_halo` (one pass
+// per layer): 17.5 M instead of 21.3 M VALU and 4.9 M instead of 11 M SALU instructions per launch, bitwise the same results.
+// (Tried with it and dropped: the taps fully unrolled into a software pipeline -- weight fragments two / three stages ahead in a
+// register ring, LDS operands one stage ahead, a scheduling barrier per stage: 131 / 133 us vs 125 us, SQ_WAIT_INST_ANY UP 11 %.)
+template <int NW, int K, int S, int CIN, int COUT, int TIN, bool HAS_RES>
+__device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
+                                              float* lds, const int ng, const int wave, const int r_in, const int q_in) {
+    // lane geometry re-derived from an opaque zero: the per-lane address arithmetic of ten layers must not be hoisted out of the group
+    // loop, where it would stay live through every other layer (the kernel runs at a 128-register budget)
+    const int oz = opaque_zero();
+    const int r = r_in + oz, q = q_in + oz;
+    constexpr int TOUT = (TIN + S - 1) / S;
+    constexpr int PADT = ((TOUT - 1) * S + K - TIN) > 0 ? ((TOUT - 1) * S + K - TIN) : 0;
+    constexpr int PADLO = PADT / 2;
+    constexpr int TPI = TIN + 2 * kHalo, TPO = TOUT + 2 * kHalo;
+    constexpr int C4 = CIN / 4, NRT = (COUT + 15) / 16;
+    constexpr int WSTEP = 4 * COUT, XSTEP = 4 * TPI;
+    static_assert(CIN % 4 == 0, "channel quads");
+    float* yout = lds + a.buf_off[L.out_buf];
+    const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
+    const int out_sz = a.buf_sz[L.out_buf];
+    const int res_sz = L.res_buf >= 0 ? a.buf_sz[L.res_buf] : 0;
+    const int npos = ng * TOUT;
+    const int ncp = (npos + 31) / 32;
+    const float* w = a.params + L.w_off;
+    const float* scale = a.ss + L.ss_off;
+    const float* shift = scale + L.c_pad;
+    for (int job = wave; job < ncp * NRT; job += NW) {
+        const int cp = job / NRT, m = job - cp * NRT;
+        const int p0 = min(cp * 32 + r, npos - 1), p1 = min(cp * 32 + 16 + r, npos - 1);
+        const int g0 = p0 / TOUT, g1 = p1 / TOUT;
+        const int t0 = p0 - g0 * TOUT, t1 = p1 - g1 * TOUT;
+        const float* wp = w + q * COUT + min(m * 16 + r, COUT - 1);
+        const float* x0 = xin + g0 * in_sz + q * TPI + t0 * S + kHalo - PADLO;
+        const float* x1 = xin + g1 * in_sz + q * TPI + t1 * S + kHalo - PADLO;
+        float sc[4], sh[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int co = min(m * 16 + q * 4 + reg, COUT - 1);
+            sc[reg] = scale[co];
+            sh[reg] = shift[co];
+        }
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // rolled taps, two half-tap weight sets refilled for the next tap (the round-2 loop)
+        constexpr int H0 = C4 / 2, H1 = C4 - H0;
+        float wa[H0 > 0 ? H0 : 1], wb[H1];
+#pragma unroll
+        for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[c4 * WSTEP];
+#pragma unroll
+        for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(H0 + c4) * WSTEP];
+#pragma unroll 1
+        for (int j = 0; j < K; ++j) {
+            const int jn = TCR_WHATIF(2) ? 0 : min(j + 1, K - 1);
+            const int jx = TCR_WHATIF(4) ? 0 : j;
+            {
+                float b0[H0 > 0 ? H0 : 1], b1[H0 > 0 ? H0 : 1];
+#pragma unroll
+                for (int c4 = 0; c4 < H0; ++c4) { b0[c4] = x0[c4 * XSTEP + jx]; b1[c4] = x1[c4 * XSTEP + jx]; }
+#pragma unroll
+                for (int c4 = 0; c4 < H0; ++c4) {
+                    acc0 = TCR_MFMA(wa[c4], b0[c4], acc0);
+                    acc1 = TCR_MFMA(wa[c4], b1[c4], acc1);
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[(jn * C4 + c4) * WSTEP];
+            }
+            {
+                float b0[H1], b1[H1];
+#pragma unroll
+                for (int c4 = 0; c4 < H1; ++c4) { b0[c4] = x0[(H0 + c4) * XSTEP + jx]; b1[c4] = x1[(H0 + c4) * XSTEP + jx]; }
+#pragma unroll
+                for (int c4 = 0; c4 < H1; ++c4) {
+                    acc0 = TCR_MFMA(wb[c4], b0[c4], acc0);
+                    acc1 = TCR_MFMA(wb[c4], b1[c4], acc1);
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(jn * C4 + H0 + c4) * WSTEP];
+            }
+        }
+        // ---- epilogue: folded BN (+ shortcut) (+ ReLU) -> LDS rows ----
+        const int dump = a.buf_off[2] + a.group * a.buf_sz[2] + (q * 16 + r);
+        const float lo = L.relu ? 0.f : -3.4e38f;
+        float rv[2][4];
+        if (HAS_RES) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int co = min(m * 16 + q * 4 + reg, COUT - 1);
+                    rv[nt][reg] = res[(nt == 0 ? g0 : g1) * res_sz + co * TPO + kHalo + (nt == 0 ? t0 : t1)];
+                }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const bool pv = cp * 32 + nt * 16 + r < npos;
+            const int g = nt == 0 ? g0 : g1, t = nt == 0 ? t0 : t1;
+            const f32x4 ac = nt == 0 ? acc0 : acc1;
+            const int base = g * out_sz + kHalo + t;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = m * 16 + q * 4 + reg;
+                float v = fmaf(ac[reg], sc[reg], sh[reg]);
+                if (HAS_RES) v = fmaxf(v + rv[nt][reg], 0.f);       // tc_resnet.py:40-41
+                else v = fmaxf(v, lo);
+                const bool ok = pv && (COUT % 16 == 0 || co < COUT) && !(TCR_WHATIF(32) && v != 12345.f);
+                yout[ok ? base + co * TPO : dump - a.buf_off[L.out_buf]] = v;
+            }
+        }
+    }
+}
+
+// First conv of the static-shape kernel (3 x 1, 40 -> 16, stride 1), activations straight from global memory.  In the generic form
+// every K-step's two operand loads were issued ONE MFMA ahead of their use (ISA: `s_waitcnt vmcnt(1)` in front of each MFMA): 30
+// exposed L1 / L2 / HBM latencies per job -- the layer took 25 us of the kernel's 125 (timing what-if, scripts/whatif_net.py) for
+// 10 % of its MFMAs.  Here a job requests ALL its operands up front (per lane 10 channel quads x 3 taps = three consecutive
+// floats each, and the 30 weight fragments; a job is 16 positions so that this fits the register budget), then runs its 30 MFMAs:
+// one exposed latency per job.  Same accumulation order.
+template <int NW, int T0>
+__device__ __forceinline__ void fused_conv0_s(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
+                                              float* lds, const int ng, const int wave, const int r_in, const int q_in) {
+    const int oz = opaque_zero();
+    const int r = r_in + oz, q = q_in + oz;
+    constexpr int K = 3, CIN = 40, COUT = 16, C4 = CIN / 4;
+    constexpr int TPI = T0 + 2 * kHalo, TPO = TPI, TOUT = T0, PADLO = 1;
+    constexpr int WSTEP = 4 * COUT, XSTEP = 4 * TPI;
+    float* yout = lds + a.buf_off[L.out_buf];
+    const int out_sz = a.buf_sz[L.out_buf];
+    const int npos = ng * TOUT;
+    const int nct = (npos + 15) / 16;
+    const float* w = a.params + L.w_off;
+    const float* scale = a.ss + L.ss_off;
+    const float* shift = scale + L.c_pad;
+    for (int job = wave; job < nct; job += NW) {            // job = 16 positions x 16 channels (30 + 30 operand registers)
+        const int p0 = min(job * 16 + r, npos - 1);
+        const int g0 = p0 / TOUT;
+        const int t0 = p0 - g0 * TOUT;
+        const float* wp = w + q * COUT + r;
+        const float* x0 = xin + g0 * in_sz + q * TPI + t0 + kHalo - PADLO;
+        float b0[C4][K], wf[K][C4];
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4)
+#pragma unroll
+            for (int j = 0; j < K; ++j) b0[c4][j] = x0[c4 * XSTEP + j];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) wf[j][c4] = wp[(j * C4 + c4) * WSTEP];
+        float sc[4], sh[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            sc[reg] = scale[q * 4 + reg];
+            sh[reg] = shift[q * 4 + reg];
+        }
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) acc0 = TCR_MFMA(wf[j][c4], b0[c4][j], acc0);
+        const int dump = a.buf_off[2] + a.group * a.buf_sz[2] + (q * 16 + r) - a.buf_off[L.out_buf];
+        const float lo = L.relu ? 0.f : -3.4e38f;
+        const bool pv = job * 16 + r < npos;
+        const int base = g0 * out_sz + kHalo + t0;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float v = fmaxf(fmaf(acc0[reg], sc[reg], sh[reg]), lo);
+            yout[pv ? base + (q * 4 + reg) * TPO : dump] = v;
+        }
+    }
+}
+
+// Head of the static-shape kernel: avg-pool by all threads, then ONE wave runs fc / fc2 on the matrix cores (D[output][utterance], the
+// arrangement of head.hip: bitwise the fmaf chain of `fused_head`), the softmax in registers with the class sum carried through the
+// three 16-lane rows in class order (bitwise the sequential sum of `fused_head`), and the stores.  `fused_head` -- runtime shapes,
+// 48 dependent global weight loads per dot product in batches of 8, twelve expf per thread -- cost 20 us of the kernel's 125.
+template <int NT, int FC, int FT, int NCLS>
+__device__ __forceinline__ void fused_head_s(const FusedArgs& a, float* lds, const int n0, const int ng, const int tid) {
+    static_assert(FC % 4 == 0 && NCLS + 2 <= 16, "one 16-row MFMA tile holds the logits and the two range outputs");
+    constexpr int TP = FT + 2 * kHalo;
+    const float* fb = lds + a.buf_off[a.feat_buf];
+    const int fsz = a.buf_sz[a.feat_buf];
+    float* pooled = lds + a.buf_off[(a.feat_buf + 1) % 3];
+    const int lane = tid & 63, r = lane & 15, q = lane >> 4;
+    // wave 0: the weight fragments are requested before the pooling phase (their latency hides behind it)
+    float af[FC / 4];
+    if (tid < 64) {
+        const int zero = opaque_zero();        // (keeps these loads inside the group loop: hoisted, they would live through every layer)
+#pragma unroll
+        for (int s = 0; s < FC / 4; ++s) {
+            const int c = 4 * s + q;
+            const float* src = r < NCLS ? a.params + a.fc_off + c * NCLS + r : a.params + a.fc2_off + c * 2 + min(r - NCLS, 1);
+            const float v = src[zero];
+            af[s] = r < NCLS + 2 ? v : 0.f;
+        }
+    }
+    for (int i = tid; i < ng * FC; i += NT) {
+        const int g = i / FC, c = i - g * FC;
+        const float* row = fb + g * fsz + c * TP + kHalo;
+        float v[FT];
+#pragma unroll
+        for (int t = 0; t < FT; ++t) v[t] = row[t];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < FT; ++t) s += v[t];
+        pooled[i] = s / (float)FT;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int g = min(r, ng - 1);
+        float bf[FC / 4];
+#pragma unroll
+        for (int s = 0; s < FC / 4; ++s) bf[s] = pooled[g * FC + 4 * s + q];
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < FC / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], acc, 0, 0, 0);
+        // this lane: utterance r, outputs o = 4 q + reg (classes 0 .. NCLS-1, then the two range outputs)
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) if (4 * q + reg < NCLS) mx = fmaxf(mx, acc[reg]);       // (NCLS % 4 == 0 or not: per-lane test)
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float e[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) e[reg] = expf(acc[reg] - mx);
+        // se = ((e_0 + e_1) + e_2) + ... in class order: row q adds its classes to the sum of rows < q
+        float se = 0.f;
+#pragma unroll
+        for (int row = 0; row < (NCLS + 3) / 4; ++row) {
+            const float prev = __shfl(se, (row > 0 ? (row - 1) * 16 : 0) + r);
+            float cur = row > 0 ? prev : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) if (4 * row + reg < NCLS) cur += e[reg];
+            if (q == row) se = cur;
+        }
+        se = __shfl(se, ((NCLS + 3) / 4 - 1) * 16 + r);
+        if (r < ng) {
+            const size_t n = (size_t)(n0 + r);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int o = 4 * q + reg;
+                if (o < NCLS) {
+                    a.logits[n * NCLS + o] = acc[reg];
+                    a.probs[n * NCLS + o] = e[reg] / se;
+                } else if (o < NCLS + 2 && a.ranges) {
+                    a.ranges[n * 2 + (o - NCLS)] = 1.0f / (1.0f + expf(-acc[reg]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Zero halos (4 + 4 floats) of the rows a static-shape layer is about to write: [ng][COUT] rows of TOUT + 8 floats.
+template <int NT, int COUT, int TOUT>
+__device__ __forceinline__ void fused_zero_halo(float* yout, const int out_sz, const int ng, const int tid_in) {
+    constexpr int TPO = TOUT + 2 * kHalo;
+    const int tid = tid_in + opaque_zero();
+    for (int i = tid; i < ng * COUT * 8; i += NT) {
+        const int row = i >> 3, k = i & 7;
+        const int g = row / COUT, co = row - g * COUT;
+        yout[g * out_sz + co * TPO + (k < 4 ? k : TOUT + k)] = 0.f;
+    }
+}
+
 // ---- head: global average pool -> fc / fc2 -> softmax / sigmoid (tc_resnet.py:43-52), shared by the fused kernels ----
 template <int NT>
 __device__ __forceinline__ void fused_head(const FusedArgs& a, float* lds, const int n0, const int ng, const int tid) {
@@ -274,7 +554,17 @@ __device__ __forceinline__ void fused_head(const FusedArgs& a, float* lds, const
 #else
 #define TCR_WAVES_PER_SIMD_4 __attribute__((amdgpu_waves_per_eu(4, 4)))     // two 8-wave workgroups per CU: <= 128 VGPRs
 #endif
-template <int NW, int T0>
+template <int NW, int K, int S, int CIN, int COUT, int TIN, int WD, bool HAS_RES>     // WD < 0: the round-2 layer (A/B arm, TCR_TUNE_NET_FUSED = 4)
+__device__ __forceinline__ void fused_layer_sel(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
+                                                float* lds, const int ng, const int wave, const int r, const int q) {
+    if constexpr (WD < 0) fused_layer_t<NW, K, S, CIN, COUT, TIN>(a, L, xin, in_sz, lds, ng, wave, r, q);
+    else {
+        fused_zero_halo<NW * 64, COUT, (TIN + S - 1) / S>(lds + a.buf_off[L.out_buf], a.buf_sz[L.out_buf], ng, (int)threadIdx.x);
+        fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES>(a, L, xin, in_sz, lds, ng, wave, r, q);
+    }
+}
+
+template <int NW, int T0, int WD>
 __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_kernel(const FusedArgs a) {
     constexpr int NT = NW * 64;
     constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2;
@@ -284,30 +574,48 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int row = a.in_c * a.in_tp;
-#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_t<NW, K_, S_, CI_, CO_, T_>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.buf_sz[a.layer[LI].in_buf], lds, ng, wave, r, q)
+#if !defined(TCR_HOST_EMULATION)
+    if (a.stagger > 0 && (int)blockIdx.x >= (int)gridDim.x / 2)
+        for (int i = 0; i < a.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+#endif
+#if TCR_FUSED_WHATIF & 8
+#define TCR_TC8_BARRIER ((void)0)
+#else
+#define TCR_TC8_BARRIER __syncthreads()
+#endif
+#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.buf_sz[a.layer[LI].in_buf], lds, ng, wave, r, q)
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
-        fused_layer_t<NW, 3, 1, 40, 16, T0>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
-        __syncthreads();
+        if constexpr (WD < 0) fused_layer_sel<NW, 3, 1, 40, 16, T0, WD, false>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
+        else if (!TCR_WHATIF(64)) {
+            fused_zero_halo<NT, 16, T0>(lds + a.buf_off[a.layer[0].out_buf], a.buf_sz[a.layer[0].out_buf], ng, tid);
+            fused_conv0_s<NW, T0>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
+        }
+        TCR_TC8_BARRIER;
         TCR_TC8(1, 1, 2, 16, 24, T0);           // block0/down (reads the same rows as conv0_0: no barrier in between)
         TCR_TC8(2, 9, 2, 16, 24, T0);
-        __syncthreads();
+        TCR_TC8_BARRIER;
         TCR_TC8(3, 9, 1, 24, 24, T1);
-        __syncthreads();
+        TCR_TC8_BARRIER;
         TCR_TC8(4, 1, 2, 24, 32, T1);
         TCR_TC8(5, 9, 2, 24, 32, T1);
-        __syncthreads();
+        TCR_TC8_BARRIER;
         TCR_TC8(6, 9, 1, 32, 32, T2);
-        __syncthreads();
+        TCR_TC8_BARRIER;
         TCR_TC8(7, 1, 2, 32, 48, T2);
         TCR_TC8(8, 9, 2, 32, 48, T2);
-        __syncthreads();
+        TCR_TC8_BARRIER;
         TCR_TC8(9, 9, 1, 48, 48, (T2 + 1) / 2);
-        __syncthreads();
-        fused_head<NT>(a, lds, n0, ng, tid);
+        TCR_TC8_BARRIER;
+        if constexpr (WD < 0) fused_head<NT>(a, lds, n0, ng, tid);
+        else if (!TCR_WHATIF(16)) {
+            if (a.nc == 12) fused_head_s<NT, 48, (T2 + 1) / 2, 12>(a, lds, n0, ng, tid);
+            else fused_head<NT>(a, lds, n0, ng, tid);
+        }
     }
 #undef TCR_TC8
+#undef TCR_TC8_BARRIER
 }
 
 // 49 / 98 when the plan is exactly TCResNet8-1.0 on 40 coefficients read from global memory, else 0
@@ -362,7 +670,9 @@ __global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
 int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, int ring, hipStream_t s) {
     void (*kern)(const FusedArgs) = nullptr;
     const int tc8 = tune_get(TCR_TUNE_NET_FUSED) == 3 ? 0 : fused_tc8_frames(a);
-#define TCR_FS(NW_, T_) if (tc8 == T_ && waves == NW_) kern = net_fused_tc8_kernel<NW_, T_>;
+    // TCR_TUNE_NET_FUSED: 0 branch-free epilogue (default); 4: the round-2 static-shape kernel (A/B arm)
+    const bool r2 = tune_get(TCR_TUNE_NET_FUSED) == 4;
+#define TCR_FS(NW_, T_) if (tc8 == T_ && waves == NW_) kern = r2 ? net_fused_tc8_kernel<NW_, T_, -1> : net_fused_tc8_kernel<NW_, T_, 0>;
     TCR_FS(4, 49) TCR_FS(8, 49) TCR_FS(16, 49) TCR_FS(4, 98) TCR_FS(8, 98) TCR_FS(16, 98)
 #undef TCR_FS
     if (kern) ring = 0;

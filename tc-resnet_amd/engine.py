@@ -36,6 +36,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 class _Base:
+    _kver = 0            # bumped by every method that lets a kernel write the variables / moving statistics (TCResNet caches its BN fold on it)
+
     def _stream(self):
         if self.device.type == "cuda":
             return torch.cuda.current_stream(self.device).cuda_stream
@@ -165,6 +167,7 @@ class TCResNet(_Base):
         self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
         self.slots: Dict[str, torch.Tensor] = {}      # optimiser slots (arena-shaped)
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._kver, self._fold_key, self._fold_ss, self._fold_event, self._fold_stream, self._fold_readers = 0, None, None, None, None, {}
         self.reset_bn()
 
     def __del__(self):
@@ -246,6 +249,39 @@ class TCResNet(_Base):
             raise TcrError(f"features must be planar [B, {want[0]}, {want[1]}], got {tuple(feat.shape)}")
 
     # ---- compute ------------------------------------------------------------------------------
+    def _weights_version(self):
+        """Changes whenever the variables or the moving statistics may have changed: torch-side writes bump the tensors' version
+        counters, kernel-side writes (train-mode forward, optimiser steps) bump `_kver` in the methods that launch them."""
+        return (self.params._version, self.stats._version, self._kver, self.params.data_ptr(), self.stats.data_ptr())
+
+    def invalidate_folded(self):
+        """Call after writing `params` / `stats` through a path torch does not see (a raw pointer handed to another library)."""
+        self._kver += 1
+
+    def _folded_table(self) -> torch.Tensor:
+        """Eval-mode BN folded to (scale, shift) ONCE per weight version (the fold used to be a launch in front of every eval
+        forward although eval weights never change between steps); refolded after load_state_dict / an optimiser step / a
+        train-mode forward.  Other streams order themselves behind the fold with an event."""
+        key = self._weights_version()
+        cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        if self._fold_key != key or self._fold_ss is None:
+            if self._fold_ss is None:
+                self._fold_ss = torch.zeros(self.lib.tcr_net_frozen_floats(self._h), dtype=torch.float32, device=self.device)
+            elif cur is not None and self._fold_readers:
+                for ev in self._fold_readers.values():      # forwards still reading the old table on other streams
+                    cur.wait_event(ev)
+            self.lib.check(self.lib.tcr_net_fold_bn(self._h, self.params.data_ptr(), self.stats.data_ptr(), self._fold_ss.data_ptr(),
+                                                    self._stream()), "tcr_net_fold_bn")
+            self._fold_key = key
+            self._fold_readers = {}
+            if cur is not None:
+                self._fold_event = torch.cuda.Event()
+                self._fold_event.record(cur)
+                self._fold_stream = cur.cuda_stream
+        elif cur is not None and cur.cuda_stream != self._fold_stream:
+            cur.wait_event(self._fold_event)
+        return self._fold_ss
+
     def forward_infer(self, feat: torch.Tensor, want_ranges: bool = False, out=None):
         """Eval-mode forward.  `out=(logits, probs)` reuses caller-owned output tensors (stream pipelines)."""
         self._check_feat(feat)
@@ -257,9 +293,17 @@ class TCResNet(_Base):
             logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
             probs = torch.empty_like(logits)
         ranges = torch.empty((b, 2), dtype=torch.float32, device=self.device) if want_ranges else None
-        self.lib.check(self.lib.tcr_net_forward_infer(self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(), b,
-                                                      ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(),
-                                                      _ptr(ranges), self._stream()), "tcr_net_forward_infer")
+        ss = self._folded_table()
+        self.lib.check(self.lib.tcr_net_forward_frozen(self._h, self.params.data_ptr(), ss.data_ptr(), feat.data_ptr(), b,
+                                                       ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(),
+                                                       _ptr(ranges), self._stream()), "tcr_net_forward_frozen")
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream(self.device)
+            if cur.cuda_stream != self._fold_stream:            # a refold must wait for this reader
+                ev = self._fold_readers.get(cur.cuda_stream)
+                if ev is None:
+                    ev = self._fold_readers[cur.cuda_stream] = torch.cuda.Event()
+                ev.record(cur)
         return (logits, probs, ranges) if want_ranges else (logits, probs)
 
     def fold_bn(self) -> torch.Tensor:
@@ -308,6 +352,7 @@ class TCResNet(_Base):
                 self.lib.check(self.lib.tcr_net_forward_train_stage(*common, st, self._stream()), "tcr_net_forward_train_stage")
                 if st < ns - 1:
                     sync_hook(self._stage_sums(0, st, ws, b))
+        self._kver += 1          # the moving statistics changed
         self._last = (feat, b, gb, sync_hook)
         return logits, probs, loss[0]
 
@@ -360,6 +405,7 @@ class TCResNet(_Base):
         self.lib.check(self.lib.tcr_sgd_momentum_step(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), self.n_param,
                                                       self.n_decay, float(lr), float(momentum), float(weight_decay),
                                                       float(grad_scale), self._stream()), "tcr_sgd_momentum_step")
+        self._kver += 1
 
     def adam_step(self, lr: float, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                   weight_decay: float = 0.0, grad_scale: float = 1.0):
@@ -367,6 +413,7 @@ class TCResNet(_Base):
         self.lib.check(self.lib.tcr_adam_step(self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), v.data_ptr(),
                                               self.n_param, self.n_decay, float(lr), float(beta1), float(beta2), float(eps),
                                               int(step), float(weight_decay), float(grad_scale), self._stream()), "tcr_adam_step")
+        self._kver += 1
 
     def rmsprop_step(self, lr: float, decay: float = 0.9, momentum: float = 0.0, eps: float = 1e-10, weight_decay: float = 0.0,
                      grad_scale: float = 1.0):
@@ -375,6 +422,7 @@ class TCResNet(_Base):
         self.lib.check(self.lib.tcr_rmsprop_step(self.params.data_ptr(), self.grads.data_ptr(), ms.data_ptr(), mom.data_ptr(),
                                                  self.n_param, self.n_decay, float(lr), float(decay), float(momentum), float(eps),
                                                  float(weight_decay), float(grad_scale), self._stream()), "tcr_rmsprop_step")
+        self._kver += 1
 
     def ema_step(self, decay: float):
         """tf.train.ExponentialMovingAverage(decay).apply(trainables): the shadow arena starts as a copy of the variables'
