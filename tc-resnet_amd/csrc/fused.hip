@@ -18,7 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Timing what-ifs of the static-shape kernel (scripts/build_whatif.py compiles this file with -DTCR_FUSED_WHATIF=<mask> into
 // side libraries; WRONG results, never part of the product build): 1 no MFMAs, 2 weights of tap 0 only, 4 LDS operands of tap 0
-// only, 8 no barriers, 16 no head, 32 no epilogue stores, 64 no first conv.
+// only, 8 no barriers, 16 no head, 32 no epilogue stores, 64 no first conv, 512 empty kernel, 1024 no halo-zero passes.
 #ifndef TCR_FUSED_WHATIF
 #define TCR_FUSED_WHATIF 0
 #endif
@@ -481,15 +481,18 @@ __device__ __forceinline__ void fused_head_s(const FusedArgs& a, float* lds, con
     __syncthreads();
 }
 
-// Zero halos (4 + 4 floats) of the rows a static-shape layer is about to write: [ng][COUT] rows of TOUT + 8 floats.
+// Zero halos (4 + 4 floats) of the rows a static-shape layer is about to write: [ng][COUT] rows of TOUT + 8 floats; one thread per
+// (row, side), four stores each (one thread per element: three times the index arithmetic, +6 us per launch).
 template <int NT, int COUT, int TOUT>
 __device__ __forceinline__ void fused_zero_halo(float* yout, const int out_sz, const int ng, const int tid_in) {
     constexpr int TPO = TOUT + 2 * kHalo;
+    if (TCR_WHATIF(1024)) return;
     const int tid = tid_in + opaque_zero();
-    for (int i = tid; i < ng * COUT * 8; i += NT) {
-        const int row = i >> 3, k = i & 7;
+    for (int i = tid; i < ng * COUT * 2; i += NT) {
+        const int row = i >> 1;
         const int g = row / COUT, co = row - g * COUT;
-        yout[g * out_sz + co * TPO + (k < 4 ? k : TOUT + k)] = 0.f;
+        float* p = yout + g * out_sz + co * TPO + ((i & 1) ? kHalo + TOUT : 0);
+        p[0] = 0.f; p[1] = 0.f; p[2] = 0.f; p[3] = 0.f;
     }
 }
 
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
 #define TCR_TC8_BARRIER __syncthreads()
 #endif
 #define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.buf_sz[a.layer[LI].in_buf], lds, ng, wave, r, q)
-    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+    for (int grp = blockIdx.x; grp < (TCR_WHATIF(512) ? 0 : a.n_groups); grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
         if constexpr (WD < 0) fused_layer_sel<NW, 3, 1, 40, 16, T0, WD, false>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
