@@ -117,23 +117,28 @@ def main():
     labels[torch.arange(B), (torch.arange(B) + rank * B) % 12] = 1.0
 
     # ---------------- headline: eval forward, 49x40 front-end ----------------
-    # One step = fused MFCC kernel + whole-network fused kernel, back to back on the current stream.  (A two-stream
-    # pipeline overlapping front-end(k+1) with network(k) -- tcresnet_amd.pipeline -- was measured no faster once the
-    # network became one LDS-resident kernel: 0.627 vs 0.617 ms/step.)
+    # One step = fused MFCC kernel + whole-network fused kernel, back to back on the current stream (so that the two HIP-event
+    # intervals add up to the step).  A two-stream pipeline overlapping front-end(k+1) with network(k) -- tcresnet_amd.pipeline --
+    # is ~3 % faster three batches deep (295.7 vs 304.7 us, scripts/ab_coresident.py); capping both grids at one workgroup per CU
+    # so that the kernels co-reside on every CU LOSES (357 - 447 us): DESIGN.md section 7.
     fe, net = build("4020")
     feat = torch.empty((B, 40, fe.n_frames + 8), device=dev)
     outbuf = (torch.empty((B, 12), device=dev), torch.empty((B, 12), device=dev))
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * (args.steps + args.warmup))]
+    # two HIP events per step on the launch stream: e[2i] in front of the front-end, e[2i+1] behind it; the network of step i runs
+    # from e[2i+1] to e[2i+2] (steps are back to back on one stream; one closing event behind the last step)
+    nev = args.steps + args.warmup
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nev + 1)]
     counter = [0]
 
     def fwd_step():
         i = counter[0]
         counter[0] += 1
-        ev[3 * i].record()
+        ev[2 * i].record()
         fe(wav, out=feat)
-        ev[3 * i + 1].record()
+        ev[2 * i + 1].record()
         net.forward_infer(feat, out=outbuf)
-        ev[3 * i + 2].record()
+        if i == nev - 1:
+            ev[2 * nev].record()
 
     # clock pre-warm: labelled, untimed, outside the K timed steps and the W warm-up steps of the contract
     for _ in range(max(0, args.prewarm)):
@@ -142,9 +147,10 @@ def main():
     torch.cuda.synchronize()
     dt = timed(fwd_step, args.steps, args.warmup, dist_on)
     value = world * B * args.steps / dt
-    fe_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(args.warmup, args.warmup + args.steps)) / args.steps
-    net_ms = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.warmup, args.warmup + args.steps)) / args.steps
-    per_step = sorted(ev[3 * i].elapsed_time(ev[3 * i + 2]) for i in range(args.warmup, args.warmup + args.steps))
+    rng = range(args.warmup, args.warmup + args.steps)
+    fe_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in rng) / args.steps
+    net_ms = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in rng) / args.steps
+    per_step = sorted(ev[2 * i].elapsed_time(ev[2 * i + 2]) for i in rng)
     pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4)
 
     w = WORK["4020"]

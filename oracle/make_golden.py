@@ -60,6 +60,39 @@ def make_frontend():
                             win=cfg.win, hop=cfg.hop)
 
 
+def edge_waveforms() -> np.ndarray:
+    """The reference's low-amplitude workload and two spectral extremes, where log(mel + 1e-6) amplifies error most:
+    rows 0-2: a SILENT clip (label `_silence_`: empty file -> zeros, datasets/audio_data_wrapper.py:164-174) mixed with a
+              background recording at volume 0.01 / 0.05 / 0.1 (augmentation_factory.py:92-97: clip(bg * volume + fg); the
+              reference draws the volume from U(0, 0.1), :30-101) -- the "recording" is int16 noise like a decoded WAV;
+    row 3:    white noise at amplitude 1e-4 (mel energies around the 1e-6 log offset);
+    row 4:    a pure full-scale 1 kHz sine (one spectral line, 90 dB above its neighbours);
+    row 5:    a 30 Hz sine at 0.5 (energy only BELOW the first mel filter: every band near the log offset)."""
+    from . import augment_ref as A
+    rng = np.random.RandomState(77)
+    bg = rng.randint(-32768, 32768, 3 * 16000).astype(np.int16)
+    rows = []
+    for i, vol in enumerate((0.01, 0.05, 0.1)):
+        crop = bg[i * 16000:(i + 1) * 16000].astype(np.float32) * np.float32(1.0 / 32768.0)
+        rows.append(A.mix_background(np.zeros(16000, np.float32), crop, vol))
+    rows.append((rng.uniform(-1.0, 1.0, 16000) * 1e-4).astype(np.float32))
+    t = np.arange(16000, dtype=np.float64) / 16000.0
+    rows.append(np.sin(2.0 * np.pi * 1000.0 * t).astype(np.float32))
+    rows.append((0.5 * np.sin(2.0 * np.pi * 30.0 * t)).astype(np.float32))
+    return np.stack(rows)
+
+
+def make_frontend_edges():
+    import torch
+    wav = edge_waveforms()
+    for tag, cfg in FRONTENDS.items():
+        m64 = R.mfcc(wav, cfg)
+        mt = TR.mfcc(torch.tensor(wav, dtype=torch.float64), cfg).numpy()
+        assert np.abs(m64 - mt).max() < 1e-9
+        np.savez_compressed(os.path.join(OUT, f"frontend_edge_{tag}.npz"), wav=wav, mfcc=m64, mfcc_deploy=R.mfcc_deploy(wav, cfg),
+                            win=cfg.win, hop=cfg.hop)
+
+
 def _keep(name: str, full: bool, key: str) -> bool:
     """Large nets store only the small tensors + a few weight tensors (weights are regenerated from the seeds)."""
     if full:
@@ -180,8 +213,13 @@ def make_dscnn():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    import sys
+    if "--edges-only" in sys.argv:          # (adds frontend_edge_*.npz without rewriting the other fixtures)
+        make_frontend_edges()
+        return
     make_dscnn()
     make_frontend()
+    make_frontend_edges()
     make_net("TCResNet8", 1.0, "4020")
     make_net("TCResNet8", 1.0, "3010", batch=3)
     make_net("TCResNet14", 1.5, "4020", batch=3, full=False)

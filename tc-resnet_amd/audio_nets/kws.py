@@ -22,15 +22,18 @@ TN = ("truncated_normal", 0.01)
 
 def _fc(g: Graph2D, net: int, units: int, name: str, bias: bool, init=TN) -> int:
     """tf.matmul(flattened, weights) [+ bias] over whatever [c, h, w] the input node has."""
-    _, h, w = g.shape(net)
-    return g.conv(net, (h, w), units, name, padding="VALID", biases_name=(name.replace("weights", "bias") if bias else None), init=init)
+    c, h, w = g.shape(net)
+    # (the variable is the reference's 2-D [K, N] matmul weight -- kws.py:79-81, 149-153 ...: NHWC flatten order == the [h, w, c, N] kernel layout)
+    return g.conv(net, (h, w), units, name, padding="VALID", biases_name=(name.replace("weights", "bias") if bias else None), init=init,
+                  tf_shape=(h * w * c, units))
 
 
 def build_model(g: Graph2D, model_settings, model_architecture: str) -> int:
     t, f, nc = model_settings["spectrogram_length"], model_settings["fingerprint_width"], model_settings["label_count"]
     drop = lambda n: g.dropout(n, 0.5)                                   # tf.nn.dropout(x, 0.5) when is_training
     if model_architecture == "single_fc":                                 # :65-95
-        return g.conv(-1, (t, f), nc, "weights", padding="VALID", biases_name="bias", init=("truncated_normal", 0.001))
+        return g.conv(-1, (t, f), nc, "weights", padding="VALID", biases_name="bias", init=("truncated_normal", 0.001),
+                      tf_shape=(t * f, nc))                               # [fingerprint_size, label_count] (:79-81)
     if model_architecture == "conv":                                      # :98-201
         net = drop(g.conv(-1, (20, 8), 64, "first_weights", padding="SAME", relu=True, biases_name="first_bias", init=TN))
         net = g.pool(net, "max", (2, 2), stride=(2, 2), padding="SAME")

@@ -59,8 +59,7 @@ class Ckpt:
             if extra and var in extra:
                 extra[var](value)
             else:
-                ti = self.engine.tensors[var]
-                want = tuple(ti.shape[i] for i in range(ti.rank))
+                want = self.engine.tf_shape(var)        # the shape the reference's graph declares (a KWS matmul weight is [K, N])
                 if tuple(value.shape) != want:
                     raise ValueError(f"Total size of new array must be unchanged for {ckpt_name} "
                                      f"lh_shape: [{value.shape}], rh_shape: [{want}]")

@@ -43,6 +43,14 @@ class _Base:
             return torch.cuda.current_stream(self.device).cuda_stream
         return None
 
+    def tf_shape(self, name: str) -> Tuple[int, ...]:
+        """Shape of variable `name` as the reference's TF graph declares it (what a TF-written checkpoint holds)."""
+        over = getattr(self, "tf_shapes", None)
+        if over and name in over:
+            return tuple(over[name])
+        ti = self.tensors[name]
+        return tuple(ti.shape[i] for i in range(ti.rank))
+
     def _check_tensor(self, t: torch.Tensor, what: str):
         if t.device.type != self.device.type or t.dtype != torch.float32 or not t.is_contiguous():
             raise TcrError(f"{what}: expected a contiguous float32 tensor on {self.device}, got {t.dtype} on {t.device}"
@@ -613,6 +621,7 @@ class Graph2D(_Base):
         self.initializers: Dict[str, object] = {}           # variable name -> "xavier" | ("truncated_normal", stddev) | "zeros"
         self.relu_nodes: List[int] = []                      # nodes whose output went through a ReLU, in build order
         self.dropout_nodes: List[int] = []                  # node ids of the dropout layers (each mask is keyed by its node id)
+        self.tf_shapes: Dict[str, Tuple[int, ...]] = {}      # variables whose TF shape differs from the kernel's [kh, kw, cin, cout] (matmul weights: [K, N])
         self.finalized = False
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self.slots: Dict[str, torch.Tensor] = {}
@@ -632,7 +641,9 @@ class Graph2D(_Base):
         return rc
 
     def conv(self, inp: int, kernel, cout: int, weights_name: str, stride=(1, 1), rate=(1, 1), padding: str = "SAME", relu: bool = False,
-             biases_name: Optional[str] = None, init="xavier") -> int:
+             biases_name: Optional[str] = None, init="xavier", tf_shape: Optional[Sequence[int]] = None) -> int:
+        if tf_shape is not None:
+            self.tf_shapes[weights_name] = tuple(int(d) for d in tf_shape)
         kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
         sh, sw = (stride, stride) if isinstance(stride, int) else stride
         dh, dw = (rate, rate) if isinstance(rate, int) else rate
@@ -703,7 +714,6 @@ class Graph2D(_Base):
     grad_view = TCResNet.grad_view
     trainable_names = TCResNet.trainable_names
     total_params = TCResNet.total_params
-    state_dict = TCResNet.state_dict
     _slot = TCResNet._slot
     slot_arena = TCResNet.slot_arena
     ema_init = TCResNet.ema_init
@@ -712,6 +722,10 @@ class Graph2D(_Base):
     sgd_momentum_step = TCResNet.sgd_momentum_step
     rmsprop_step = TCResNet.rmsprop_step
     l2_loss = TCResNet.l2_loss
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        """TF variable name -> array in the shape the reference's graph declares (matmul weights [K, N], not [h, w, c, N])."""
+        return {n: self._view(n).detach().cpu().numpy().copy().reshape(self.tf_shape(n)) for n in self.tensors}
 
     def load_state_dict(self, sd: Dict[str, np.ndarray], strict: bool = True):
         for n, ti in self.tensors.items():

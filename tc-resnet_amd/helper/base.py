@@ -42,7 +42,15 @@ class Base:
                 agg["model_loss"].append(np.float32(float(self.model.model_loss)))
             agg["batch_infer_time"].append(ms)
             agg["unit_infer_time"].append(ms / self.args.batch_size)
-        return {k: np.vstack(v) for k, v in agg.items() if v}
+        out = {k: np.vstack(v) for k, v in agg.items() if v}
+        if world > 1:
+            # data parallel: every rank evaluated its shard of each batch; the metrics are over all of them (rank order = sample order
+            # within a batch does not matter to any metric)
+            import torch.distributed as dist
+            parts = [None] * world
+            dist.all_gather_object(parts, out)
+            out = {k: np.vstack([p[k] for p in parts]) for k in out}
+        return out
 
     def run_evaluation(self, global_step: int, iters: Optional[int] = None, is_training: bool = False) -> Dict[str, object]:
         eval_dict = self.run_inference(global_step, iters, is_training, do_eval=True)

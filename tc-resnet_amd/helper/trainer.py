@@ -58,7 +58,8 @@ class TrainerBase(AudioBase):
         self.global_step_from_checkpoint = tf_utils.get_global_step_from_checkpoint(a.checkpoint_path)
         self.global_step = self.global_step_from_checkpoint
         if a.boundaries_epoch:
-            boundaries = [b * self.dataset.num_samples // self.dataset.batch_size for b in a.boundaries]
+            # (an optimisation step consumes batch_size samples on EVERY data-parallel rank: epochs count the global batch)
+            boundaries = [b * self.dataset.num_samples // (self.dataset.batch_size * self.world) for b in a.boundaries]
         else:
             boundaries = list(a.boundaries)
         if a.relative:
@@ -113,7 +114,7 @@ class TrainerBase(AudioBase):
             arena = eng.slot_arena(slot)
             for name, ti in eng.tensors.items():
                 if ti.arena == 0:
-                    out[f"{name}/{slot}"] = arena[ti.offset:ti.offset + ti.size].view(*[ti.shape[i] for i in range(ti.rank)])
+                    out[f"{name}/{slot}"] = arena[ti.offset:ti.offset + ti.size].view(*eng.tf_shape(name))    # slots have their variable's TF shape
         return out
 
     def _extra_variables(self) -> Dict[str, Callable[[np.ndarray], None]]:
@@ -155,8 +156,8 @@ class TrainerBase(AudioBase):
         sd["global_step"] = np.array(self.global_step, np.int64)
         if a.optimizer == "adam":
             t = self.model.step_count()
-            sd["beta1_power"] = np.array(0.9 ** t, np.float32)
-            sd["beta2_power"] = np.array(0.999 ** t, np.float32)
+            sd["beta1_power"] = np.array(0.9 ** (t + 1), np.float32)      # AdamOptimizer: accumulator starts at beta, x beta per step
+            sd["beta2_power"] = np.array(0.999 ** (t + 1), np.float32)
         tf_bundle.write_checkpoint(prefix, sd)
         if name in self._kept:
             self._kept.remove(name)
@@ -179,7 +180,8 @@ class TrainerBase(AudioBase):
 
     # ---- loop ---------------------------------------------------------------------------------------------------------
     def build_epoch(self, step):
-        return (step * self.dataset.batch_size) / self.dataset.num_samples
+        """helper/trainer.py:104-105 of the reference, with the data-parallel global batch (world = 1: the reference's formula)."""
+        return (step * self.dataset.batch_size * self.world) / self.dataset.num_samples
 
     def run_single_step(self):
         lr = piecewise_constant(self.global_step, self.boundaries, self.args.lr_list)
@@ -229,6 +231,7 @@ class TrainerBase(AudioBase):
         input run forward with is_training=True (batch-statistics BN, dropout), no update; the metrics are logged."""
         iters = self.build_evaluate_iterations(iters)
         t0 = time.time()
+        self._sync_replica_state()          # (replicas drift apart in their BN moving statistics between checkpoints)
         eval_dict = self.run_inference(global_step, iters=iters, is_training=True)
         self.last_eval = self.evaluate_metrics(eval_dict)
         if self.rank == 0:

@@ -72,6 +72,37 @@ def check_frontend(lib, tag):
     return err
 
 
+def check_frontend_edges(lib, tag):
+    """Low-amplitude / extreme-spectrum rows (oracle/make_golden.py::edge_waveforms).
+    Rows 0-3 -- silent clips under background noise at volume 0.01 / 0.05 / 0.1 (the reference's `_silence_` workload) and 1e-4 noise --
+    hold the same 1e-4 as the ordinary rows although log(mel + 1e-6) is steepest there; every kernel variant and the deploy path.
+    Rows 4-5 are pure tones (a full-scale 1 kHz line; a 30 Hz line below the first filter): every other bin of the float64 spectrum is
+    Hann leakage 100+ dB down, i.e. BELOW float32 round-off of the line (|X| ~ 320, eps |X| ~ 4e-5, power noise ~ 1e-9 against the 1e-6
+    log offset), so a float32 FFT's answer depends on its butterfly order: the float32 NumPy restatement itself is 4-8e-5 from the
+    float64 oracle on these rows (1.5e-5 on ordinary ones), the kernels 3-7e-4.  Bound: 1e-3.  The deploy path has NO offset
+    (log(max(x, 1e-12)), and TF's C++ op computes in double): its empty bands are pure round-off there -- recorded, bounded at 0.5,
+    a documented limitation of a float32 path on noise-free tones."""
+    fx = load(f"frontend_edge_{tag}.npz")
+    wav = to_dev(lib, fx["wav"])
+    errs = {}
+    fe = make_frontend(lib, fx["win"], fx["hop"])
+    got = fe.reference_view(fe(wav))[..., 0].cpu().numpy()
+    errs["packed"] = np.abs(got - fx["mfcc"]).max(axis=(1, 2))
+    try:
+        lib.tcr_tune(1, 4)                                  # the general scalar-FP32 kernel
+        g2 = fe.reference_view(fe(wav))[..., 0].cpu().numpy()
+        errs["scalar"] = np.abs(g2 - fx["mfcc"]).max(axis=(1, 2))
+    finally:
+        lib.tcr_tune(1, 0)
+    fd = make_frontend(lib, fx["win"], fx["hop"], method="mfcc_deploy")
+    gd = fd.reference_view(fd(wav))[..., 0].cpu().numpy()
+    errs["deploy"] = np.abs(gd - fx["mfcc_deploy"]).max(axis=(1, 2))
+    for k, e in errs.items():
+        assert e[:4].max() < MFCC_TOL, f"edge rows {tag} / {k}: per-row max abs err {e}"
+        assert e[4:].max() < (0.5 if k == "deploy" else 1e-3), f"pure-tone rows {tag} / {k}: per-row max abs err {e}"
+    return errs
+
+
 def check_frontend_deploy(lib, tag):
     """Deploy-path MFCC (audio_spectrogram + mfcc op semantics, method "mfcc_deploy") against oracle.mfcc_deploy."""
     fx = load(f"frontend_{tag}.npz")

@@ -15,6 +15,11 @@ def test_frontend(emu_lib, tag):
     Cm.check_frontend(emu_lib, tag)
 
 
+@pytest.mark.parametrize("tag", ["3010", "4020"])
+def test_frontend_edge_rows(emu_lib, tag):
+    Cm.check_frontend_edges(emu_lib, tag)
+
+
 def test_frontend_variants(emu_lib):
     fx = Cm.load("frontend_4020.npz")
     wav = torch.from_numpy(fx["wav"])

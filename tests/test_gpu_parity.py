@@ -23,6 +23,59 @@ def test_frontend(hip_lib, tag):
 
 
 @pytest.mark.parametrize("tag", ["3010", "4020"])
+def test_frontend_edge_rows(hip_lib, tag):
+    Cm.check_frontend_edges(hip_lib, tag)
+
+
+def test_augment_frontend_net_chain_matches_oracle(hip_lib):
+    """The composed path the reference feeds its model with (datasets/audio_data_wrapper.py:37-58 -> preprocessors.py:183-194 ->
+    tc_resnet.py:57-70): tcr_augment_fwd -> front-end -> TCResNet8 eval forward against augment_ref -> R.mfcc -> R.forward.  The batch
+    holds ordinary clips, silent clips (empty file) under background noise at volumes 0.01 / 0.05 / 0.1 and an un-mixed silent clip:
+    logits within 1e-4, identical argmax."""
+    from oracle import augment_ref as A
+    from tcresnet_amd.datasets import augmentation_factory as F
+    from tcresnet_amd import runtime
+    rng = np.random.RandomState(21)
+    desired = 16000
+    t = np.arange(20000) / 16000.0
+    clips = [np.clip((0.3 * np.sin(2 * np.pi * (300 + 170 * i) * t) + 0.2 * rng.uniform(-1, 1, t.size)) * 32768, -32768, 32767).astype(np.int16)[:n]
+             for i, n in enumerate((16000, 12000, 20000, 15999, 16000, 9000))]
+    clips += [np.zeros(0, np.int16)]                        # the `_silence_` sample: '' filename -> empty clip -> zeros
+    bgs = [rng.randint(-32768, 32768, 3 * desired).astype(np.int16), (rng.randint(-2000, 2000, 2 * desired)).astype(np.int16)]
+    idx = np.array([0, 1, 2, 3, 4, 5, 6, 6, 6, 6, 6, 0], np.int64)
+    shift = np.array([0, 100, -1600, 1599, -3, 7, 0, 55, -200, 0, 0, 0], np.int32)
+    bg_idx = np.array([0, 1, 0, 1, 0, 1, 0, 0, 1, 1, 0, 1], np.int64)
+    bg_crop = np.array([0, 5, 1000, 31, 17, 16000, 100, 32000, 777, 3, 0, 0], np.int64)
+    vol = np.array([0.0, 0.02, 0.1, 0.07, 0.0, 0.05, 0.01, 0.05, 0.1, 0.1, 0.0, 0.1], np.float32)
+    runtime.set_default(hip_lib, "cuda")
+    try:
+        pool, bg = F.PcmPool(clips), F.PcmPool(bgs)
+        fn = F.get_audio_augmentation_fn("anchored_slice_or_pad_with_shift")
+        wav = fn(pool, idx, desired, "wav", 16000, background_data=bg, is_training=True, draws=(shift, bg_idx, bg_crop, vol))[..., 0].contiguous()
+    finally:
+        runtime.set_default(None, None)
+    ref_wav = A.augment_batch(pool.data.cpu().numpy(), pool.offsets[idx], pool.lengths[idx], shift, bg.data.cpu().numpy(),
+                              bg.offsets[bg_idx] + bg_crop, vol, desired)
+    assert np.array_equal(wav.cpu().numpy(), ref_wav)       # (the input stage is bit exact)
+    assert np.abs(ref_wav[10]).max() == 0 and 0 < np.abs(ref_wav[6]).max() < 0.011
+    for tag, cfg in (("4020", R.FRONTEND_4020), ("3010", R.FRONTEND_3010)):
+        arch = R.make_tcresnet("TCResNet8", 1.0)
+        p, s = R.init_params(arch, 5)
+        R.randomize_bn(arch, p, s, 6)
+        fe = Cm.make_frontend(hip_lib, cfg.win, cfg.hop)
+        net = Cm.make_net(hip_lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+        feat = fe(wav)
+        logits, probs = net.forward_infer(feat)
+        x = R.mfcc(ref_wav.astype(np.float64), cfg)
+        ref = R.forward(arch, p, s, x, False)
+        assert np.abs(fe.reference_view(feat)[..., 0].cpu().numpy() - x).max() < Cm.MFCC_TOL, tag
+        err = np.abs(logits.cpu().numpy() - ref["logits"]).max()
+        assert err < Cm.LOGIT_TOL, f"{tag}: chained logits differ by {err}"
+        assert np.array_equal(logits.cpu().numpy().argmax(1), ref["logits"].argmax(1))
+        assert np.abs(probs.cpu().numpy() - ref["probs"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["3010", "4020"])
 def test_frontend_deploy_path(hip_lib, tag):
     Cm.check_frontend_deploy(hip_lib, tag)
     try:                                    # the general (scalar-FP32) kernel implements the same method
