@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     constexpr int UNIT = 16 * XLD;
     constexpr int PLD = NBINS + 31;         // row stride = 32 (mod 64) banks: the two frames of a wave never collide
     constexpr int kMelItemBins = mel_item_bins(NC);
+    constexpr bool kItemsLds = QV >= 15;    // mel item descriptors read from LDS per trip instead of held in registers (see kDctPre)
     constexpr int LMS = 80;                 // log-mel row stride, = 16 (mod 32): the DCT's MFMA B fragment reads 32 distinct banks
 
     __shared__ v2 s_x[16 * UNIT];                   // transpose tiles, then the FFT output of each unit; after the real-FFT split the
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     __shared__ float s_lm[NMEL * LMS];              // log-mel [mel][frame], 64 frames
     constexpr int NIT = mel_items_fast(NC);         // items of the unrolled trips
     __shared__ v2 s_wit[kMelItemBins * NIT];        // mel slopes [bin of the item][item], pre-scaled by 1/4 (1/2), zero past an item's end
+    __shared__ int s_items[kItemsLds ? kMelItemsMax : 1];
     static_assert(kMelItemsMax <= UNIT && NIT <= UNIT, "the item sums of a frame live in one transpose unit");
 
     const int tid = threadIdx.x;
@@ -261,9 +263,13 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     const int nitems = a.mel_ifirst[NSEG];
     // round-invariant: the items this lane takes (one per trip) and the item ranges of the bands it finishes
     constexpr int TRIPS = mel_trips(NC);
-    int item_d[TRIPS], band_i[NMEL / LPF];
+    int item_d[kItemsLds ? 1 : TRIPS], band_i[NMEL / LPF];
+    if (kItemsLds) {
+        for (int i = threadIdx.x; i < kMelItemsMax; i += 256) s_items[i] = a.mel_items[i];
+    } else {
 #pragma unroll
-    for (int tr = 0; tr < TRIPS; ++tr) item_d[tr] = a.mel_items[min(lf + LPF * tr, kMelItemsMax - 1)];
+        for (int tr = 0; tr < TRIPS; ++tr) item_d[kItemsLds ? 0 : tr] = a.mel_items[min(lf + LPF * tr, kMelItemsMax - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < NMEL / LPF; ++i) {
         const int m = lf + LPF * i;
@@ -290,7 +296,10 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     };
     // DCT A fragments of the first kDctPre coefficient tiles: round-invariant, loaded once (their latency would otherwise be paid
     // at the end of every chunk)
-    constexpr int kDctPre = 3;
+    // 30 / 20 ms windows (QV 15 / 16): 10 - 12 more window + prefetch registers than the 40 ms window.  Preloading three DCT tiles
+    // spilled 20 - 72 B per lane there; one tile is spill-free but exposes the other tiles' loads at every chunk end (250 vs 234 us);
+    // two tiles + the mel item descriptors read from LDS instead of held in registers: spill-free AND as fast.
+    constexpr int kDctPre = QV >= 15 ? (MAG ? 1 : 2) : 3;      // (the magnitude variants -- deploy path, log-mel -- carry the square roots: one tile)
     float dcta[kDctPre][NMEL / 4];
     if (!a.no_dct) {
 #pragma unroll
@@ -380,9 +389,14 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
 #pragma unroll 1
             for (int tr = 0; tr < TRIPS; ++tr) {            // (rolled: one trip's 16 reads in flight, not all trips' -- register budget)
                 const int it = lf + LPF * tr;
-                int d = item_d[0];
+                int d;
+                if (kItemsLds) {
+                    d = s_items[min(it, kMelItemsMax - 1)];
+                } else {
+                    d = item_d[0];
 #pragma unroll
-                for (int q = 1; q < TRIPS; ++q) d = tr == q ? item_d[q] : d;
+                    for (int q = 1; q < TRIPS; ++q) d = tr == q ? item_d[kItemsLds ? 0 : q] : d;
+                }
                 const float* pk = P + (d & 1023);            // (items past the filterbank's last: bin 0 with zero slopes)
                 const v2* wk = s_wit + it;
                 float p[kMelItemBins];
