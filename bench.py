@@ -193,6 +193,19 @@ def main():
     }
 
     if not args.no_extras:
+        # ---------------- batch-1 latency (configs[0]'s regime; the CPU baseline's batch-1 number sits in cpu_baseline.forward_by_batch) ----
+        w1 = wav[:1].contiguous()
+        o1 = (torch.empty((1, 12), device=dev), torch.empty((1, 12), device=dev))
+        for _ in range(50):
+            net.forward_waveform(fe, w1, out=o1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            net.forward_waveform(fe, w1, out=o1)
+            torch.cuda.synchronize()
+        out["latency_batch_1"] = {"value": round((time.perf_counter() - t0) / 200 * 1e6, 1), "unit": "us", "higher_is_better": False,
+                                  "workload": "one utterance, waveform -> softmax, host call (tcr_forward_waveform) + device synchronisation per "
+                                              "utterance; the two kernels' own serial latency dominates (persistent front-end set-up + one network group)"}
         # ---------------- training step (configs[2]) ----------------
         # Every step computes the MFCC of its own batch; like the reference's tf.data prefetch, the front-end of step k+1 is
         # issued on a second stream while step k's forward/backward/update occupy the main stream (FeaturePrefetcher).

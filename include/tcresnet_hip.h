@@ -154,6 +154,17 @@ int tcr_net_forward_frozen(const tcr_net* net, const float* params, const float*
                            int batch, void* workspace, size_t workspace_bytes,
                            float* logits, float* probs, float* ranges, void* stream);
 
+/* The whole eval path of one batch in ONE call: waveform -> MFCC -> (BN fold when `refold` != 0) -> network -> softmax, i.e.
+ * model.build(wavs, labels, is_training=False) + session.run(outputs) of the reference (factory/audio_nets.py:41-60,
+ * datasets/preprocessors.py:183-194, audio_nets/tc_resnet.py:6-54, helper/base.py:86-104).  Same kernels and results as
+ * tcr_frontend_fwd + tcr_net_fold_bn + tcr_net_forward_frozen; it exists for small batches, where three host calls cost more than
+ * the kernels (B <= 64: ~70 us -> the kernels' own time).
+ * feat: caller-owned scratch for the features, [batch][n_coef][n_frames + 2 * TCR_HALO] floats; frozen_ss: the folded table
+ * (tcr_net_frozen_floats), rewritten when `refold` is non-zero (stats may be NULL otherwise). */
+int tcr_forward_waveform(const tcr_frontend_cfg* cfg, const void* plan_dev, const tcr_net* net, const float* params,
+                         const float* stats, float* frozen_ss, int refold, const float* wav, int batch, float* feat,
+                         void* workspace, size_t workspace_bytes, float* logits, float* probs, float* ranges, void* stream);
+
 /* Train-mode forward (is_training=True): batch-statistics BN with moving-stat update
  * (decay, Bessel-corrected variance), inverted dropout after the global pool, softmax,
  * mean cross-entropy (factory/audio_nets.py:161-173).  Saves what backward needs in `workspace`.

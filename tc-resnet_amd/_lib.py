@@ -76,6 +76,7 @@ _PROTOTYPES = {
     "tcr_net_frozen_floats": (C.c_int64, [_P]),
     "tcr_net_fold_bn": (C.c_int, [_P, _P, _P, _P, _P]),
     "tcr_net_forward_frozen": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P, _P, _P, _P]),
+    "tcr_forward_waveform": (C.c_int, [C.POINTER(FrontendCfg), _P, _P, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     "tcr_net_backward": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P, _P]),
     "tcr_net_num_stages": (C.c_int, [_P, C.c_int]),
     "tcr_net_stage_sums": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),

@@ -420,6 +420,21 @@ extern "C" int tcr_net_forward_frozen(const tcr_net* net, const float* params, c
     return forward_infer_impl(net, params, nullptr, frozen_ss, feat, batch, workspace, workspace_bytes, logits, probs, ranges, stream);
 }
 
+extern "C" int tcr_forward_waveform(const tcr_frontend_cfg* cfg, const void* plan_dev, const tcr_net* net, const float* params,
+                                    const float* stats, float* frozen_ss, int refold, const float* wav, int batch, float* feat,
+                                    void* workspace, size_t workspace_bytes, float* logits, float* probs, float* ranges, void* stream) {
+    TCR_REQUIRE(cfg && net && frozen_ss && feat, "tcr_forward_waveform: null argument");
+    TCR_REQUIRE(cfg->n_coef == net->cfg.in_channels && cfg->n_frames == net->cfg.t_in,
+                "tcr_forward_waveform: the front-end yields %d x %d features, the network expects %d x %d", cfg->n_coef, cfg->n_frames,
+                net->cfg.in_channels, net->cfg.t_in);
+    TCR_TRY(tcr_frontend_fwd(cfg, plan_dev, wav, batch, feat, stream));
+    if (refold) {
+        TCR_REQUIRE(params && stats, "tcr_forward_waveform: refold needs params and stats");
+        TCR_TRY(fold_bn(*net, params, stats, frozen_ss, static_cast<hipStream_t>(stream)));
+    }
+    return forward_infer_impl(net, params, nullptr, frozen_ss, feat, batch, workspace, workspace_bytes, logits, probs, ranges, stream);
+}
+
 static int forward_infer_impl(const tcr_net* net, const float* params, const float* stats, const float* frozen_ss, const float* feat,
                               int batch, void* workspace, size_t workspace_bytes, float* logits, float* probs, float* ranges, void* stream) {
     TCR_REQUIRE(net && params && feat && workspace && logits && probs, "tcr_net_forward_infer: null argument");

@@ -176,6 +176,7 @@ class TCResNet(_Base):
         self.slots: Dict[str, torch.Tensor] = {}      # optimiser slots (arena-shaped)
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self._kver, self._fold_key, self._fold_ss, self._fold_event, self._fold_stream, self._fold_readers = 0, None, None, None, None, {}
+        self._wave_feat: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self.reset_bn()
 
     def __del__(self):
@@ -312,6 +313,45 @@ class TCResNet(_Base):
                 if ev is None:
                     ev = self._fold_readers[cur.cuda_stream] = torch.cuda.Event()
                 ev.record(cur)
+        return (logits, probs, ranges) if want_ranges else (logits, probs)
+
+    def forward_waveform(self, frontend: "Frontend", wav: torch.Tensor, want_ranges: bool = False, out=None, feat: Optional[torch.Tensor] = None):
+        """Waveforms [B, n_samples] -> (logits, probs): front-end, BN fold when the weights changed since the last fold, and the network
+        in ONE host call (`tcr_forward_waveform`).  Bitwise `forward_infer(frontend(wav))`; built for small batches, where the three
+        calls of that form cost more than their kernels."""
+        if wav.dim() == 3:
+            wav = wav[..., 0]
+        if wav.dim() != 2 or wav.shape[1] != frontend.cfg.n_samples:
+            raise TcrError(f"front-end expects [B, {frontend.cfg.n_samples}] waveforms, got {tuple(wav.shape)}")
+        self._check_tensor(wav, "front-end input")
+        b = wav.shape[0]
+        key = (b, frontend.cfg.n_coef, frontend.cfg.n_frames)
+        if feat is None:
+            feat = self._wave_feat.get(key)
+            if feat is None:
+                feat = self._wave_feat[key] = torch.empty((b, frontend.cfg.n_coef, padded_len(frontend.cfg.n_frames)), dtype=torch.float32,
+                                                          device=self.device)
+        ws = self.workspace(b, False)
+        if out is not None:
+            logits, probs = out
+        else:
+            logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
+            probs = torch.empty_like(logits)
+        ranges = torch.empty((b, 2), dtype=torch.float32, device=self.device) if want_ranges else None
+        ver = self._weights_version()
+        cur = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+        refold = self._fold_key != ver or self._fold_ss is None or (cur is not None and cur != self._fold_stream)
+        if refold and (self._fold_ss is None or self._fold_readers or (cur is not None and cur != self._fold_stream)):
+            ss = self._folded_table()           # allocation / cross-stream ordering: the general path
+            refold = False
+        else:
+            ss = self._fold_ss
+        self.lib.check(self.lib.tcr_forward_waveform(C.byref(frontend.cfg), frontend.plan.data_ptr(), self._h, self.params.data_ptr(),
+                                                     self.stats.data_ptr(), ss.data_ptr(), int(refold), wav.data_ptr(), b, feat.data_ptr(),
+                                                     ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), _ptr(ranges),
+                                                     self._stream()), "tcr_forward_waveform")
+        if refold:
+            self._fold_key = ver
         return (logits, probs, ranges) if want_ranges else (logits, probs)
 
     def fold_bn(self) -> torch.Tensor:

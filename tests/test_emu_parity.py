@@ -148,3 +148,32 @@ def test_bn_backward_fused_equals_pair(emu_lib):
 
 def test_dscnn_staged_sync_bn_api(emu_lib):
     Cm.check_dscnn_staged_equals_unstaged(emu_lib, "S", 3)
+
+
+def test_forward_waveform_single_call_is_the_three_call_path(emu_lib):
+    """tcr_forward_waveform (front-end + fold-if-stale + network in one host call) == frontend -> forward_infer, bitwise; the fold
+    follows weight changes (load_state_dict, an optimiser step)."""
+    lib = emu_lib
+    fx = Cm.load("tcresnet8_1.0_4020.npz")
+    arch, p, s = Cm.fixture_params(fx, "TCResNet8", 1.0)
+    fe = Cm.make_frontend(lib, fx["win"], fx["hop"])
+    net = Cm.make_net(lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+    wav = Cm.to_dev(lib, fx["wav"])
+    ref = net.forward_infer(fe(wav), want_ranges=True)
+    got = net.forward_waveform(fe, wav, want_ranges=True)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert np.abs(got[0].cpu().numpy() - fx["eval_logits"]).max() < Cm.LOGIT_TOL
+    # weights change -> the cached fold is refreshed inside the same call
+    s2 = {k: (v * 1.5 if "moving_variance" in k else v + 0.1) for k, v in s.items()}
+    sd = dict(p); sd.update(s2)
+    net.load_state_dict(sd)
+    got2 = net.forward_waveform(fe, wav[:3].contiguous())
+    fresh = Cm.make_net(lib, "TCResNet8", 1.0, fe.n_frames, p, s2)
+    ref2 = fresh.forward_infer(fe(wav[:3].contiguous()))
+    assert torch.equal(got2[0], ref2[0]) and torch.equal(got2[1], ref2[1]) and not torch.equal(got2[0], got[0][:3])
+    lab = Cm.to_dev(lib, fx["labels"])
+    net.forward_train(fe(wav), lab, keep_prob=1.0); net.backward(); net.sgd_momentum_step(0.1, 0.9, 0.001)
+    got3 = net.forward_waveform(fe, wav)
+    ref3 = net.forward_infer(fe(wav))
+    assert torch.equal(got3[0], ref3[0]) and not torch.equal(got3[0], got[0])
