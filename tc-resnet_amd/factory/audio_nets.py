@@ -150,6 +150,27 @@ class AudioNetModel(TFModel):
     def step_count(self) -> int:
         return self._step
 
+    def set_trainable_scopes(self, trainable_scopes: str, logger=None):
+        """`--trainable_scopes a,b`: tf_utils.get_variables_to_train (common/tf_utils.py:19-37 of the reference) -- the trainable
+        variables whose name re.match-es one of the comma-separated scopes (tf.get_collection's filter); '' trains everything.
+        Every other variable is left out of the optimiser's var_list (helper/trainer.py:199-222): no update, no slot update, no
+        weight decay step (its L2 term still counts in total_loss); BN moving statistics keep updating (slim's update ops)."""
+        import re
+        scopes = [sc.strip() for sc in trainable_scopes.split(",")] if trainable_scopes else []
+        names = [n for n, ti in self.engine.tensors.items() if ti.arena == 0]
+        train = [n for n in names if any(re.match(sc, n) for sc in scopes)] if scopes else names
+        self._frozen = [(int(ti.offset), int(ti.size)) for n, ti in self.engine.tensors.items() if ti.arena == 0 and n not in set(train)]
+        for n in (train if scopes else []):
+            if logger is not None:
+                logger.info("vars to train > %s", n)
+        return train
+
+    _OPT_SLOTS = {"mom": ("Momentum",), "gd": ("Momentum",), "adam": ("Adam", "Adam_1"), "rmsprop": ("RMSProp", "RMSProp_1")}
+
+    def _frozen_arenas(self, optimizer, ema):
+        eng = self.engine
+        return [eng.params] + [eng.slot_arena(n) for n in self._OPT_SLOTS[optimizer] + (("ExponentialMovingAverage",) if ema else ())]
+
     def train_step(self, wavs, labels, learning_rate, optimizer="mom", momentum=None, decay=None, epsilon=None, sync_bn=False,
                    ema_decay=None):
         """One optimisation step on a (local shard of a) batch; returns (total_loss, model_loss) as device scalars.
@@ -166,6 +187,10 @@ class AudioNetModel(TFModel):
         dp.backward()
         l2 = self.engine.l2_loss(self.args.weight_decay)
         wd = float(self.args.weight_decay)
+        frozen = getattr(self, "_frozen", None)
+        stash = None
+        if frozen:      # variables outside --trainable_scopes: the arena-wide optimiser kernels run, then their slices are put back
+            stash = [[a[o:o + n].clone() for o, n in frozen] for a in self._frozen_arenas(optimizer, ema_decay is not None)]
         if optimizer == "mom":
             self.engine.sgd_momentum_step(learning_rate, 0.9 if momentum is None else momentum, wd)
         elif optimizer == "gd":
@@ -179,6 +204,10 @@ class AudioNetModel(TFModel):
             raise NotImplementedError(f"optimizer {optimizer}")
         if ema_decay is not None:
             self.engine.ema_step(ema_decay)
+        if stash is not None:
+            for a, saved in zip(self._frozen_arenas(optimizer, ema_decay is not None), stash):
+                for (o, n), v in zip(frozen, saved):
+                    a[o:o + n].copy_(v)
         self._model_loss = dp.mean_loss(loss_sum, b)
         self._total_loss = self._model_loss + l2
         return self._total_loss, self._model_loss

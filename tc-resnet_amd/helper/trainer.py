@@ -99,7 +99,9 @@ class TrainerBase(AudioBase):
         self.setup_essentials(a.max_to_keep)
         self.optimizer_kwargs = self.build_optimizer(a.optimizer, momentum=a.momentum, decay=a.optimizer_decay, epsilon=a.optimizer_epsilon)
         if getattr(a, "trainable_scopes", ""):
-            raise NotImplementedError("--trainable_scopes: partial training is not built (every reference script trains all variables)")
+            trained = self.model.set_trainable_scopes(a.trainable_scopes, self.log)
+            if not trained:
+                self.log.info("Empty variables_to_train")           # (the reference's train op is then tf.no_op(), :220-222)
         if a.use_ema:
             self.model.engine.ema_init()
         self.routine_restore_and_initialize()

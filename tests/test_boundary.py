@@ -186,9 +186,22 @@ def test_trainer_flags_are_honoured_or_refused(rt, tmp_path):
     tc_resnet.reset_engines()
     with pytest.raises(TypeError):                  # tf.train.AdamOptimizer(momentum=...) is a constructor error in the reference too
         train_audio.train(train_audio.parse_arguments(REF_TRAIN_CMD.replace("--optimizer mom", "--optimizer adam").format(d=tmp_path / "x").split()))
+    # --trainable_scopes (common/tf_utils.py:19-37): only the variables re.match-ing a scope get an update / slot / decay step; the
+    # others stay bit for bit (BN moving statistics are not variables of the optimiser: they keep updating)
     tc_resnet.reset_engines()
-    with pytest.raises(NotImplementedError):
-        train_audio.train(train_audio.parse_arguments(REF_TRAIN_CMD.replace("--optimizer mom", "--trainable_scopes TCResNet8/fc --optimizer mom").format(d=tmp_path / "y").split()))
+    tr = train_audio.train(train_audio.parse_arguments(REF_TRAIN_CMD.replace("--optimizer mom", "--trainable_scopes TCResNet8/fc,TCResNet8/block2/conv2_1/B --optimizer mom")
+                                                       .replace("--max_step_from_restore 3", "--max_step_from_restore 2").format(d=tmp_path / "y").split()))
+    eng = tr.model.engine
+    fresh = type(eng)(eng.scope, eng.channels, eng.in_channels, eng.t_in, eng.num_classes, lib=eng.lib, device=eng.device)
+    fresh.init_xavier(0)
+    init, now, mom = fresh.state_dict(), eng.state_dict(), eng.slot_arena("Momentum")
+    moved = {n for n in eng.trainable_names() if not np.array_equal(init[n], now[n])}
+    assert moved == {"TCResNet8/fc/weights", "TCResNet8/fc2/weights", "TCResNet8/block2/conv2_1/BatchNorm/gamma", "TCResNet8/block2/conv2_1/BatchNorm/beta"} - \
+        ({"TCResNet8/fc2/weights"} if np.array_equal(init["TCResNet8/fc2/weights"], now["TCResNet8/fc2/weights"]) and float(tr.args.weight_decay) == 0 else set())
+    for n, ti in eng.tensors.items():
+        if ti.arena == 0 and n not in moved:
+            assert float(mom[ti.offset:ti.offset + ti.size].abs().max()) == 0.0, n      # no slot update either
+    assert any(not np.array_equal(init[n], now[n]) for n in now if n.endswith("moving_mean"))
     with pytest.raises(SystemExit):
         train_audio.parse_arguments(REF_TRAIN_CMD.replace("--step_evaluation 500", "--step_evaluation 0").format(d=tmp_path).split())
 
