@@ -249,6 +249,12 @@ int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, const float* f
 /* Cross-replica (sync) BN for DS-CNN, as tcr_net_*_stage: stage u of the forward ends with unit u's {sum y, sum y^2} (2*C float64) in
  * the hand-off buffer, stage k of the backward with {sum dz, sum dz*xhat} of unit (units-1-k); the host all-reduces them between stages.
  * tcr_dscnn_num_stages() stages each way; with one replica the staged run is bitwise the unstaged one. */
+/* Where a training forward left the post-BN+ReLU activation of BN unit `unit` (0 = conv_1, then depthwise / pointwise of every
+ * separable block) inside the caller's training workspace: [batch][channels][padded] floats at float offset *offset, the `positions`
+ * values of a plane behind a TCR_HALO-float halo.  The reference's `endpoints` of ds_cnn.py:46-62,104-118; used by the parity tests
+ * to take the float64 oracle's gradient on the kernels' side of ReLU inputs within round-off of zero. */
+int tcr_dscnn_num_units(const tcr_dscnn* net);
+int tcr_dscnn_unit_output(const tcr_dscnn* net, int unit, int batch, int64_t* offset, int* channels, int* positions, int* padded);
 int tcr_dscnn_num_stages(const tcr_dscnn* net);
 int tcr_dscnn_stage_sums(const tcr_dscnn* net, int backward, int stage, void* workspace, int batch, double** sums_dev, int64_t* n_doubles);
 int tcr_dscnn_forward_train_stage(const tcr_dscnn* net, const float* params, float* stats, const float* feat, const float* labels,

@@ -194,9 +194,10 @@ def depthwise_conv2d_bwd(x, w, dy, stride):
     return dxp[:, pt:pt + x.shape[1], pl:pl + x.shape[2], :], dw
 
 
-def _bn_relu_bwd(da, out, c):
-    """Backward of relu(xhat + beta) with train-mode statistics (FusedBatchNormGrad, scale=False): returns (dz, dbeta)."""
-    dy = da * (out > 0)
+def _bn_relu_bwd(da, out, c, positive=None):
+    """Backward of relu(xhat + beta) with train-mode statistics (FusedBatchNormGrad, scale=False): returns (dz, dbeta).
+    positive: optional boolean mask to use instead of (out > 0) (tests: the implementation's side of inputs within round-off of 0)."""
+    dy = da * ((out > 0) if positive is None else positive)
     n = dy.shape[0] * dy.shape[1] * dy.shape[2]
     dbeta = dy.sum(axis=(0, 1, 2))
     dgx = (dy * c["xhat"]).sum(axis=(0, 1, 2))
@@ -208,11 +209,12 @@ def loss(logits, labels_onehot):
     return float(-(labels_onehot * log_softmax(logits)).sum(axis=1).mean())
 
 
-def backward(blocks: List[DsBlock], p, fwd, labels_onehot):
+def backward(blocks: List[DsBlock], p, fwd, labels_onehot, masks=None):
     """Gradient of the mean softmax cross-entropy wrt every trainable.  The conv biases feed a train-mode BN: their
     gradient (sum of dz) is zero up to round-off; it is computed honestly here."""
     g: Dict[str, np.ndarray] = {}
     cache = fwd["cache"]
+    masks = masks or {}             # cache key ("conv_ds_2/mid", ...) -> ReLU mask replacing (activation > 0)
     b = labels_onehot.shape[0]
     dlogits = (fwd["probs"] - labels_onehot) / b
     g["DSCNN/fc1/weights"] = fwd["pooled"].T @ dlogits
@@ -223,15 +225,15 @@ def backward(blocks: List[DsBlock], p, fwd, labels_onehot):
     for blk in reversed(blocks):
         pre = f"DSCNN/{blk.scope}"
         if blk.type == "separable":
-            dz, g[pre + "/pw_batch_norm/beta"] = _bn_relu_bwd(da, cache[blk.scope + "/out"], cache[pre + "/pw_batch_norm"])
+            dz, g[pre + "/pw_batch_norm/beta"] = _bn_relu_bwd(da, cache[blk.scope + "/out"], cache[pre + "/pw_batch_norm"], masks.get(blk.scope + "/out"))
             g[pre + "/pointwise_conv/biases"] = dz.sum(axis=(0, 1, 2))
             da, g[pre + "/pointwise_conv/weights"] = conv2d_bwd(cache[blk.scope + "/mid"], p[pre + "/pointwise_conv/weights"], dz, (1, 1))
-            dz, g[pre + "/dw_batch_norm/beta"] = _bn_relu_bwd(da, cache[blk.scope + "/mid"], cache[pre + "/dw_batch_norm"])
+            dz, g[pre + "/dw_batch_norm/beta"] = _bn_relu_bwd(da, cache[blk.scope + "/mid"], cache[pre + "/dw_batch_norm"], masks.get(blk.scope + "/mid"))
             g[pre + "/depthwise_conv/biases"] = dz.sum(axis=(0, 1, 2))
             da, g[pre + "/depthwise_conv/depthwise_weights"] = depthwise_conv2d_bwd(
                 cache[blk.scope + "/in"], p[pre + "/depthwise_conv/depthwise_weights"], dz, blk.stride)
         else:
-            dz, g[pre + "/batch_norm/beta"] = _bn_relu_bwd(da, cache[blk.scope + "/out"], cache[pre + "/batch_norm"])
+            dz, g[pre + "/batch_norm/beta"] = _bn_relu_bwd(da, cache[blk.scope + "/out"], cache[pre + "/batch_norm"], masks.get(blk.scope + "/out"))
             g[pre + "/biases"] = dz.sum(axis=(0, 1, 2))
             _, g[pre + "/weights"] = conv2d_bwd(cache[blk.scope + "/in"], p[pre + "/weights"], dz, blk.stride, need_dx=False)
     return g

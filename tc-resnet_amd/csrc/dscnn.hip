@@ -874,6 +874,17 @@ extern "C" int tcr_dscnn_forward_train_stage(const tcr_dscnn* net, const float* 
                                    logits, probs, loss_out, stage, stage + 1, stream);
 }
 
+extern "C" int tcr_dscnn_num_units(const tcr_dscnn* net) { return net ? (int)ds_units(*net).size() : 0; }
+
+extern "C" int tcr_dscnn_unit_output(const tcr_dscnn* net, int unit, int batch, int64_t* offset, int* channels, int* positions, int* padded) {
+    TCR_REQUIRE(net && offset && channels && positions && padded && batch > 0, "tcr_dscnn_unit_output: bad argument");
+    const std::vector<DsUnit> units = ds_units(*net);
+    TCR_REQUIRE(unit >= 0 && unit < (int)units.size(), "tcr_dscnn_unit_output: unit %d of %d", unit, (int)units.size());
+    const DsTrainWs w = ds_carve(*net, batch);
+    *offset = w.act[unit]; *channels = units[unit].c; *positions = units[unit].P; *padded = tcr_padded_len(units[unit].P);
+    return TCR_OK;
+}
+
 extern "C" int tcr_dscnn_stage_sums(const tcr_dscnn* net, int backward, int stage, void* workspace, int batch, double** sums_dev,
                                     int64_t* n_doubles) {
     TCR_REQUIRE(net && workspace && sums_dev && n_doubles, "tcr_dscnn_stage_sums: null argument");

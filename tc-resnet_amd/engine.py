@@ -601,6 +601,14 @@ class DSCNN(_Base):
         self._last = (feat, b, gb, sync_hook)
         return logits, probs, loss[0]
 
+    def unit_output(self, unit: int, batch: int) -> torch.Tensor:
+        """[B, C, P] view of BN unit `unit`'s post-ReLU activation left in the training workspace by the last forward_train at `batch`."""
+        off, c, pos, pad = C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+        self.lib.check(self.lib.tcr_dscnn_unit_output(self._h, int(unit), int(batch), C.byref(off), C.byref(c), C.byref(pos), C.byref(pad)),
+                       "tcr_dscnn_unit_output")
+        ws = self.train_workspace(batch)
+        return ws[off.value: off.value + batch * c.value * pad.value].view(batch, c.value, pad.value)[:, :, HALO:HALO + pos.value]
+
     def _stage_sums(self, backward: int, stage: int, ws: torch.Tensor, batch: int) -> torch.Tensor:
         ptr, n = C.c_void_p(), C.c_int64()
         self.lib.check(self.lib.tcr_dscnn_stage_sums(self._h, backward, stage, ws.data_ptr(), batch, C.byref(ptr), C.byref(n)),

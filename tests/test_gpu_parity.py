@@ -270,18 +270,29 @@ def test_dscnn_train_full_batch(hip_lib):
     ref = D.forward(blocks, p, s, R.mfcc(base, dataclasses.replace(R.FRONTEND_4020, num_mfccs=10)), True)
     assert np.abs(l[0].cpu().numpy() - ref["logits"]).max() < Cm.LOGIT_TOL
     assert abs(float(loss_sum) / 4096 - D.loss(ref["logits"], labels64)) < 1e-4
-    gref = D.backward(blocks, p, ref, labels64)
-    # 64 utterances x 11 BN+ReLU layers x 276 channels x 65-250 positions = ~20 M ReLU inputs.  Those within 1e-5 of the kink
-    # (counted from the float64 forward) may be masked differently by an f32 forward; one flip in a 276-channel depthwise /
-    # pointwise layer moves that channel's gradient entries by O(1 / positions-per-channel).  No such inputs: every gradient to
-    # 1e-3 of the tensor's largest entry; otherwise per-tensor 1e-3 still holds for the tensors downstream of every ReLU (fc1) and
-    # 2e-2 for the rest.
-    near = sum(int((np.abs(c["xhat"] + p[k + "/beta"]) < 1e-5).sum()) for k, c in ref["cache"].items() if isinstance(c, dict) and "xhat" in c)
+    # 64 utterances x 11 BN+ReLU layers x 276 channels x 65-250 positions = ~20 M ReLU inputs, some tens of them within 1e-5 of the
+    # kink, where an f32 forward may land on the other side; ONE flip moves a depthwise / pointwise gradient entry by O(1 / positions).
+    # As for the graph-engine families (tests/test_models2d.py), the float64 oracle takes the kernels' own side for exactly those
+    # inputs (tcr_dscnn_unit_output, consulted only where |xhat + beta| < 1e-5): every gradient then holds 1e-3 of its tensor's
+    # largest entry at the full batch (round 2 allowed 2e-2 here).
+    keys, near, masks = [], 0, {}
+    for blk in blocks:
+        keys += [(blk.scope + "/out", f"DSCNN/{blk.scope}/batch_norm")] if blk.type != "separable" else \
+            [(blk.scope + "/mid", f"DSCNN/{blk.scope}/dw_batch_norm"), (blk.scope + "/out", f"DSCNN/{blk.scope}/pw_batch_norm")]
+    assert len(keys) == net.lib.tcr_dscnn_num_units(net._h)
+    for ui, (ck, bn) in enumerate(keys):
+        pre = ref["cache"][bn]["xhat"] + p[bn + "/beta"]                    # [64, H, W, C]: the ReLU's input
+        close = np.abs(pre) < 1e-5
+        near += int(close.sum())
+        if close.any():
+            act = net.unit_output(ui, 4096)[:64].cpu().numpy()                # [64, C, H*W] (tile 0 of the batch)
+            kpos = np.transpose(act.reshape(64, pre.shape[3], pre.shape[1], pre.shape[2]), (0, 2, 3, 1)) > 0
+            masks[ck] = np.where(close, kpos, pre > 0)
+    gref = D.backward(blocks, p, ref, labels64, masks=masks)
     for k in ("DSCNN/fc1/weights", "DSCNN/fc1/biases", "DSCNN/conv_ds_5/pointwise_conv/weights", "DSCNN/conv_ds_3/depthwise_conv/depthwise_weights",
-              "DSCNN/conv_ds_1/dw_batch_norm/beta", "DSCNN/conv_1/weights"):
+              "DSCNN/conv_ds_1/dw_batch_norm/beta", "DSCNN/conv_ds_2/pw_batch_norm/beta", "DSCNN/conv_ds_1/pointwise_conv/weights", "DSCNN/conv_1/weights"):
         got = net.grad_view(k).cpu().numpy().reshape(gref[k].shape)
-        tol = 1e-3 if (near == 0 or "fc1" in k) else 2e-2
-        assert np.abs(got - gref[k]).max() < tol * np.abs(gref[k]).max(), (k, near)
+        assert np.abs(got - gref[k]).max() < 1e-3 * np.abs(gref[k]).max(), (k, near)
     net.stats.copy_(stats0)
     logits2, _, loss2 = net.forward_train(feat, labels)
     g2 = net.backward()
