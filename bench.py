@@ -228,9 +228,10 @@ def main():
         # every secondary leg: >= 20 timed steps after >= 10 warm-up steps whatever the command line says (the driver's
         # --steps 20 --warmup 5 used to leave the DS-CNN leg 6 steps after 2: a bimodal 4.3 / 8.8 ms)
         tsteps, twarm = max(20, args.steps // 2), max(10, args.warmup // 2)
+        c0 = dp.collectives
         tdt = timed(train_step, tsteps, twarm, dist_on)
         out["train"] = {"value": round(world * B * tsteps / tdt, 1), "unit": "utterances/s", "ms_per_step": round(tdt / tsteps * 1e3, 4),
-                        "steps": tsteps, "workload": "TCResNet8-1.0 train step: MFCC (prefetched on a second stream) + train-mode BN fwd + bwd + momentum (wd 1e-3, keep_prob 0.5), "
+                        "steps": tsteps, "collectives_per_step": round((dp.collectives - c0) / (tsteps + twarm), 2), "workload": "TCResNet8-1.0 train step: MFCC (prefetched on a second stream) + train-mode BN fwd + bwd + momentum (wd 1e-3, keep_prob 0.5), "
                                                      f"batch {B}/GPU" + (f", {coll} all-reduce of the flat gradient arena" if dist_on else "")}
         # ---------------- TCResNet14-1.5 training (configs[3]: global batch 32768 = 8 x 4096 over RCCL) ----------------
         net14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, fe.n_frames, 12, device=dev)
@@ -246,9 +247,10 @@ def main():
             net14.sgd_momentum_step(0.1, 0.9, 0.001)
 
         t14 = max(20, args.steps // 4)
+        c0 = dp14.collectives
         dt14 = timed(train14_step, t14, 10, dist_on)
         out["train_tcresnet14_1.5"] = {"value": round(world * B * t14 / dt14, 1), "unit": "utterances/s", "ms_per_step": round(dt14 / t14 * 1e3, 4),
-                                       "steps": t14, "workload": f"TCResNet14-1.5 train step, batch 4096/GPU (global {world * B}), 303 144 params"
+                                       "steps": t14, "collectives_per_step": round((dp14.collectives - c0) / (t14 + 10), 2), "workload": f"TCResNet14-1.5 train step, batch 4096/GPU (global {world * B}), 303 144 params"
                                                                  + (f", {coll} all-reduce of the 1.21 MB gradient arena" if dist_on else "")}
         del net14, dp14
         # ---------------- 30/10 ms front-end (98x40, the reference's training scripts) ----------------

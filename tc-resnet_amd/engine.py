@@ -16,6 +16,9 @@ from . import _lib
 from ._lib import HALO, DSCNNCfg, FrontendCfg, TCResNetCfg, TensorInfo, TcrError, padded_len
 
 
+DP_TAIL = 16        # floats behind the gradient arena that ride along with its all-reduce (the replicas' loss sum): one collective per step
+
+
 def _resolve(lib: Optional[_lib.Library], device) -> Tuple[_lib.Library, torch.device]:
     if lib is None:
         lib = _lib.get()            # raises when the HIP extension is missing
@@ -172,7 +175,7 @@ class TCResNet(_Base):
             self.tensors[ti.name.decode()] = ti
         self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
         self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_param + DP_TAIL, dtype=torch.float32, device=self.device)     # (+ the data-parallel tail: parallel.py)
         self.slots: Dict[str, torch.Tensor] = {}      # optimiser slots (arena-shaped)
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self._kver, self._fold_key, self._fold_ss, self._fold_event, self._fold_stream, self._fold_readers = 0, None, None, None, None, {}
@@ -515,7 +518,7 @@ class DSCNN(_Base):
             self.tensors[ti.name.decode()] = ti
         self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
         self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_param + DP_TAIL, dtype=torch.float32, device=self.device)     # (+ the data-parallel tail: parallel.py)
         self.slots: Dict[str, torch.Tensor] = {}
         self._ws: Dict[int, torch.Tensor] = {}
         self._train_ws: Dict[int, torch.Tensor] = {}
@@ -754,7 +757,7 @@ class Graph2D(_Base):
             self.tensors[ti.name.decode()] = ti
         self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
         self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_param + DP_TAIL, dtype=torch.float32, device=self.device)     # (+ the data-parallel tail: parallel.py)
         self.init_variables(0)
 
     # ---- variables ---------------------------------------------------------------------------------------------------

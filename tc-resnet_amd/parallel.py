@@ -34,9 +34,13 @@ class DataParallel:
         self.rank = dist.get_rank(group) if self.enabled else 0
         if self.enabled and ranks_share_gpu() and hasattr(net, "lib"):
             net.lib.tcr_tune(7, 1)          # TCR_TUNE_WGRAD_STREAM: everything on the caller's stream (see ranks_share_gpu)
+        self.collectives = 0                # all-reduces issued so far (tests / bench: collectives per step)
+        self._loss = None                   # this step's local loss sum (forward_train) ...
+        self._loss_reduced = None           # ... and its all-reduced value, carried in the tail of the gradient arena
 
     def _sum(self, t: torch.Tensor):
         if self.enabled:
+            self.collectives += 1
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def forward_train(self, feat, labels, keep_prob=1.0, seed=0, label_smoothing=0.0):
@@ -44,15 +48,28 @@ class DataParallel:
         gradients is the gradient of the global mean loss; dropout masks are indexed by global sample id."""
         b = feat.shape[0]
         hook = self._sum if (self.sync_bn and self.enabled) else None
-        return self.net.forward_train(feat, labels, keep_prob=keep_prob, seed=seed, sample_offset=self.rank * b,
-                                      global_batch=self.world * b, label_smoothing=label_smoothing, sync_hook=hook)
+        out = self.net.forward_train(feat, labels, keep_prob=keep_prob, seed=seed, sample_offset=self.rank * b,
+                                     global_batch=self.world * b, label_smoothing=label_smoothing, sync_hook=hook)
+        self._loss, self._loss_reduced = out[2], None
+        return out
 
     def backward(self):
+        """Local backward, then ONE all-reduce of the gradient arena; the replica's loss sum rides in the arena's tail
+        (engine.DP_TAIL), so that logging the global mean loss costs no second collective."""
         g = self.net.backward()
-        self._sum(g)                    # one RCCL all-reduce of the whole arena
+        n = int(self.net.n_param)
+        has_tail = self.enabled and self._loss is not None and g.numel() > n
+        if has_tail:
+            g[n:n + 1].copy_(self._loss.detach().reshape(1))
+        self._sum(g)
+        if has_tail:
+            self._loss_reduced = (self._loss, g[n].clone())
+            g[n:n + 1].zero_()              # (the arena reads the same as a single-process one)
         return g
 
     def mean_loss(self, loss_sum: torch.Tensor, local_batch: int) -> torch.Tensor:
+        if self._loss_reduced is not None and self._loss_reduced[0] is loss_sum:
+            return self._loss_reduced[1] / float(self.world * local_batch)
         t = loss_sum.detach().clone().reshape(1)
         self._sum(t)
         return t[0] / float(self.world * local_batch)

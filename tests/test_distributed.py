@@ -68,7 +68,8 @@ def _worker(rank, world, port, sync_bn, out_dir, kind, name, width, b):
     net.sgd_momentum_step(0.1, 0.9, 0.001)
     torch.cuda.synchronize() if fe.device.type == "cuda" else None
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), grads=g.cpu().numpy(), logits=logits.cpu().numpy(), loss=float(mean_loss),
-             params=net.params.cpu().numpy(), stats=net.stats.cpu().numpy())
+             params=net.params.cpu().numpy(), stats=net.stats.cpu().numpy(), collectives=dp.collectives,
+             units=(lib.tcr_dscnn_num_units(net._h) if name == "DSCNN" else lib.tcr_net_num_stages(net._h, 0) - 1))
     dist.destroy_process_group()
 
 
@@ -85,6 +86,10 @@ def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b, grad_tol=2e-5):
     # replicas hold identical gradients / parameters / moving statistics after the all-reduce
     assert np.array_equal(r[0]["grads"], r[1]["grads"]) and np.array_equal(r[0]["params"], r[1]["params"])
     assert abs(float(r[0]["loss"]) - float(r[1]["loss"])) == 0.0
+    # collectives per step: ONE for the gradient arena (the loss sum rides in its tail), plus -- cross-replica BN only -- one
+    # per BN unit in the forward and one in the backward (2 x 10 for TCResNet8, 2 x 16 for TCResNet14, 2 x 11 for DS-CNN)
+    for ri in r:
+        assert int(ri["collectives"]) == 1 + (2 * int(ri["units"]) if sync_bn else 0), (int(ri["collectives"]), int(ri["units"]))
     if sync_bn:
         assert np.array_equal(r[0]["stats"], r[1]["stats"])
     # single process, global batch of 2b, same dropout stream (masks are indexed by global sample id)
