@@ -14,7 +14,7 @@ def wall(fn, n=200, warm=50):
     for _ in range(n): fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e6
-libs = [("this", T._lib.get())] + [(os.path.basename(p)[7:-3], T._lib.load_from(p, "hip")) for p in sorted(glob.glob(os.path.join(ROOT, "tc-resnet_amd", "lib", "side", "libtcr_*.so")))]
+libs = [("this", T._lib.get())] + [(os.path.basename(p)[7:-3], T._lib.load_from(p, "hip", allow_missing=True)) for p in sorted(glob.glob(os.path.join(ROOT, "tc-resnet_amd", "lib", "side", "libtcr_*.so")))]
 for tag, win, hop, nco in (("4020", 640, 320, 40), ("3010", 480, 160, 40), ("4020/10", 640, 320, 10)):
     fes = [(n, T.Frontend(window_size_samples=win, window_stride_samples=hop, num_mfccs=nco, lib=l, device=dev)) for n, l in libs]
     ref = fes[0][1](wav).clone()

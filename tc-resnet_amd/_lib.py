@@ -139,11 +139,13 @@ ABI_SYMBOLS = tuple(_PROTOTYPES.keys())
 class Library:
     """A loaded C-ABI library with typed prototypes and status checking."""
 
-    def __init__(self, path: str, kind: str):
+    def __init__(self, path: str, kind: str, allow_missing: bool = False):
         self.path = path
         self.kind = kind            # "hip" (gfx950 product build) or "emu" (tests only)
         self._dll = C.CDLL(path)
         for name, (res, args) in _PROTOTYPES.items():
+            if allow_missing and not hasattr(self._dll, name):      # (side libraries of OLDER revisions: scripts/build_ref_lib.py)
+                continue
             fn = getattr(self._dll, name)       # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
@@ -170,8 +172,8 @@ def get() -> Library:
     return _HIP
 
 
-def load_from(path: str, kind: str = "emu") -> Library:
-    return Library(path, kind)
+def load_from(path: str, kind: str = "emu", allow_missing: bool = False) -> Library:
+    return Library(path, kind, allow_missing)
 
 
 def padded_len(t: int) -> int:

@@ -104,23 +104,27 @@ if (++c4 == C4) { c4 = 0; off = ++j; }                                          
         for (int i = 0; i < R - 1; ++i)
             if (s0 + i < nsteps) TCR_FUSED_STEP(ar[i], )
 #undef TCR_FUSED_STEP
-        // ---- epilogue: folded BN (+ shortcut) (+ ReLU) -> LDS rows of the output buffer ----
+        // ---- epilogue, branch-free (round 3, as in fused_layer_s): lanes past the last position / past Cout store into the pad behind
+        // the buffers, the residual reads use clamped addresses, the halo zeros come from fused_zero_halo_g ----
+        const int dump = a.buf_off[2] + a.group * a.buf_sz[2] + (q * 16 + r) - a.buf_off[L.out_buf];
+        const float lo = L.relu ? 0.f : -3.4e38f;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            if (cp * 32 + nt * 16 + r >= npos) continue;
+            const bool pv = cp * 32 + nt * 16 + r < npos;
             const int g = nt == 0 ? g0 : g1, t = nt == 0 ? t0 : t1;
             const f32x4 ac = nt == 0 ? acc0 : acc1;
+            const int base = g * out_sz + kHalo + t;
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (res) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) rv[reg] = res[g * res_sz + min(m * 16 + q * 4 + reg, L.cout - 1) * tpo + kHalo + t];
+            }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int co = m * 16 + q * 4 + reg;
-                if (co >= L.cout) continue;
                 float v = fmaf(ac[reg], sc[reg], sh[reg]);
-                if (res) v = fmaxf(v + res[g * res_sz + co * tpo + kHalo + t], 0.f);      // tc_resnet.py:40-41
-                else if (L.relu) v = fmaxf(v, 0.f);
-                float* dst = yout + g * out_sz + co * tpo + kHalo + t;
-                dst[0] = v;
-                if (t == 0) { dst[-4] = 0.f; dst[-3] = 0.f; dst[-2] = 0.f; dst[-1] = 0.f; }
-                if (t == L.tout - 1) { dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f; dst[4] = 0.f; }
+                v = res ? fmaxf(v + rv[reg], 0.f) : fmaxf(v, lo);      // tc_resnet.py:40-41
+                yout[(pv && co < L.cout) ? base + co * tpo : dump] = v;
             }
         }
     }
@@ -637,6 +641,151 @@ static int fused_tc8_frames(const FusedArgs& a) {
     return t0;
 }
 
+// Runtime-shape twins of fused_zero_halo / fused_conv0_s / fused_head_s for the generic walk (TCResNet14, other widths).
+template <int NT>
+__device__ __forceinline__ void fused_zero_halo_g(float* yout, const int out_sz, const int ng, const int cout, const int tout, const int tid_in) {
+    const int tpo = tout + 2 * kHalo;
+    const int tid = tid_in + opaque_zero();
+    const float inv = 1.0f / (float)cout;
+    for (int i = tid; i < ng * cout * 2; i += NT) {
+        const int row = i >> 1;
+        const int g = fast_div(row, cout, inv), co = row - g * cout;
+        float* p = yout + g * out_sz + co * tpo + ((i & 1) ? kHalo + tout : 0);
+        p[0] = 0.f; p[1] = 0.f; p[2] = 0.f; p[3] = 0.f;
+    }
+}
+
+// first conv (3 x 1, stride 1, 40 input channels) from global memory with every operand of a job requested up front
+template <int NW>
+__device__ __forceinline__ void fused_conv0_g(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
+                                              float* lds, const int ng, const int wave, const int r_in, const int q_in) {
+    constexpr int K = 3, C4 = 10, PADLO = 1;
+    const int oz = opaque_zero();
+    const int r = r_in + oz, q = q_in + oz;
+    const int cout = L.cout, tout = L.tout, tpi = L.tin + 2 * kHalo, tpo = tout + 2 * kHalo;
+    const int wstep = 4 * cout, xstep = 4 * tpi;
+    float* yout = lds + a.buf_off[L.out_buf];
+    const int out_sz = a.buf_sz[L.out_buf];
+    const int npos = ng * tout;
+    const int nct = (npos + 15) / 16, nrt = (cout + 15) / 16;
+    const float* w = a.params + L.w_off;
+    const float* scale = a.ss + L.ss_off;
+    const float* shift = scale + L.c_pad;
+    const float inv_tout = 1.0f / (float)tout;
+    for (int job = wave; job < nct * nrt; job += NW) {
+        const int ct = job / nrt, m = job - ct * nrt;
+        const int p0 = min(ct * 16 + r, npos - 1);
+        const int g0 = fast_div(p0, tout, inv_tout);
+        const int t0 = p0 - g0 * tout;
+        const float* wp = w + q * cout + min(m * 16 + r, cout - 1);
+        const float* x0 = xin + g0 * in_sz + q * tpi + t0 + kHalo - PADLO;
+        float b0[C4][K], wf[K][C4];
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4)
+#pragma unroll
+            for (int j = 0; j < K; ++j) b0[c4][j] = x0[c4 * xstep + j];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) wf[j][c4] = wp[(j * C4 + c4) * wstep];
+        float sc[4], sh[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int co = min(m * 16 + q * 4 + reg, cout - 1);
+            sc[reg] = scale[co];
+            sh[reg] = shift[co];
+        }
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][c4], b0[c4][j], acc0, 0, 0, 0);
+        const int dump = a.buf_off[2] + a.group * a.buf_sz[2] + (q * 16 + r) - a.buf_off[L.out_buf];
+        const float lo = L.relu ? 0.f : -3.4e38f;
+        const bool pv = ct * 16 + r < npos;
+        const int base = g0 * out_sz + kHalo + t0;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int co = m * 16 + q * 4 + reg;
+            const float v = fmaxf(fmaf(acc0[reg], sc[reg], sh[reg]), lo);
+            yout[(pv && co < cout) ? base + co * tpo : dump] = v;
+        }
+    }
+}
+
+// head with runtime shapes: pool by all threads, fc / fc2 + softmax by one wave on the matrix cores (feat_c % 4 == 0, nc <= 14)
+template <int NT>
+__device__ __forceinline__ void fused_head_g(const FusedArgs& a, float* lds, const int n0, const int ng, const int tid_in) {
+    const int tid = tid_in + opaque_zero();
+    const int fc = a.feat_c, ft = a.feat_t, nc = a.nc;
+    const int tp = ft + 2 * kHalo;
+    const float* fb = lds + a.buf_off[a.feat_buf];
+    const int fsz = a.buf_sz[a.feat_buf];
+    float* pooled = lds + a.buf_off[(a.feat_buf + 1) % 3];
+    const int lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const float inv_fc = 1.0f / (float)fc;
+    for (int i = tid; i < ng * fc; i += NT) {
+        const int g = fast_div(i, fc, inv_fc), c = i - g * fc;
+        const float* row = fb + g * fsz + c * tp + kHalo;
+        float s = 0.f;
+        for (int t = 0; t < ft; ++t) s += row[t];
+        pooled[i] = s / (float)ft;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int g = min(r, ng - 1);
+        const float* wsrc = r < nc ? a.params + a.fc_off + r : a.params + a.fc2_off + min(r - nc, 1);
+        const int wstride = r < nc ? nc : 2;
+        const bool wv = r < nc + 2;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int nst = fc >> 2;
+        for (int s0 = 0; s0 < nst; s0 += 6) {           // six K-steps per trip: their 6 + 6 operand loads in flight together
+            float af[6], bf[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int c = 4 * min(s0 + i, nst - 1) + q;
+                af[i] = wsrc[c * wstride];
+                bf[i] = pooled[g * fc + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (s0 + i < nst) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv ? af[i] : 0.f, bf[i], acc, 0, 0, 0);
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) if (4 * q + reg < nc) mx = fmaxf(mx, acc[reg]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float e[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) e[reg] = expf(acc[reg] - mx);
+        float se = 0.f;
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {             // class sum carried through the 16-lane rows in class order
+            const float prev = __shfl(se, (row > 0 ? (row - 1) * 16 : 0) + r);
+            float cur = row > 0 ? prev : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) if (4 * row + reg < nc) cur += e[reg];
+            if (q == row) se = cur;
+        }
+        se = __shfl(se, 48 + r);
+        if (r < ng) {
+            const size_t n = (size_t)(n0 + r);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int o = 4 * q + reg;
+                if (o < nc) {
+                    a.logits[n * nc + o] = acc[reg];
+                    a.probs[n * nc + o] = e[reg] / se;
+                } else if (o < nc + 2 && a.ranges) {
+                    a.ranges[n * 2 + (o - nc)] = 1.0f / (1.0f + expf(-acc[reg]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 template <int NW, int R>
 __global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
     constexpr int NT = NW * 64;
@@ -661,12 +810,18 @@ __global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
 
         for (int li = 0; li < a.n_layers; ++li) {
             const FusedLayer L = a.layer[li];
-            if (li == 0 && a.in_global) fused_layer<NW, R>(a, L, a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
-            else fused_layer<NW, R>(a, L, lds + a.buf_off[L.in_buf], a.buf_sz[L.in_buf], lds, ng, wave, r, q);
+            fused_zero_halo_g<NT>(lds + a.buf_off[L.out_buf], a.buf_sz[L.out_buf], ng, L.cout, L.tout, tid);
+            if (li == 0 && a.in_global) {
+                if (L.k == 3 && L.cin == 40 && L.stride == 1 && L.pad_lo == 1) fused_conv0_g<NW>(a, L, a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
+                else fused_layer<NW, R>(a, L, a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
+            } else {
+                fused_layer<NW, R>(a, L, lds + a.buf_off[L.in_buf], a.buf_sz[L.in_buf], lds, ng, wave, r, q);
+            }
             if (!L.no_barrier) __syncthreads();         // (a block's shortcut conv and its first conv read the same input: one phase)
         }
 
-        fused_head<NT>(a, lds, n0, ng, tid);
+        if ((a.feat_c & 3) == 0 && a.nc + 2 <= 16) fused_head_g<NT>(a, lds, n0, ng, tid);
+        else fused_head<NT>(a, lds, n0, ng, tid);
     }
 }
 
