@@ -561,12 +561,14 @@ __device__ __forceinline__ void fused_head(const FusedArgs& a, float* lds, const
 #else
 #define TCR_WAVES_PER_SIMD_4 __attribute__((amdgpu_waves_per_eu(4, 4)))     // two 8-wave workgroups per CU: <= 128 VGPRs
 #endif
-template <int NW, int K, int S, int CIN, int COUT, int TIN, int WD, bool HAS_RES>     // WD < 0: the round-2 layer (A/B arm, TCR_TUNE_NET_FUSED = 4)
+// WD < 0: the round-2 layer (A/B arm, TCR_TUNE_NET_FUSED = 4).  HALO: some consumer convolves this layer's rows (K > 1) and so reads
+// their zero halo; the shortcut convs' outputs (only ever a residual term) and the last block output (only pooled) skip the zero pass.
+template <int NW, int K, int S, int CIN, int COUT, int TIN, int WD, bool HAS_RES, bool HALO = true>
 __device__ __forceinline__ void fused_layer_sel(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
                                                 float* lds, const int ng, const int wave, const int r, const int q) {
     if constexpr (WD < 0) fused_layer_t<NW, K, S, CIN, COUT, TIN>(a, L, xin, in_sz, lds, ng, wave, r, q);
     else {
-        fused_zero_halo<NW * 64, COUT, (TIN + S - 1) / S>(lds + a.buf_off[L.out_buf], a.buf_sz[L.out_buf], ng, (int)threadIdx.x);
+        if constexpr (HALO) fused_zero_halo<NW * 64, COUT, (TIN + S - 1) / S>(lds + a.buf_off[L.out_buf], a.buf_sz[L.out_buf], ng, (int)threadIdx.x);
         fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES>(a, L, xin, in_sz, lds, ng, wave, r, q);
     }
 }
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
 #else
 #define TCR_TC8_BARRIER __syncthreads()
 #endif
-#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.buf_sz[a.layer[LI].in_buf], lds, ng, wave, r, q)
+#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9), (K_ != 1 && LI != 9)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.buf_sz[a.layer[LI].in_buf], lds, ng, wave, r, q)
     for (int grp = blockIdx.x; grp < (TCR_WHATIF(512) ? 0 : a.n_groups); grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
