@@ -287,6 +287,11 @@ int tcr_g2d_batch_norm(tcr_g2d* g, int in, int center, int scale, int relu, floa
 int tcr_g2d_pool(tcr_g2d* g, int in, int is_max, int kh, int kw, int sh, int sw, int valid_padding);
 int tcr_g2d_add(tcr_g2d* g, int a, int b, int relu);                 /* net += layer_in [; relu] */
 int tcr_g2d_dropout(tcr_g2d* g, int in, float keep_prob);            /* tf.nn.dropout / slim.dropout; identity in eval mode */
+/* SVDF layer of KWSModel --architecture low_latency_svdf (audio_nets/kws.py:490-680, training graph): after the frequency filters (a
+ * 1 x F VALID conv) `time_filter` applies one filter of the plane's length per channel (tf.matmul with weights_time [filters, T], :604-612),
+ * `group_sum` adds the `rank` filters of a unit, the bias and the ReLU (:613-628). */
+int tcr_g2d_time_filter(tcr_g2d* g, int in, const char* weights_name);
+int tcr_g2d_group_sum(tcr_g2d* g, int in, int group, int relu, const char* biases_name);
 int tcr_g2d_node_shape(const tcr_g2d* g, int node, int* c, int* h, int* w);
 /* A node's activation inside the workspace of a forward call at (batch, train): [batch][C][plane_floats], the H*W values of a
  * plane start `halo` floats in.  What the reference exposes as `endpoints` (audio_nets/res.py:66, tc_resnet.py:95). */

@@ -216,6 +216,16 @@ def kws_forward(params, x, architecture, is_training=False, masks=None):
     elif architecture == "tiny_conv":
         h = d(_relu(conv2d(x4, p["first_weights"], stride=(2, 2), padding="SAME", bias=p["first_bias"])))
         logits = _flat(h) @ p["final_fc_weights"].reshape(-1, p["final_fc_weights"].shape[-1]) + p["final_fc_bias"]
+    elif architecture == "low_latency_svdf":                                      # kws.py:490-680, training graph (all frames, no runtime memory)
+        rank = 2
+        wf = p["weights_frequency"].reshape(x.shape[2], -1)                       # [F, filters]
+        act = torch.einsum("btf,fk->kbt", x, wf)                                  # conv1d over time, transposed to [filters, B, T] (:586-600)
+        out = torch.einsum("kbt,kt->kb", act, p["weights_time"].reshape(act.shape[0], -1))     # tf.matmul(activations_time, weights_time) (:604-612)
+        units = out.reshape(-1, rank, x.shape[0]).sum(dim=1).t()                  # [B, units] (:613-621)
+        h = d(_relu(units + p["bias"]))
+        h = d(h @ p["first_fc_weights"].reshape(-1, 256) + p["first_fc_bias"])
+        h = d(h @ p["second_fc_weights"].reshape(256, 256) + p["second_fc_bias"])
+        logits = h @ p["final_fc_weights"].reshape(256, -1) + p["final_fc_bias"]
     else:
         raise ValueError(architecture)
     return {"logits": logits, "probs": F.softmax(logits, dim=-1), "new_stats": {}}

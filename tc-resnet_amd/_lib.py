@@ -109,6 +109,8 @@ _PROTOTYPES = {
     "tcr_g2d_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tcr_g2d_add": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "tcr_g2d_dropout": (C.c_int, [_P, C.c_int, C.c_float]),
+    "tcr_g2d_time_filter": (C.c_int, [_P, C.c_int, C.c_char_p]),
+    "tcr_g2d_group_sum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_char_p]),
     "tcr_g2d_node_shape": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tcr_g2d_node_output": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "tcr_g2d_finalize": (C.c_int, [_P, C.c_int]),

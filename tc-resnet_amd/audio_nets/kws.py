@@ -6,9 +6,14 @@ variable names (first_weights, first_bias, second_weights, ..., final_fc_weights
 A TF `reshape(x, [-1, H*W*C]) @ W[H*W*C, N]` is the VALID convolution of the [H, W, C] activation with W viewed as
 [H, W, C, N] -- the flatten order of NHWC and the HWIO weight layout coincide -- so every matmul is a conv node.
 
-`low_latency_svdf` is not built: its graph keeps a [num_filters, batch = 1, time] runtime-memory variable and only runs at
-batch 1 (kws.py:490-680; `runtime_settings` is None at :576, so the reference cannot build it for evaluation); none of the reference's scripts uses it."""
+`low_latency_svdf` (kws.py:490-680) is built as the reference's TRAINING graph computes it -- every frame of the window, no runtime memory --:
+frequency filters = a 1 x F VALID conv, `Graph2D.time_filter` = the per-filter time filters, `Graph2D.group_sum` = rank sum + bias + ReLU, three
+fully-connected layers.  The reference's evaluation branch streams through a batch-1 `runtime-memory` variable and cannot even be built there
+(`runtime_settings` is None at :576); here evaluation runs the same all-frames graph without dropout, and `runtime-memory` is carried as a
+constant zero variable so that checkpoints hold every global variable of the reference graph."""
 from __future__ import annotations
+
+import numpy as np
 
 import math
 
@@ -60,8 +65,18 @@ def build_model(g: Graph2D, model_settings, model_architecture: str) -> int:
     if model_architecture == "tiny_conv":                                 # :681-757
         net = drop(g.conv(-1, (10, 8), 8, "first_weights", stride=(2, 2), padding="SAME", relu=True, biases_name="first_bias", init=TN))
         return _fc(g, net, nc, "final_fc_weights", True)
-    if model_architecture == "low_latency_svdf":
-        raise NotImplementedError("low_latency_svdf keeps a batch-1 runtime-memory variable (kws.py:490-680; `runtime_settings` is None at :576, so the reference cannot build it for evaluation) and is not built")
+    if model_architecture == "low_latency_svdf":                          # :490-680, the training graph (every frame, no runtime memory)
+        rank, num_units = 2, 1280
+        nf = rank * num_units
+        # frequency filters: tf.nn.conv1d over [B, T * F, 1] with stride F == a 1 x F VALID conv of the [T x F] plane (:586-596)
+        net = g.conv(-1, (1, f), nf, "weights_frequency", padding="VALID", init=TN, tf_shape=(f, nf))
+        net = g.time_filter(net, "weights_time", init=TN)                 # [filters, T] time filters (:604-612)
+        net = drop(g.group_sum(net, rank, relu=True, biases_name="bias"))  # rank sum + bias + relu (+ dropout) (:613-634)
+        net = drop(_fc(g, net, 256, "first_fc_weights", True))
+        net = drop(_fc(g, net, 256, "second_fc_weights", True))
+        # `runtime-memory` [filters, 1, T]: the streaming-inference state (trainable=False, zeros; only the deploy-time branch writes it)
+        g.constants["runtime-memory"] = np.zeros((nf, 1, t), np.float32)
+        return _fc(g, net, nc, "final_fc_weights", True)
     raise Exception('model_architecture argument "' + model_architecture + '" not recognized, should be one of "single_fc", "conv",'
                     ' "low_latency_conv, "one_fstride4", "trad_fpool3", "low_latency_svdf" or "tiny_conv"')
 

@@ -627,6 +627,76 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
 #undef TCR_TC8_BARRIER
 }
 
+// TCResNet14-1.5 (channels 24 / 36 / 36 / 48 / 48 / 72 / 72; BASELINE.json configs[3]'s network) with compile-time layer shapes, T0 = 49 or 98
+// frames: the same static layer (`fused_layer_s`), first conv (`fused_conv0_g`: 24 output channels = two row tiles) and head as the
+// TCResNet8 instance.  Blocks 1 / 3 / 5 have identity shortcuts: their second conv adds the block input, which lives in its own output
+// buffer (each lane reads the residual of exactly the elements it then writes).
+template <int NW, int T0>
+__global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc14w_kernel(const FusedArgs a) {
+    constexpr int NT = NW * 64;
+    constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2, T3 = (T2 + 1) / 2;
+    float* lds = reinterpret_cast<float*>(dyn_lds());
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int row = a.in_c * a.in_tp;
+#define TCR_L(LI, K_, S_, CI_, CO_, T_, RES_, HALO_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, 0, RES_, HALO_>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.buf_sz[a.layer[LI].in_buf], lds, ng, wave, r, q)
+    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+        const int n0 = grp * a.group;
+        const int ng = min(a.group, a.batch - n0);
+        fused_zero_halo<NT, 24, T0>(lds + a.buf_off[a.layer[0].out_buf], a.buf_sz[a.layer[0].out_buf], ng, tid);
+        fused_conv0_g<NW>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
+        __syncthreads();
+        TCR_L(1, 1, 2, 24, 36, T0, false, false);       // block0: shortcut conv + first conv (same input rows: one phase)
+        TCR_L(2, 9, 2, 24, 36, T0, false, true);
+        __syncthreads();
+        TCR_L(3, 9, 1, 36, 36, T1, true, true);
+        __syncthreads();
+        TCR_L(4, 9, 1, 36, 36, T1, false, true);        // block1 (identity shortcut)
+        __syncthreads();
+        TCR_L(5, 9, 1, 36, 36, T1, true, true);
+        __syncthreads();
+        TCR_L(6, 1, 2, 36, 48, T1, false, false);       // block2
+        TCR_L(7, 9, 2, 36, 48, T1, false, true);
+        __syncthreads();
+        TCR_L(8, 9, 1, 48, 48, T2, true, true);
+        __syncthreads();
+        TCR_L(9, 9, 1, 48, 48, T2, false, true);        // block3 (identity)
+        __syncthreads();
+        TCR_L(10, 9, 1, 48, 48, T2, true, true);
+        __syncthreads();
+        TCR_L(11, 1, 2, 48, 72, T2, false, false);      // block4
+        TCR_L(12, 9, 2, 48, 72, T2, false, true);
+        __syncthreads();
+        TCR_L(13, 9, 1, 72, 72, T3, true, true);
+        __syncthreads();
+        TCR_L(14, 9, 1, 72, 72, T3, false, true);       // block5 (identity)
+        __syncthreads();
+        TCR_L(15, 9, 1, 72, 72, T3, true, false);
+        __syncthreads();
+        if (a.nc == 12) fused_head_s<NT, 72, T3, 12>(a, lds, n0, ng, tid);
+        else fused_head<NT>(a, lds, n0, ng, tid);
+    }
+#undef TCR_L
+}
+
+// 49 / 98 when the plan is exactly TCResNet14-1.5 on 40 coefficients read from global memory, else 0
+static int fused_tc14w_frames(const FusedArgs& a) {
+    static const int shape[16][4] = {{3, 1, 40, 24}, {1, 2, 24, 36}, {9, 2, 24, 36}, {9, 1, 36, 36}, {9, 1, 36, 36}, {9, 1, 36, 36}, {1, 2, 36, 48}, {9, 2, 36, 48},
+                                     {9, 1, 48, 48}, {9, 1, 48, 48}, {9, 1, 48, 48}, {1, 2, 48, 72}, {9, 2, 48, 72}, {9, 1, 72, 72}, {9, 1, 72, 72}, {9, 1, 72, 72}};
+    if (a.n_layers != 16 || !a.in_global || a.in_c != 40) return 0;
+    const int t0 = a.layer[0].tin;
+    if (t0 != 49 && t0 != 98) return 0;
+    int t = t0;
+    for (int i = 0; i < 16; ++i) {
+        const FusedLayer& L = a.layer[i];
+        if (L.k != shape[i][0] || L.stride != shape[i][1] || L.cin != shape[i][2] || L.cout != shape[i][3] || L.tin != t) return 0;
+        if (i == 2 || i == 7 || i == 12) t = (t + 1) / 2;
+    }
+    return t0;
+}
+
 // 49 / 98 when the plan is exactly TCResNet8-1.0 on 40 coefficients read from global memory, else 0
 static int fused_tc8_frames(const FusedArgs& a) {
     static const int shape[10][4] = {{3, 1, 40, 16}, {1, 2, 16, 24}, {9, 2, 16, 24}, {9, 1, 24, 24}, {1, 2, 24, 32},
@@ -835,6 +905,10 @@ int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, 
 #define TCR_FS(NW_, T_) if (tc8 == T_ && waves == NW_) kern = r2 ? net_fused_tc8_kernel<NW_, T_, -1> : net_fused_tc8_kernel<NW_, T_, 0>;
     TCR_FS(4, 49) TCR_FS(8, 49) TCR_FS(16, 49) TCR_FS(4, 98) TCR_FS(8, 98) TCR_FS(16, 98)
 #undef TCR_FS
+    const int tc14 = (kern || tune_get(TCR_TUNE_NET_FUSED) == 3 || tune_get(TCR_TUNE_NET_FUSED) == 4) ? 0 : fused_tc14w_frames(a);
+#define TCR_F14(NW_, T_) if (tc14 == T_ && waves == NW_) kern = net_fused_tc14w_kernel<NW_, T_>;
+    TCR_F14(8, 49) TCR_F14(16, 49) TCR_F14(8, 98) TCR_F14(16, 98)
+#undef TCR_F14
     if (kern) ring = 0;
 #define TCR_FK(NW_, R_) if (!kern && waves == NW_ && ring == R_) kern = net_fused_kernel<NW_, R_>;
     TCR_FK(4, 4) TCR_FK(4, 8) TCR_FK(4, 16) TCR_FK(8, 4) TCR_FK(8, 8) TCR_FK(8, 16) TCR_FK(16, 4) TCR_FK(16, 8) TCR_FK(16, 16)

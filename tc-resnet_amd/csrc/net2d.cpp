@@ -12,7 +12,7 @@
 #include "net2d.h"
 
 namespace tcr {
-enum { G2D_CONV = 0, G2D_BN = 1, G2D_POOL = 2, G2D_ADD = 3, G2D_DROPOUT = 4 };
+enum { G2D_CONV = 0, G2D_BN = 1, G2D_POOL = 2, G2D_ADD = 3, G2D_DROPOUT = 4, G2D_TFILT = 5, G2D_GSUM = 6 };
 
 struct G2dNode {
     int kind = 0, in0 = -1, in1 = -1;       // inputs: node ids, -1 = the network input
@@ -31,6 +31,8 @@ struct G2dNode {
     bool is_max = false;
     // dropout
     float keep = 1.0f;
+    // group sum
+    int group = 1;
 };
 
 static int64_t al64(int64_t v) { return (v + 63) / 64 * 64; }
@@ -214,6 +216,32 @@ extern "C" int tcr_g2d_dropout(tcr_g2d* g, int in, float keep_prob) {
     return (int)g->nodes.size() - 1;
 }
 
+// SVDF (audio_nets/kws.py:490-680): per-channel filter over the whole input plane -> [C, 1, 1]; variable `weights_name` [C, plane]
+extern "C" int tcr_g2d_time_filter(tcr_g2d* g, int in, const char* weights_name) {
+    G2D_CHECK_IN(g, in, "tcr_g2d_time_filter");
+    TCR_REQUIRE(weights_name && weights_name[0], "tcr_g2d_time_filter: the variable needs a name");
+    G2dNode n;
+    int c, h, w;
+    shape_of(*g, in, &c, &h, &w);
+    n.kind = G2D_TFILT; n.in0 = in; n.c = c; n.h = 1; n.w = 1; n.cin = h * w; n.w_name = weights_name;
+    g->nodes.push_back(n);
+    return (int)g->nodes.size() - 1;
+}
+
+// sum of `group` consecutive channels (+ bias) (+ ReLU) of a 1 x 1 node -> [C / group, 1, 1]
+extern "C" int tcr_g2d_group_sum(tcr_g2d* g, int in, int group, int relu, const char* biases_name) {
+    G2D_CHECK_IN(g, in, "tcr_g2d_group_sum");
+    int c, h, w;
+    shape_of(*g, in, &c, &h, &w);
+    TCR_REQUIRE(h == 1 && w == 1 && group >= 1 && c % group == 0, "tcr_g2d_group_sum: needs a 1 x 1 input whose %d channels divide by the group %d", c, group);
+    G2dNode n;
+    n.kind = G2D_GSUM; n.in0 = in; n.c = c / group; n.h = 1; n.w = 1; n.group = group; n.relu = relu != 0;
+    n.bias = biases_name && biases_name[0];
+    if (n.bias) n.b_name = biases_name;
+    g->nodes.push_back(n);
+    return (int)g->nodes.size() - 1;
+}
+
 extern "C" int tcr_g2d_node_shape(const tcr_g2d* g, int node, int* c, int* h, int* w) {
     TCR_REQUIRE(g && c && h && w && node >= -1 && node < (int)g->nodes.size(), "tcr_g2d_node_shape: bad argument");
     shape_of(*g, node, c, h, w);
@@ -247,6 +275,17 @@ extern "C" int tcr_g2d_finalize(tcr_g2d* g, int logits_node) {
                 n.w_off = o;
                 info(n.w_name, TCR_WEIGHT, 0, o, sz, {n.kh, n.kw, n.cin, n.c});
                 o = al64(o + sz + 64);
+                if (n.bias) {
+                    n.b_off = o;
+                    info(n.b_name, TCR_BETA, 0, o, n.c, {n.c});
+                    o = al64(o + n.c + 64);
+                }
+            } else if (n.kind == G2D_TFILT && pass == 0) {
+                const int64_t sz = (int64_t)n.c * n.cin;
+                n.w_off = o;
+                info(n.w_name, TCR_WEIGHT, 0, o, sz, {n.c, n.cin});
+                o = al64(o + sz + 64);
+            } else if (n.kind == G2D_GSUM && pass == 0) {
                 if (n.bias) {
                     n.b_off = o;
                     info(n.b_name, TCR_BETA, 0, o, n.c, {n.c});
@@ -387,6 +426,14 @@ static int g2d_forward(const tcr_g2d* g, const float* params, float* stats, cons
                 TCR_TRY(launch_eltwise2d(0, a, s));
                 break;
             }
+            case G2D_TFILT: {
+                TCR_TRY(launch_tfilt_fwd(in0, params + n.w_off, out, batch, n.c, n.cin, s));
+                break;
+            }
+            case G2D_GSUM: {
+                TCR_TRY(launch_gsum_fwd(in0, n.bias ? params + n.b_off : nullptr, out, batch, n.c, n.group, n.relu ? 1 : 0, s));
+                break;
+            }
             case G2D_DROPOUT: {
                 if (!train) break;              // identity: consumers read the input (in_ptr)
                 Elt2dArgs a;
@@ -518,6 +565,16 @@ extern "C" int tcr_g2d_backward(const tcr_g2d* g, const float* params, const flo
                 if (n.relu) TCR_TRY(relu_mask());
                 TCR_TRY(fan_out(base + w.grad[n.in0]));
                 TCR_TRY(fan_out(base + w.grad[n.in1]));
+                break;
+            }
+            case G2D_TFILT: {
+                TCR_TRY(launch_tfilt_bwd(G, in0, params + n.w_off, gin0, grads + n.w_off, batch, n.c, n.cin, s));
+                break;
+            }
+            case G2D_GSUM: {
+                if (n.relu) TCR_TRY(relu_mask());
+                if (n.bias) TCR_TRY(launch_chan_sum2d(G, grads + n.b_off, batch, n.c, 1, pp, s));
+                if (gin0) TCR_TRY(launch_gsum_dx(G, gin0, batch, n.c, n.group, s));
                 break;
             }
             case G2D_DROPOUT: {

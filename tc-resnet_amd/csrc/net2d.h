@@ -50,6 +50,10 @@ int launch_pool2d_bwd(const Pool2dArgs& a, hipStream_t s);
 int launch_eltwise2d(int mode, const Elt2dArgs& a, hipStream_t s);
 int launch_head2d(const float* z, const float* labels, float* logits, float* probs, float* dz, float* loss_utt, int batch, int nc, int pp,
                   float inv_global_batch, float label_smoothing, hipStream_t s);
+int launch_tfilt_fwd(const float* x, const float* w, float* y, int batch, int c, int plane, hipStream_t s);
+int launch_tfilt_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, int batch, int c, int plane, hipStream_t s);
+int launch_gsum_fwd(const float* x, const float* bias, float* y, int batch, int units, int group, int relu, hipStream_t s);
+int launch_gsum_dx(const float* dy, float* dx, int batch, int units, int group, hipStream_t s);
 int launch_features_to_plane(const float* feat, float* out, int batch, int t, int f, hipStream_t s);
 
 }  // namespace tcr

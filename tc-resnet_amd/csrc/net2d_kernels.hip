@@ -350,6 +350,83 @@ int launch_eltwise2d(int mode, const Elt2dArgs& a, hipStream_t s) {
     return check_launch("eltwise2d_kernel");
 }
 
+// ---- SVDF pieces (audio_nets/kws.py:490-680): per-channel time filter over the whole plane, rank-group sum --------------------------------
+// time filter: y[b][c] = sum_p x[b][c][p] * w[c][p]  (tf.matmul(activations_time [F, B, T], weights_time [F, T, 1]), kws.py:604-612)
+__global__ __launch_bounds__(256) void tfilt_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                        int64_t rows, int c, int plane, int ppi, int ppo) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        const float* xr = x + i * ppi + kHalo;
+        const float* wr = w + (size_t)ch * plane;
+        float s = 0.f;
+        for (int p = 0; p < plane; ++p) s = fmaf(xr[p], wr[p], s);
+        y[i * ppo + kHalo] = s;
+    }
+}
+// dx[b][c][p] += dy[b][c] * w[c][p]
+__global__ __launch_bounds__(256) void tfilt_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                       int64_t rows, int c, int plane, int ppi, int ppo) {
+    const int64_t total = rows * plane;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / plane;
+        const int p = (int)(i - r * plane);
+        dx[r * ppi + kHalo + p] += dy[r * ppo + kHalo] * w[(size_t)(r % c) * plane + p];
+    }
+}
+// dw[c][p] = sum_b dy[b][c] * x[b][c][p]  (fixed order over the batch: reproducible)
+__global__ __launch_bounds__(256) void tfilt_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                       int batch, int c, int plane, int ppi, int ppo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c * plane) return;
+    const int ch = i / plane, p = i - ch * plane;
+    float s = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        const int64_t r = (int64_t)b * c + ch;
+        s = fmaf(dy[r * ppo + kHalo], x[r * ppi + kHalo + p], s);
+    }
+    dw[i] = s;
+}
+// group sum: y[b][u] = [relu](sum_r x[b][u * g + r] + bias[u])  (reshape [units, rank, batch] + reduce_sum + bias_add + relu, kws.py:613-628)
+__global__ __launch_bounds__(256) void gsum_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y,
+                                                       int64_t rows, int units, int group, int pp, int relu) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / units;
+        const int u = (int)(i - b * units);
+        const float* xr = x + ((int64_t)b * units * group + (int64_t)u * group) * pp + kHalo;
+        float s = 0.f;
+        for (int r = 0; r < group; ++r) s += xr[(size_t)r * pp];
+        if (bias) s += bias[u];
+        y[i * pp + kHalo] = relu ? fmaxf(s, 0.f) : s;
+    }
+}
+// dx[b][u * g + r] += dy[b][u]
+__global__ __launch_bounds__(256) void gsum_dx_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t rows_in, int group, int pp) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows_in; i += (int64_t)gridDim.x * 256)
+        dx[i * pp + kHalo] += dy[(i / group) * pp + kHalo];
+}
+
+int launch_tfilt_fwd(const float* x, const float* w, float* y, int batch, int c, int plane, hipStream_t s) {
+    hipLaunchKernelGGL(tfilt_fwd_kernel, dim3(grid1d((int64_t)batch * c)), dim3(256), 0, s, x, w, y, (int64_t)batch * c, c, plane,
+                       plane + 2 * kHalo, 1 + 2 * kHalo);
+    return check_launch("tfilt_fwd_kernel");
+}
+int launch_tfilt_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, int batch, int c, int plane, hipStream_t s) {
+    if (dx) hipLaunchKernelGGL(tfilt_dx_kernel, dim3(grid1d((int64_t)batch * c * plane)), dim3(256), 0, s, dy, w, dx, (int64_t)batch * c, c, plane,
+                               plane + 2 * kHalo, 1 + 2 * kHalo);
+    hipLaunchKernelGGL(tfilt_dw_kernel, dim3(ceil_div(c * plane, 256)), dim3(256), 0, s, dy, x, dw, batch, c, plane, plane + 2 * kHalo, 1 + 2 * kHalo);
+    return check_launch("tfilt_bwd_kernel");
+}
+int launch_gsum_fwd(const float* x, const float* bias, float* y, int batch, int units, int group, int relu, hipStream_t s) {
+    hipLaunchKernelGGL(gsum_fwd_kernel, dim3(grid1d((int64_t)batch * units)), dim3(256), 0, s, x, bias, y, (int64_t)batch * units, units, group,
+                       1 + 2 * kHalo, relu);
+    return check_launch("gsum_fwd_kernel");
+}
+int launch_gsum_dx(const float* dy, float* dx, int batch, int units, int group, hipStream_t s) {
+    hipLaunchKernelGGL(gsum_dx_kernel, dim3(grid1d((int64_t)batch * units * group)), dim3(256), 0, s, dy, dx, (int64_t)batch * units * group, group,
+                       1 + 2 * kHalo);
+    return check_launch("gsum_dx_kernel");
+}
+
 // ---- head: logits rows -> softmax / cross-entropy / dlogits -----------------------------------------------------------------
 // z [B][NC][pp] with one interior element per row (the logits node is 1 x 1 spatially).
 __global__ __launch_bounds__(64) void head2d_kernel(const float* __restrict__ z, const float* __restrict__ labels, float* __restrict__ logits,

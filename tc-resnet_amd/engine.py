@@ -175,7 +175,8 @@ class TCResNet(_Base):
             self.tensors[ti.name.decode()] = ti
         self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
         self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.n_param + DP_TAIL, dtype=torch.float32, device=self.device)     # (+ the data-parallel tail: parallel.py)
+        self._grads_buf = torch.zeros(self.n_param + DP_TAIL, dtype=torch.float32, device=self.device)     # arena + the data-parallel tail (parallel.py)
+        self.grads = self._grads_buf[:self.n_param]
         self.slots: Dict[str, torch.Tensor] = {}      # optimiser slots (arena-shaped)
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self._kver, self._fold_key, self._fold_ss, self._fold_event, self._fold_stream, self._fold_readers = 0, None, None, None, None, {}
@@ -518,7 +519,8 @@ class DSCNN(_Base):
             self.tensors[ti.name.decode()] = ti
         self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
         self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.n_param + DP_TAIL, dtype=torch.float32, device=self.device)     # (+ the data-parallel tail: parallel.py)
+        self._grads_buf = torch.zeros(self.n_param + DP_TAIL, dtype=torch.float32, device=self.device)     # arena + the data-parallel tail (parallel.py)
+        self.grads = self._grads_buf[:self.n_param]
         self.slots: Dict[str, torch.Tensor] = {}
         self._ws: Dict[int, torch.Tensor] = {}
         self._train_ws: Dict[int, torch.Tensor] = {}
@@ -672,6 +674,7 @@ class Graph2D(_Base):
         self.initializers: Dict[str, object] = {}           # variable name -> "xavier" | ("truncated_normal", stddev) | "zeros"
         self.relu_nodes: List[int] = []                      # nodes whose output went through a ReLU, in build order
         self.dropout_nodes: List[int] = []                  # node ids of the dropout layers (each mask is keyed by its node id)
+        self.constants: Dict[str, np.ndarray] = {}          # non-trainable variables of the reference graph that stay constant (checkpoint completeness)
         self.tf_shapes: Dict[str, Tuple[int, ...]] = {}      # variables whose TF shape differs from the kernel's [kh, kw, cin, cout] (matmul weights: [K, N])
         self.finalized = False
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -710,6 +713,18 @@ class Graph2D(_Base):
                    eps: float = 0.001) -> int:
         return self._relu(relu, self._node(self.lib.tcr_g2d_batch_norm(self._h, inp, int(center), int(scale), int(relu), float(decay),
                                                                        float(eps), prefix.encode()), "tcr_g2d_batch_norm"))
+
+    def time_filter(self, inp: int, weights_name: str, init="xavier") -> int:
+        """One filter of the plane's length per channel -> [C, 1, 1] (SVDF time filters, kws.py:604-612); variable [C, plane]."""
+        self.initializers[weights_name] = init
+        return self._node(self.lib.tcr_g2d_time_filter(self._h, inp, weights_name.encode()), "tcr_g2d_time_filter")
+
+    def group_sum(self, inp: int, group: int, relu: bool = False, biases_name: Optional[str] = None) -> int:
+        """Sum of `group` consecutive channels of a 1 x 1 node (+ bias) (+ ReLU) (SVDF rank sum, kws.py:613-628)."""
+        if biases_name:
+            self.initializers[biases_name] = "zeros"
+        return self._relu(relu, self._node(self.lib.tcr_g2d_group_sum(self._h, inp, int(group), int(relu), (biases_name or "").encode()),
+                                           "tcr_g2d_group_sum"))
 
     def pool(self, inp: int, kind: str, kernel=None, stride=(1, 1), padding: str = "VALID") -> int:
         kh, kw = (0, 0) if kernel is None else ((kernel, kernel) if isinstance(kernel, int) else kernel)
@@ -757,7 +772,8 @@ class Graph2D(_Base):
             self.tensors[ti.name.decode()] = ti
         self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
         self.stats = torch.zeros(self.n_stat, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.n_param + DP_TAIL, dtype=torch.float32, device=self.device)     # (+ the data-parallel tail: parallel.py)
+        self._grads_buf = torch.zeros(self.n_param + DP_TAIL, dtype=torch.float32, device=self.device)     # arena + the data-parallel tail (parallel.py)
+        self.grads = self._grads_buf[:self.n_param]
         self.init_variables(0)
 
     # ---- variables ---------------------------------------------------------------------------------------------------
@@ -776,7 +792,9 @@ class Graph2D(_Base):
 
     def state_dict(self) -> Dict[str, np.ndarray]:
         """TF variable name -> array in the shape the reference's graph declares (matmul weights [K, N], not [h, w, c, N])."""
-        return {n: self._view(n).detach().cpu().numpy().copy().reshape(self.tf_shape(n)) for n in self.tensors}
+        sd = {n: self._view(n).detach().cpu().numpy().copy().reshape(self.tf_shape(n)) for n in self.tensors}
+        sd.update({n: v.copy() for n, v in getattr(self, "constants", {}).items()})     # non-trainable graph variables that never change here
+        return sd
 
     def load_state_dict(self, sd: Dict[str, np.ndarray], strict: bool = True):
         for n, ti in self.tensors.items():
@@ -799,7 +817,7 @@ class Graph2D(_Base):
             if ti.kind == 0:
                 init = self.initializers.get(n, "xavier")
                 if init == "xavier":
-                    kh, kw, cin, cout = shape
+                    kh, kw, cin, cout = shape if len(shape) == 4 else (1, 1) + tuple(shape)
                     lim = math.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
                     w = (torch.rand(shape, generator=gen, dtype=torch.float32) * 2.0 - 1.0) * lim
                 else:                       # ("truncated_normal", stddev): redraw beyond two standard deviations

@@ -343,7 +343,7 @@ class GoogleKWS:
 
 
 class KWSModel(_GraphModel):
-    """factory/audio_nets.py:205-225 -> audio_nets/kws.py; `--architecture` as in the reference (low_latency_svdf is refused)."""
+    """factory/audio_nets.py:205-225 -> audio_nets/kws.py; `--architecture` as in the reference (all seven)."""
 
     def __init__(self, args, dataset=None):
         super().__init__(args, dataset)

@@ -57,14 +57,16 @@ class DataParallel:
         """Local backward, then ONE all-reduce of the gradient arena; the replica's loss sum rides in the arena's tail
         (engine.DP_TAIL), so that logging the global mean loss costs no second collective."""
         g = self.net.backward()
-        n = int(self.net.n_param)
-        has_tail = self.enabled and self._loss is not None and g.numel() > n
+        buf = getattr(self.net, "_grads_buf", None)           # the arena followed by engine.DP_TAIL floats
+        n = g.numel()
+        has_tail = self.enabled and self._loss is not None and buf is not None and buf.numel() > n and buf.data_ptr() == g.data_ptr()
         if has_tail:
-            g[n:n + 1].copy_(self._loss.detach().reshape(1))
-        self._sum(g)
-        if has_tail:
-            self._loss_reduced = (self._loss, g[n].clone())
-            g[n:n + 1].zero_()              # (the arena reads the same as a single-process one)
+            buf[n:n + 1].copy_(self._loss.detach().reshape(1))
+            self._sum(buf[:n + 1])
+            self._loss_reduced = (self._loss, buf[n].clone())
+            buf[n:n + 1].zero_()
+        else:
+            self._sum(g)
         return g
 
     def mean_loss(self, loss_sum: torch.Tensor, local_batch: int) -> torch.Tensor:

@@ -30,7 +30,7 @@ def rt(request):
 def _randomise(eng, seed):
     """Non-trivial values for every variable (biases, BN gamma / beta / moving statistics included)."""
     rng = np.random.RandomState(seed)
-    sd = eng.state_dict()
+    sd = {k: v for k, v in eng.state_dict().items() if k in eng.tensors}       # (not the constants of the reference graph, e.g. SVDF's runtime-memory)
     for k, v in sd.items():
         ti = eng.tensors[k]
         if ti.kind == 0:
@@ -135,7 +135,7 @@ def test_resnet2d8(rt, pool):
            masks_of=masks_of)
 
 
-@pytest.mark.parametrize("arch", ["conv", "trad_fpool3", "one_fstride4", "low_latency_conv", "tiny_conv", "single_fc"])
+@pytest.mark.parametrize("arch", ["conv", "trad_fpool3", "one_fstride4", "low_latency_conv", "tiny_conv", "single_fc", "low_latency_svdf"])
 def test_kws(rt, arch):
     from tcresnet_amd.audio_nets import kws
     t, f, b = SIZES[rt.kind]["kws"]
@@ -148,8 +148,11 @@ def test_kws(rt, arch):
     def masks_of(seed, off, batch):
         return [O.dropout_mask(seed, n, off, batch, int(np.prod(eng.shape(n))), 0.5) for n in nodes]
     _check(rt, eng, lambda p, s, x, tr, m: O.kws_forward(p, x, arch, tr, m), t, f, b, masks_of=masks_of if nodes else None)
-    with pytest.raises(NotImplementedError):
-        kws.get_engine(ms, "low_latency_svdf")
+    if arch == "low_latency_svdf":          # the reference's variables, in their TF shapes (kws.py:577-583, 586-590, 604-607, 623-624)
+        sd = eng.state_dict()
+        assert sd["weights_frequency"].shape == (f, 2560) and sd["weights_time"].shape == (2560, t) and sd["bias"].shape == (1280,)
+        assert sd["runtime-memory"].shape == (2560, 1, t) and not sd["runtime-memory"].any()
+        assert sd["first_fc_weights"].shape == (1280, 256) and sd["final_fc_weights"].shape == (256, 12)
 
 
 def test_model_classes_train_and_evaluate(rt, tmp_path):
