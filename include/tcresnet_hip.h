@@ -204,6 +204,19 @@ int tcr_net_forward_train_stage(const tcr_net* net, const float* params, float* 
 int tcr_net_backward_stage(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch,
                            void* workspace, size_t workspace_bytes, float* grads, int stage, void* stream);
 
+/* The same hand-off by DEPENDENCY LEVEL (round 3): the units whose statistics become available together are handed over at once --
+ * forward: conv0 | per block (down, conv_a) | conv_b; backward: per block, last first, (conv_b, down) | conv_a; then conv0 -- so a
+ * training step needs 2 x (1 + 2 x blocks) all-reduces instead of 2 x (BN units): TCResNet8 14 instead of 20, TCResNet14 26 instead
+ * of 32.  Levels 0 .. tcr_net_num_levels() - 1; after every level but the last the caller all-reduces (sum) the *n_doubles float64
+ * values at *sums_dev (tcr_net_level_sums).  One replica: bitwise the unstaged run. */
+int tcr_net_num_levels(const tcr_net* net, int backward);
+int tcr_net_level_sums(const tcr_net* net, int backward, int level, void* workspace, int batch, double** sums_dev, int64_t* n_doubles);
+int tcr_net_forward_train_level(const tcr_net* net, const float* params, float* stats, const float* feat, const float* labels, int batch,
+                                int global_batch, float keep_prob, uint64_t seed, int64_t sample_offset, float label_smoothing,
+                                void* workspace, size_t workspace_bytes, float* logits, float* probs, float* loss_out, int level, void* stream);
+int tcr_net_backward_level(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch,
+                           void* workspace, size_t workspace_bytes, float* grads, int level, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Network: DS-CNN S / M / L (audio_nets/ds_cnn.py:19-118), the depthwise-separable baseline     */
 /* ------------------------------------------------------------------------------------------ */

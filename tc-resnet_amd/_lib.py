@@ -83,6 +83,11 @@ _PROTOTYPES = {
     "tcr_net_forward_train_stage": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int64,
                                               C.c_float, _P, C.c_size_t, _P, _P, _P, C.c_int, _P]),
     "tcr_net_backward_stage": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_int, _P]),
+    "tcr_net_num_levels": (C.c_int, [_P, C.c_int]),
+    "tcr_net_level_sums": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "tcr_net_forward_train_level": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int64,
+                                              C.c_float, _P, C.c_size_t, _P, _P, _P, C.c_int, _P]),
+    "tcr_net_backward_level": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_int, _P]),
     "tcr_dscnn_create": (C.c_int, [C.POINTER(DSCNNCfg), C.POINTER(_P)]),
     "tcr_dscnn_destroy": (None, [_P]),
     "tcr_dscnn_param_floats": (C.c_int64, [_P]),

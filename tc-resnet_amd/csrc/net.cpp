@@ -66,7 +66,7 @@ struct Workspace {
     std::vector<int64_t> gact;              // grad wrt activation per conv layer (train)
     std::vector<int64_t> mean, invstd;      // saved batch statistics (train)
     std::vector<int64_t> wg, wtl;           // per-layer wgrad partial slabs / re-arranged dgrad weights (train)
-    int64_t partial = -1, sums = -1, kcoef = -1;
+    int64_t partial = -1, sums = -1, sums_slot = 0, kcoef = -1;    // sums: two slots of sums_slot floats (2 x Cmax doubles): main units / shortcut units
     int64_t partial2 = -1, kcoef2 = -1;     // second set: the shortcut branch's BN backward runs concurrently on the side stream
     int64_t dropped = -1, dscale = -1, dlogits = -1, loss_utt = -1, dpool = -1;
     int64_t wgrad_scratch = -1, wt = -1, fc_partial = -1;
@@ -107,7 +107,8 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
     }
     if (train) {
         w.partial = take((int64_t)kPhaseMaxRows * 2 * cmax);
-        w.sums = take(2 * 2 * cmax);        // doubles
+        w.sums_slot = align_up(2 * 2 * (int64_t)cmax, 64);        // 2 x Cmax doubles
+        w.sums = take(2 * w.sums_slot);     // slot 0: main-chain units, slot 1: the blocks' shortcut (`down`) units -- a dependency level hands both over at once
         w.kcoef = take(3 * (int64_t)align_up(cmax, 64));
         w.partial2 = take((int64_t)kPhaseMaxRows * 2 * cmax);
         w.kcoef2 = take(3 * (int64_t)align_up(cmax, 64));
@@ -254,6 +255,56 @@ extern "C" int tcr_net_num_stages(const tcr_net* net, int backward) {
     (void)backward;
     return net ? (int)net->units.size() + 1 : 0;
 }
+
+// ---- dependency levels of the cross-replica BN hand-off ----------------------------------------------------------------------
+// A level = the BN units whose batch statistics become available together.  Forward: conv0 | per block (down, conv_a) | conv_b.
+// Backward: per block, last first, (conv_b, down) | conv_a; then conv0 -- a block's shortcut BN backward depends only on the
+// block-output gradient, like conv_b's, but its data gradient must be added AFTER conv_a's, so its second half runs one level late.
+namespace tcr {
+struct LevelPlan {
+    std::vector<int> post;      // units finished first (finalize + everything downstream of their statistics) ...
+    std::vector<int> pre;       // ... then units whose statistics are produced (one hand-off for all of them)
+    bool first = false, last = false;
+};
+static std::vector<std::vector<int>> level_units(const tcr_net& net, int backward) {
+    std::vector<std::vector<int>> lv;
+    if (!backward) {
+        lv.push_back({0});
+        for (const Block& b : net.blocks) {
+            if (b.down >= 0) lv.push_back({b.down, b.a}); else lv.push_back({b.a});
+            lv.push_back({b.b});
+        }
+    } else {
+        for (int bi = (int)net.blocks.size() - 1; bi >= 0; --bi) {
+            const Block& b = net.blocks[bi];
+            if (b.down >= 0) lv.push_back({b.b, b.down}); else lv.push_back({b.b});
+            lv.push_back({b.a});
+        }
+        lv.push_back({0});
+    }
+    return lv;
+}
+static bool is_down_li(const tcr_net& net, int li) {
+    for (const Block& b : net.blocks) if (b.down == li) return true;
+    return false;
+}
+static LevelPlan level_plan(const tcr_net& net, int backward, int level) {
+    const std::vector<std::vector<int>> lv = level_units(net, backward);
+    const int n = (int)lv.size();
+    LevelPlan p;
+    p.first = level == 0; p.last = level == n;
+    if (level < n) p.pre = lv[level];
+    if (!backward) {
+        if (level > 0) p.post = lv[level - 1];
+    } else {
+        if (level > 0) for (int li : lv[level - 1]) if (!is_down_li(net, li)) p.post.push_back(li);
+        if (level > 1) for (int li : lv[level - 2]) if (is_down_li(net, li)) p.post.push_back(li);
+    }
+    return p;
+}
+}  // namespace tcr
+
+extern "C" int tcr_net_num_levels(const tcr_net* net, int backward) { return net ? (int)tcr::level_units(*net, backward).size() + 1 : 0; }
 
 // ---- eval-mode forward ------------------------------------------------------------------------
 namespace tcr {
@@ -523,6 +574,16 @@ struct TrainCtx {
     hipStream_t s;
 };
 
+// float64 hand-off slot of unit `li` (cross-replica BN): shortcut units use the second slot, so that a block's `down` and the conv
+// sharing its dependency level (conv_a in the forward, conv_b in the backward) can be all-reduced in one call
+static bool is_down_unit(const tcr_net& net, int li) {
+    for (const Block& b : net.blocks) if (b.down == li) return true;
+    return false;
+}
+static double* sums_of(const TrainCtx& c, int li) {
+    return reinterpret_cast<double*>(c.base + c.w.sums + (is_down_unit(*c.net, li) ? c.w.sums_slot : 0));
+}
+
 // conv + per-channel sums of the raw output (everything before the cross-replica hand-off)
 static bool fused_with_down(const tcr_net& net, int li, int* down_of_a, int* a_of_down) {
     for (const Block& b : net.blocks) {
@@ -567,7 +628,7 @@ static int fwd_unit_pre(const TrainCtx& c, int li, hipStream_t rs, float* partia
     int nchunk = 0;
     TCR_TRY(launch_chan_reduce(0, r, &nchunk, rs));
     if (!c.sync_bn) return TCR_OK;          // the finalize kernel sums the partial rows itself
-    return launch_chan_sums(partial, nchunk, l.cout, reinterpret_cast<double*>(c.base + c.w.sums), rs);
+    return launch_chan_sums(partial, nchunk, l.cout, sums_of(c, li), rs);
 }
 
 // statistics -> scale/shift, moving-stat update, normalise (+ReLU / +residual)
@@ -579,7 +640,7 @@ static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* r
     BnFinalizeArgs f;
     f.partial = partial;
     f.nchunk = c.sync_bn ? 0 : (rows >= 0 ? rows : chan_reduce_launch_chunks(c.batch * l.tout, l.tout));
-    f.sums = reinterpret_cast<const double*>(c.base + c.w.sums);
+    f.sums = sums_of(c, li);
     f.gamma = c.params + l.gamma_off; f.beta = c.params + l.beta_off;
     f.moving_mean = stats + l.mean_off; f.moving_var = stats + l.var_off;
     f.scale = ss; f.shift = ss + l.c_pad;
@@ -694,7 +755,7 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
                                 const float* labels, int batch, int global_batch, int sync_bn, float keep_prob,
                                 uint64_t seed, int64_t sample_offset, float label_smoothing,
                                 void* workspace, size_t workspace_bytes, float* logits, float* probs, float* loss_out,
-                                int stage_begin, int stage_end, void* stream) {
+                                int stage_begin, int stage_end, void* stream, const LevelPlan* plan = nullptr) {
     TCR_REQUIRE(net && params && stats && feat && labels && workspace && logits && probs && loss_out, "tcr_net_forward_train: null argument");
     TCR_REQUIRE(batch > 0 && global_batch >= batch, "tcr_net_forward_train: batch %d / global_batch %d", batch, global_batch);
     TCR_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "tcr_net_forward_train: keep_prob %g outside (0, 1]", keep_prob);
@@ -711,8 +772,42 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
     c.side = c.s;
     if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1 && !sync_bn) TCR_TRY(side_stream(*net, &c.side));
     const int nu = (int)net->units.size();
-    TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_forward_train: bad stage range [%d, %d)", stage_begin, stage_end);
+    TCR_REQUIRE(plan || (stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end), "tcr_net_forward_train: bad stage range [%d, %d)", stage_begin, stage_end);
     const bool phases = phases_usable(c);
+    if (plan) {         // one dependency level (cross-replica BN): finish `post`, then produce the statistics of `pre`
+        TCR_REQUIRE(c.sync_bn, "tcr_net_forward_train_level: levels exist for the cross-replica hand-off");
+        auto partial_of = [&](int li) { return c.base + (is_down_unit(*net, li) ? c.w.partial2 : c.w.partial); };
+        bool first = true;
+        for (int li : plan->post) {
+            if (phases) TCR_TRY(fwd_unit_post(c, li, stats, nullptr, c.s, partial_of(li), train_phase_rows(phase_of_unit(c, li, &first))));
+            else TCR_TRY(fwd_unit_post(c, li, stats, unit_residual(c, li), c.s, partial_of(li)));
+        }
+        for (int li : plan->pre) {
+            if (phases) {
+                const TrainPhaseArgs pa = phase_of_unit(c, li, &first);
+                int rows = train_phase_rows(pa);
+                if (first) TCR_TRY(launch_train_phase(pa, &rows, c.s));
+                TCR_TRY(launch_chan_sums(partial_of(li), rows, net->layers[li].cout, sums_of(c, li), c.s));
+            } else {
+                TCR_TRY(fwd_unit_pre(c, li, c.s, partial_of(li)));
+            }
+        }
+        if (!plan->last) return TCR_OK;
+        if (phases) TCR_TRY(launch_train_phase(phase_of_unit(c, -1, &first), nullptr, c.s));       // the head's input + the last shortcut
+        HeadArgs h;
+        std::memset(&h, 0, sizeof(h));
+        h.feat = c.base + c.w.act[net->units[nu - 1]];
+        h.wfc = params + net->layers[net->fc].w_off;
+        h.wfc2 = params + net->layers[net->fc2].w_off;
+        h.labels = labels; h.logits = logits; h.probs = probs; h.ranges = nullptr;
+        h.dropped = c.base + c.w.dropped; h.dscale = c.base + c.w.dscale;
+        h.dlogits = c.base + c.w.dlogits; h.loss_utt = c.base + c.w.loss_utt;
+        h.batch = batch; h.c = net->feat_c; h.nc = net->cfg.num_classes; h.t = net->feat_t; h.tp = tcr_padded_len(net->feat_t);
+        h.keep_prob = keep_prob; h.seed = seed; h.sample_offset = sample_offset;
+        h.inv_global_batch = 1.0f / (float)global_batch; h.label_smoothing = label_smoothing;
+        TCR_TRY(launch_head_fwd(h, true, c.s));
+        return launch_sum_vector(c.base + c.w.loss_utt, batch, loss_out, c.s);
+    }
     for (int st = stage_begin; phases && st < stage_end; ++st) {
         // Group-resident phases: conv (+ the block's `down`) with the statistics in its epilogue; the previous unit's BN affine,
         // ReLU and residual are applied while the phase stages its input.  Between phases only the tiny finalize kernels run.
@@ -729,7 +824,7 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
             const TrainPhaseArgs pa = phase_of_unit(c, li, &first);
             int rows = train_phase_rows(pa);
             if (first) TCR_TRY(launch_train_phase(pa, &rows, c.s));
-            if (c.sync_bn) TCR_TRY(launch_chan_sums(partial_of(li), rows, net->layers[li].cout, reinterpret_cast<double*>(c.base + c.w.sums), c.s));
+            if (c.sync_bn) TCR_TRY(launch_chan_sums(partial_of(li), rows, net->layers[li].cout, sums_of(c, li), c.s));
         } else {
             TCR_TRY(launch_train_phase(phase_of_unit(c, -1, &first), nullptr, c.s));       // the head's input + the last shortcut
             HeadArgs h;
@@ -811,6 +906,33 @@ extern "C" int tcr_net_forward_train_stage(const tcr_net* net, const float* para
                                 label_smoothing, workspace, workspace_bytes, logits, probs, loss_out, stage, stage + 1, stream);
 }
 
+extern "C" int tcr_net_forward_train_level(const tcr_net* net, const float* params, float* stats, const float* feat,
+                                           const float* labels, int batch, int global_batch, float keep_prob, uint64_t seed,
+                                           int64_t sample_offset, float label_smoothing, void* workspace, size_t workspace_bytes,
+                                           float* logits, float* probs, float* loss_out, int level, void* stream) {
+    TCR_REQUIRE(net && level >= 0 && level < tcr_net_num_levels(net, 0), "tcr_net_forward_train_level: bad level %d", level);
+    const LevelPlan plan = level_plan(*net, 0, level);
+    return forward_train_stages(net, params, stats, feat, labels, batch, global_batch, 1, keep_prob, seed, sample_offset,
+                                label_smoothing, workspace, workspace_bytes, logits, probs, loss_out, 0, 1, stream, &plan);
+}
+
+// The float64 sums a level hands over: [2 x C] of its main-chain unit at the start of the region, and -- when the level also holds a
+// shortcut unit -- [2 x C_down] in the second slot, one contiguous range (the gap behind the first unit's sums rides along).
+extern "C" int tcr_net_level_sums(const tcr_net* net, int backward, int level, void* workspace, int batch, double** sums_dev, int64_t* n_doubles) {
+    TCR_REQUIRE(net && workspace && sums_dev && n_doubles, "tcr_net_level_sums: null argument");
+    const std::vector<std::vector<int>> lv = level_units(*net, backward);
+    TCR_REQUIRE(level >= 0 && level < (int)lv.size(), "tcr_net_level_sums: level %d has no hand-off", level);
+    const Workspace w = carve(*net, batch, true);
+    *sums_dev = reinterpret_cast<double*>(static_cast<float*>(workspace) + w.sums);
+    int64_t n = 0;
+    for (int li : lv[level]) {
+        const int64_t end = (is_down_unit(*net, li) ? w.sums_slot / 2 : 0) + 2 * (int64_t)net->layers[li].cout;
+        n = end > n ? end : n;
+    }
+    *n_doubles = n;
+    return TCR_OK;
+}
+
 namespace tcr { static std::vector<int> backward_order(const tcr_net& net); }
 
 extern "C" int tcr_net_stage_sums(const tcr_net* net, int backward, int stage, void* workspace, int batch,
@@ -820,7 +942,7 @@ extern "C" int tcr_net_stage_sums(const tcr_net* net, int backward, int stage, v
     TCR_REQUIRE(stage >= 0 && stage < nu, "tcr_net_stage_sums: stage %d has no BN hand-off", stage);
     const Workspace w = carve(*net, batch, true);
     const int li = backward ? backward_order(*net)[stage] : net->units[stage];
-    *sums_dev = reinterpret_cast<double*>(static_cast<float*>(workspace) + w.sums);
+    *sums_dev = reinterpret_cast<double*>(static_cast<float*>(workspace) + w.sums + (is_down_unit(*net, li) ? w.sums_slot : 0));
     *n_doubles = 2 * (int64_t)net->layers[li].cout;
     return TCR_OK;
 }
@@ -887,7 +1009,7 @@ static int bwd_unit_pre(const TrainCtx& c, const BwdUnit& u, hipStream_t st, flo
     int nchunk = 0;
     TCR_TRY(launch_chan_reduce(1, r, &nchunk, st));
     if (!c.sync_bn) return TCR_OK;
-    return launch_chan_sums(partial, nchunk, l.cout, reinterpret_cast<double*>(c.base + c.w.sums), st);
+    return launch_chan_sums(partial, nchunk, l.cout, sums_of(c, u.li), st);
 }
 
 // parts: 1 = BN backward (finalize + apply -> dy), 2 = weight gradient, 4 = data gradient.  bn_stream / partial / kc: where the
@@ -905,7 +1027,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
         BnBwdFinalizeArgs f;
         f.partial = partial;
         f.nchunk = c.sync_bn ? 0 : chan_reduce_launch_chunks(c.batch * l.tout, l.tout);
-        f.sums = reinterpret_cast<const double*>(c.base + c.w.sums); f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[u.li];
+        f.sums = sums_of(c, u.li); f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[u.li];
         f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
         f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
         f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
@@ -1112,7 +1234,7 @@ static int bwd_finalize(const TrainCtx& c, int li, float* grads, float* partial,
     BnBwdFinalizeArgs f;
     f.partial = partial;
     f.nchunk = c.sync_bn ? 0 : rows;
-    f.sums = reinterpret_cast<const double*>(c.base + c.w.sums); f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[li];
+    f.sums = sums_of(c, li); f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[li];
     f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
     f.k1 = kc; f.k2 = kc + kstride; f.k3 = kc + 2 * kstride;
     f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
@@ -1123,7 +1245,8 @@ static int bwd_finalize(const TrainCtx& c, int li, float* grads, float* partial,
 }  // namespace tcr
 
 static int backward_stages(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch, int sync_bn,
-                           void* workspace, size_t workspace_bytes, float* grads, int stage_begin, int stage_end, void* stream) {
+                           void* workspace, size_t workspace_bytes, float* grads, int stage_begin, int stage_end, void* stream,
+                           const LevelPlan* plan = nullptr) {
     TCR_REQUIRE(net && params && feat && workspace && grads, "tcr_net_backward: null argument");
     TCR_REQUIRE(batch > 0 && global_batch >= batch, "tcr_net_backward: batch %d / global_batch %d", batch, global_batch);
     TrainCtx c;
@@ -1140,9 +1263,9 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) TCR_TRY(side_stream(*net, &c.side));
     const std::vector<int> order = backward_order(*net);
     const int nu = (int)order.size();
-    TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);
+    TCR_REQUIRE(plan || (stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end), "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);
     const float* dpool = c.base + c.w.dpool;
-    const bool bwd_phases = bwd_phases_usable(c, dpool);
+    const bool bwd_phases = !plan && bwd_phases_usable(c, dpool);
     auto reduce_slabs = [&]() -> int {      // every layer's split-K slabs -> dW, one launch (after the side stream has drained)
         if (c.side != c.s && (hipEventRecord(net->ev_join, c.side) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join, 0) != hipSuccess)) {
             set_error("tcr_net_backward: stream join failed");
@@ -1158,6 +1281,7 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
         }
         return launch_wgrad_reduce_multi(rm, c.s);
     };
+    if (plan) { stage_begin = plan->first ? 0 : 1; stage_end = stage_begin + 1; }
     for (int st = stage_begin; st < stage_end; ++st) {
         if (st == 0) {
             // head: zero the arena (padding + fc2, which gets no loss gradient), fc wgrad, pooled gradient
@@ -1179,6 +1303,16 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
                 dm.e[dm.n++] = {params + l.w_off, c.base + c.w.wtl[li], l.k, l.cin, l.cout, l.stride, l.pad_lo};
             }
             TCR_TRY(launch_dgrad_weights_multi(dm, c.s));
+        }
+        if (plan) {     // one dependency level: the per-layer kernels on the caller's stream, shortcut units on the second scratch set
+            TCR_REQUIRE(c.sync_bn, "tcr_net_backward_level: levels exist for the cross-replica hand-off");
+            for (int li : plan->post) {
+                const bool dn = is_down_unit(*net, li);
+                TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, li, dpool), grads, dpool, BWD_ALL, c.s, bwd_partial_of(c, li), c.base + (dn ? c.w.kcoef2 : c.w.kcoef)));
+            }
+            for (int li : plan->pre) TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, li, dpool), c.s, bwd_partial_of(c, li)));
+            if (plan->last) TCR_TRY(reduce_slabs());
+            continue;
         }
         if (bwd_phases) {
             // Group-resident phases.  Per unit, in `order` (block: conv_b, conv_a, down):
@@ -1209,8 +1343,7 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
                 if (li == net->blocks[nb - 1].b || li == net->blocks[nb - 1].down)      // (gradient of the pooled head, broadcast over time)
                     TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, li, dpool), c.s, bwd_partial_of(c, li)));
                 else if (c.sync_bn)
-                    TCR_TRY(launch_chan_sums(bwd_partial_of(c, li), bwd_rows_of(c, li, dpool), net->layers[li].cout,
-                                             reinterpret_cast<double*>(c.base + c.w.sums), c.s));
+                    TCR_TRY(launch_chan_sums(bwd_partial_of(c, li), bwd_rows_of(c, li, dpool), net->layers[li].cout, sums_of(c, li), c.s));
             }
             if (st == nu) TCR_TRY(reduce_slabs());
             continue;
@@ -1262,4 +1395,11 @@ extern "C" int tcr_net_backward(const tcr_net* net, const float* params, const f
 extern "C" int tcr_net_backward_stage(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch,
                                       void* workspace, size_t workspace_bytes, float* grads, int stage, void* stream) {
     return backward_stages(net, params, feat, batch, global_batch, 1, workspace, workspace_bytes, grads, stage, stage + 1, stream);
+}
+
+extern "C" int tcr_net_backward_level(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch,
+                                      void* workspace, size_t workspace_bytes, float* grads, int level, void* stream) {
+    TCR_REQUIRE(net && level >= 0 && level < tcr_net_num_levels(net, 1), "tcr_net_backward_level: bad level %d", level);
+    const tcr::LevelPlan plan = tcr::level_plan(*net, 1, level);
+    return backward_stages(net, params, feat, batch, global_batch, 1, workspace, workspace_bytes, grads, 0, 1, stream, &plan);
 }

@@ -398,12 +398,12 @@ class TCResNet(_Base):
                   logits.data_ptr(), probs.data_ptr(), loss.data_ptr())
         if sync_hook is None:
             self.lib.check(self.lib.tcr_net_forward_train(*common, self._stream()), "tcr_net_forward_train")
-        else:
-            ns = self.lib.tcr_net_num_stages(self._h, 0)
-            for st in range(ns):
-                self.lib.check(self.lib.tcr_net_forward_train_stage(*common, st, self._stream()), "tcr_net_forward_train_stage")
-                if st < ns - 1:
-                    sync_hook(self._stage_sums(0, st, ws, b))
+        else:           # cross-replica BN: one hand-off per dependency level (a block's shortcut conv rides with its first conv)
+            nl = self.lib.tcr_net_num_levels(self._h, 0)
+            for lv in range(nl):
+                self.lib.check(self.lib.tcr_net_forward_train_level(*common, lv, self._stream()), "tcr_net_forward_train_level")
+                if lv < nl - 1:
+                    sync_hook(self._level_sums(0, lv, ws, b))
         self._kver += 1          # the moving statistics changed
         self._last = (feat, b, gb, sync_hook)
         return logits, probs, loss[0]
@@ -415,6 +415,13 @@ class TCResNet(_Base):
         off = (ptr.value - ws.data_ptr()) // 4
         return ws[off:off + 2 * n.value].view(torch.float64)        # 2*C float64 sums living inside the f32 workspace
 
+    def _level_sums(self, backward: int, level: int, ws: torch.Tensor, batch: int) -> torch.Tensor:
+        ptr, n = C.c_void_p(), C.c_int64()
+        self.lib.check(self.lib.tcr_net_level_sums(self._h, backward, level, ws.data_ptr(), batch, C.byref(ptr), C.byref(n)),
+                       "tcr_net_level_sums")
+        off = (ptr.value - ws.data_ptr()) // 4
+        return ws[off:off + 2 * n.value].view(torch.float64)        # the level's float64 sums (one contiguous range)
+
     def backward(self) -> torch.Tensor:
         """Gradient of the mean cross-entropy wrt every trainable, into self.grads (L2 excluded)."""
         feat, b, gb, sync_hook = self._last
@@ -423,13 +430,13 @@ class TCResNet(_Base):
             self.lib.check(self.lib.tcr_net_backward(self._h, self.params.data_ptr(), feat.data_ptr(), b, ws.data_ptr(),
                                                      ws.numel() * 4, self.grads.data_ptr(), self._stream()), "tcr_net_backward")
         else:
-            ns = self.lib.tcr_net_num_stages(self._h, 1)
-            for st in range(ns):
-                self.lib.check(self.lib.tcr_net_backward_stage(self._h, self.params.data_ptr(), feat.data_ptr(), b, gb,
-                                                               ws.data_ptr(), ws.numel() * 4, self.grads.data_ptr(), st,
-                                                               self._stream()), "tcr_net_backward_stage")
-                if st < ns - 1:
-                    sync_hook(self._stage_sums(1, st, ws, b))
+            nl = self.lib.tcr_net_num_levels(self._h, 1)
+            for lv in range(nl):
+                self.lib.check(self.lib.tcr_net_backward_level(self._h, self.params.data_ptr(), feat.data_ptr(), b, gb,
+                                                               ws.data_ptr(), ws.numel() * 4, self.grads.data_ptr(), lv,
+                                                               self._stream()), "tcr_net_backward_level")
+                if lv < nl - 1:
+                    sync_hook(self._level_sums(1, lv, ws, b))
         return self.grads
 
     def _slot(self, name: str) -> torch.Tensor:

@@ -404,8 +404,10 @@ def check_staged_equals_unstaged(lib, name, width, batch, tag="4020", keep_prob=
         logits, probs, loss = net.forward_train(feat, labels, keep_prob=keep_prob, seed=11, sync_hook=hook)
         g = net.backward().clone()
         outs.append((logits.clone(), probs.clone(), loss.clone(), g, net.stats.clone()))
-    nbn = len([c for c in arch.convs() if c.bn])
-    assert len(seen) == 2 * nbn and all(dt == torch.float64 for dt, _ in seen)
+    # one hand-off per dependency level each way: conv0, and per block (shortcut + first conv) | second conv
+    nblocks = len(R.tcresnet_channels(name, float(width))) - 1
+    assert lib.tcr_net_num_levels(net._h, 0) - 1 == 1 + 2 * nblocks == lib.tcr_net_num_levels(net._h, 1) - 1
+    assert len(seen) == 2 * (1 + 2 * nblocks) and all(dt == torch.float64 for dt, _ in seen)
     for a, b, what in zip(outs[0], outs[1], ("logits", "probs", "loss", "grads", "moving stats")):
         assert torch.equal(a, b), f"staged {what} differ from the unstaged run (max |d| {float((a - b).abs().max())})"
     assert torch.isfinite(outs[0][3]).all()

@@ -69,7 +69,7 @@ def _worker(rank, world, port, sync_bn, out_dir, kind, name, width, b):
     torch.cuda.synchronize() if fe.device.type == "cuda" else None
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), grads=g.cpu().numpy(), logits=logits.cpu().numpy(), loss=float(mean_loss),
              params=net.params.cpu().numpy(), stats=net.stats.cpu().numpy(), collectives=dp.collectives,
-             units=(lib.tcr_dscnn_num_units(net._h) if name == "DSCNN" else lib.tcr_net_num_stages(net._h, 0) - 1))
+             handoffs=(2 * lib.tcr_dscnn_num_units(net._h) if name == "DSCNN" else lib.tcr_net_num_levels(net._h, 0) + lib.tcr_net_num_levels(net._h, 1) - 2))
     dist.destroy_process_group()
 
 
@@ -86,10 +86,15 @@ def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b, grad_tol=2e-5):
     # replicas hold identical gradients / parameters / moving statistics after the all-reduce
     assert np.array_equal(r[0]["grads"], r[1]["grads"]) and np.array_equal(r[0]["params"], r[1]["params"])
     assert abs(float(r[0]["loss"]) - float(r[1]["loss"])) == 0.0
-    # collectives per step: ONE for the gradient arena (the loss sum rides in its tail), plus -- cross-replica BN only -- one
-    # per BN unit in the forward and one in the backward (2 x 10 for TCResNet8, 2 x 16 for TCResNet14, 2 x 11 for DS-CNN)
+    # collectives per step: ONE for the gradient arena (the loss sum rides in its tail), plus -- cross-replica BN only -- one per
+    # dependency level in the forward and one in the backward: TC-ResNet 2 x (1 + 2 x blocks) (TCResNet8: 14, TCResNet14: 26; a block's
+    # shortcut unit rides with the conv of its level), DS-CNN one per BN unit (2 x 11)
     for ri in r:
-        assert int(ri["collectives"]) == 1 + (2 * int(ri["units"]) if sync_bn else 0), (int(ri["collectives"]), int(ri["units"]))
+        assert int(ri["collectives"]) == 1 + (int(ri["handoffs"]) if sync_bn else 0), (int(ri["collectives"]), int(ri["handoffs"]))
+        if name == "TCResNet8":
+            assert int(ri["handoffs"]) == 14
+        elif name == "TCResNet14":
+            assert int(ri["handoffs"]) == 26
     if sync_bn:
         assert np.array_equal(r[0]["stats"], r[1]["stats"])
     # single process, global batch of 2b, same dropout stream (masks are indexed by global sample id)
