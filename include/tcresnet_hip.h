@@ -328,6 +328,16 @@ int tcr_g2d_forward_train(const tcr_g2d* g, const float* params, float* stats, c
                           size_t workspace_bytes, float* logits, float* probs, float* loss_out, void* stream);
 int tcr_g2d_backward(const tcr_g2d* g, const float* params, const float* x, int batch, uint64_t seed, int64_t sample_offset,
                      void* workspace, size_t workspace_bytes, float* grads, void* stream);
+/* Cross-replica BN for the graph engine (round 3): the forward / backward stop behind every BN node's statistics (graph order / reverse
+ * graph order), the caller all-reduces the 2 x C float64 sums (tcr_g2d_stage_sums) and runs the next stage; stages
+ * 0 .. tcr_g2d_num_stages() - 1 (= BN nodes + 1).  One replica: bitwise the unstaged run. */
+int tcr_g2d_num_stages(const tcr_g2d* g);
+int tcr_g2d_stage_sums(const tcr_g2d* g, int backward, int stage, void* workspace, int batch, double** sums_dev, int64_t* n_doubles);
+int tcr_g2d_forward_train_stage(const tcr_g2d* g, const float* params, float* stats, const float* x, const float* labels, int batch,
+                                int global_batch, uint64_t seed, int64_t sample_offset, float label_smoothing, void* workspace,
+                                size_t workspace_bytes, float* logits, float* probs, float* loss_out, int stage, void* stream);
+int tcr_g2d_backward_stage(const tcr_g2d* g, const float* params, const float* x, int batch, int global_batch, uint64_t seed,
+                           int64_t sample_offset, void* workspace, size_t workspace_bytes, float* grads, int stage, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Optimiser (helper/trainer.py:171-197) and L2 (factory/audio_nets.py:175-182)                */
@@ -349,6 +359,10 @@ int tcr_rmsprop_step(float* params, const float* grads, float* ms, float* mom, i
 int tcr_ema_step(float* shadow, const float* params, int64_t n, float decay, void* stream);
 /* out[0] = weight_decay * sum_{i<n_decay} 0.5*w_i^2 (device float). */
 int tcr_l2_loss(const float* params, int64_t n_decay, float weight_decay, float* out, void* stream);
+/* Batch SUM of the softmax cross-entropy of logits rows [batch][num_classes] against one-hot (optionally smoothed) labels: the model
+ * loss of an evaluation build (tf.losses.softmax_cross_entropy, factory/audio_nets.py:161-173) times the batch. */
+int tcr_xent_loss_sum(const float* logits, const float* labels, int batch, int num_classes, float label_smoothing,
+                      float* loss_utt, float* loss_sum, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Input stage: PCM decode + crop/pad + time shift + background mix            */

@@ -131,6 +131,11 @@ _PROTOTYPES = {
     "tcr_g2d_forward_train": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_float, _P, C.c_size_t, _P, _P, _P,
                                         _P]),
     "tcr_g2d_backward": (C.c_int, [_P, _P, _P, C.c_int, C.c_uint64, C.c_int64, _P, C.c_size_t, _P, _P]),
+    "tcr_g2d_num_stages": (C.c_int, [_P]),
+    "tcr_g2d_stage_sums": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "tcr_g2d_forward_train_stage": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_float, _P, C.c_size_t, _P, _P, _P,
+                                              C.c_int, _P]),
+    "tcr_g2d_backward_stage": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int64, _P, C.c_size_t, _P, C.c_int, _P]),
     "tcr_sgd_momentum_step": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "tcr_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int64, C.c_float, C.c_float, _P]),
@@ -138,6 +143,7 @@ _PROTOTYPES = {
                                    C.c_float, _P]),
     "tcr_ema_step": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "tcr_l2_loss": (C.c_int, [_P, C.c_int64, C.c_float, _P, _P]),
+    "tcr_xent_loss_sum": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
 }
 
 ABI_SYMBOLS = tuple(_PROTOTYPES.keys())

@@ -583,10 +583,6 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int row = a.in_c * a.in_tp;
-#if !defined(TCR_HOST_EMULATION)
-    if (a.stagger > 0 && (int)blockIdx.x >= (int)gridDim.x / 2)
-        for (int i = 0; i < a.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
-#endif
 #if TCR_FUSED_WHATIF & 8
 #define TCR_TC8_BARRIER ((void)0)
 #else

@@ -234,9 +234,40 @@ __global__ __launch_bounds__(256) void sum_vector_kernel(const float* __restrict
     }
 }
 
+// per-utterance softmax cross-entropy from logits rows [B][NC] (eval builds: tf.losses.softmax_cross_entropy, factory/audio_nets.py:168-173)
+__global__ __launch_bounds__(64) void xent_rows_kernel(const float* __restrict__ logits, const float* __restrict__ labels, float* __restrict__ loss_utt,
+                                                       int batch, int nc, float label_smoothing) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= batch) return;
+    const float* z = logits + (size_t)n * nc;
+    float mx = z[0];
+    for (int k = 1; k < nc; ++k) mx = fmaxf(mx, z[k]);
+    float se = 0.f;
+    for (int k = 0; k < nc; ++k) se += expf(z[k] - mx);
+    const float lse = logf(se);
+    float loss = 0.f;
+    for (int k = 0; k < nc; ++k) {
+        float y = labels[(size_t)n * nc + k];
+        if (label_smoothing > 0.f) y = y * (1.0f - label_smoothing) + label_smoothing / (float)nc;
+        loss -= y * ((z[k] - mx) - lse);
+    }
+    loss_utt[n] = loss;
+}
+
 int launch_sum_vector(const float* in, int n, float* out, hipStream_t s) {
     hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(256), 0, s, in, n, out);
     return check_launch("sum_vector_kernel");
 }
 
 }  // namespace tcr
+
+// Sum over the batch of the softmax cross-entropy of logits rows against (optionally smoothed) one-hot labels: the evaluation graph's
+// model loss (factory/audio_nets.py:161-173) times the batch.  loss_utt: caller-owned scratch of `batch` floats; loss_sum: one float.
+extern "C" int tcr_xent_loss_sum(const float* logits, const float* labels, int batch, int num_classes, float label_smoothing,
+                                 float* loss_utt, float* loss_sum, void* stream) {
+    TCR_REQUIRE(logits && labels && loss_utt && loss_sum && batch > 0 && num_classes > 0, "tcr_xent_loss_sum: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(tcr::xent_rows_kernel, dim3(tcr::ceil_div(batch, 64)), dim3(64), 0, s, logits, labels, loss_utt, batch, num_classes, label_smoothing);
+    TCR_TRY(tcr::check_launch("xent_rows_kernel"));
+    return tcr::launch_sum_vector(loss_utt, batch, loss_sum, s);
+}

@@ -131,7 +131,6 @@ struct FusedArgs {
     int feat_c, feat_t, nc;
     int fc_off, fc2_off;
     int in_global;              // the first layer reads the feature rows straight from global memory (no LDS copy)
-    int stagger;                // experiment: workgroups of the second dispatch half start this many x 64 cycles late
     FusedLayer layer[kFusedMaxLayers];
 };
 

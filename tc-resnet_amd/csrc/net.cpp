@@ -416,7 +416,6 @@ static int forward_infer_fused(const tcr_net& net, const float* params, const fl
     int grid = 256 * per_cu;
     if (grid > a.n_groups) grid = a.n_groups;
     if (tune_get(TCR_TUNE_FUSED_GRID) > 0 && grid > tune_get(TCR_TUNE_FUSED_GRID)) grid = tune_get(TCR_TUNE_FUSED_GRID);
-    a.stagger = tune_get(TCR_TUNE_FUSED_GRID) < 0 ? -tune_get(TCR_TUNE_FUSED_GRID) : 0;
     // knob: waves + 100 * ring (0: default)
     const int knob = tune_get(TCR_TUNE_FUSED_WAVES);
     const int waves = knob % 100 ? knob % 100 : (per_cu >= 4 ? 4 : (per_cu >= 2 ? 8 : 16)), ring = knob / 100 ? knob / 100 : 4;

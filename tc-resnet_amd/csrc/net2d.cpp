@@ -4,6 +4,7 @@
 // reference) through tcr_g2d_conv / batch_norm / pool / add / dropout; this file lays out the variable arenas under the
 // caller's TF names, carves the workspace and sequences the kernels of net2d_kernels.hip + bn.hip for eval forward, train forward
 // and backward.  Host-only state; every device buffer belongs to the caller.
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -73,7 +74,7 @@ static void out_dim(int len, int k_eff, int stride, bool valid, int* out, int* p
 
 struct G2dWorkspace {
     std::vector<int64_t> out, grad, mean, invstd, ss, argmax;
-    int64_t partial = -1, kcoef = -1, scratch_c = -1, wgrad = -1, loss_utt = -1, dlogits = -1;
+    int64_t partial = -1, kcoef = -1, scratch_c = -1, wgrad = -1, loss_utt = -1, dlogits = -1, sums = -1;
     int64_t grad_begin = 0, grad_end = 0;
     int64_t total = 0;
 };
@@ -104,6 +105,7 @@ static G2dWorkspace carve2d(const tcr_g2d& g, int batch, bool train) {
         for (size_t i = 0; i < nn; ++i) w.grad[i] = take((int64_t)batch * g.nodes[i].c * pp_of(g.nodes[i].h, g.nodes[i].w));
         w.grad_end = o;
         w.partial = take((int64_t)512 * 2 * g.cmax);
+        w.sums = take(2 * 2 * al64(g.cmax));        // 2 x C float64 sums: the cross-replica BN hand-off
         w.kcoef = take(3 * al64(g.cmax));
         w.scratch_c = take(2 * al64(g.cmax));
         w.wgrad = take(wgmax);
@@ -119,6 +121,13 @@ static const float* in_ptr(const tcr_g2d& g, const G2dWorkspace& w, const float*
     const G2dNode& n = g.nodes[id];
     if (n.kind == G2D_DROPOUT && !train) return in_ptr(g, w, base, x, n.in0, train);
     return base + w.out[id];
+}
+
+// BN nodes in graph order: under cross-replica BN the forward / backward stop behind each one's statistics
+static std::vector<int> bn_nodes(const tcr_g2d& g) {
+    std::vector<int> v;
+    for (size_t i = 0; i < g.nodes.size(); ++i) if (g.nodes[i].kind == G2D_BN) v.push_back((int)i);
+    return v;
 }
 
 static Conv2dArgs conv_args(const tcr_g2d& g, const G2dNode& n, int batch) {
@@ -354,7 +363,9 @@ extern "C" int tcr_g2d_input_from_features(const float* feat, int batch, int t, 
 // ---- forward ------------------------------------------------------------------------------------------------------------------
 static int g2d_forward(const tcr_g2d* g, const float* params, float* stats, const float* x, const float* labels, int batch, int global_batch,
                        bool train, uint64_t seed, int64_t sample_offset, float label_smoothing, void* workspace, size_t workspace_bytes,
-                       float* logits, float* probs, float* loss_out, void* stream) {
+                       float* logits, float* probs, float* loss_out, void* stream, int stage = -1) {
+    // stage >= 0 (cross-replica BN): run from BN node #(stage - 1)'s finalize (stage 0: the input) up to BN node #stage's statistics, which
+    // are left as float64 sums for the caller's all-reduce; the last stage finishes with the head
     TCR_REQUIRE(g && g->finalized && params && stats && x && workspace && logits && probs, "tcr_g2d_forward: null argument");
     TCR_REQUIRE(batch > 0 && global_batch >= batch, "tcr_g2d_forward: batch %d / global_batch %d", batch, global_batch);
     const G2dWorkspace w = carve2d(*g, batch, train);
@@ -364,7 +375,11 @@ static int g2d_forward(const tcr_g2d* g, const float* params, float* stats, cons
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* base = static_cast<float*>(workspace);
-    for (size_t i = 0; i < g->nodes.size(); ++i) {
+    const bool staged = stage >= 0;
+    const std::vector<int> bns = staged ? bn_nodes(*g) : std::vector<int>();
+    TCR_REQUIRE(!staged || (train && stage <= (int)bns.size()), "tcr_g2d_forward_train_stage: bad stage %d", stage);
+    const size_t i0 = staged && stage > 0 ? (size_t)bns[stage - 1] : 0;
+    for (size_t i = i0; i < g->nodes.size(); ++i) {
         const G2dNode& n = g->nodes[i];
         const float* in0 = in_ptr(*g, w, base, x, n.in0, train);
         float* out = w.out[i] >= 0 ? base + w.out[i] : nullptr;
@@ -380,17 +395,24 @@ static int g2d_forward(const tcr_g2d* g, const float* params, float* stats, cons
                 float* ss = base + w.ss[i];
                 const float* beta = params + (n.center ? n.beta_off : g->zeros_off);
                 if (train) {
-                    ChanReduceArgs r;
-                    std::memset(&r, 0, sizeof(r));
-                    r.y = in0; r.partial = base + w.partial; r.npos = batch * n.h * n.w; r.c = n.c; r.t = n.h * n.w; r.tp = pp;
+                    const bool resume = staged && stage > 0 && (int)i == bns[stage - 1];      // (its statistics were handed over)
                     int nchunk = 0;
-                    TCR_TRY(launch_chan_reduce(0, r, &nchunk, s));
+                    if (!resume) {
+                        ChanReduceArgs r;
+                        std::memset(&r, 0, sizeof(r));
+                        r.y = in0; r.partial = base + w.partial; r.npos = batch * n.h * n.w; r.c = n.c; r.t = n.h * n.w; r.tp = pp;
+                        TCR_TRY(launch_chan_reduce(0, r, &nchunk, s));
+                        if (staged) {
+                            TCR_TRY(launch_chan_sums(base + w.partial, nchunk, n.c, reinterpret_cast<double*>(base + w.sums), s));
+                            return TCR_OK;          // hand-off: the caller all-reduces the sums, then runs the next stage
+                        }
+                    }
                     BnFinalizeArgs f;
-                    f.partial = base + w.partial; f.nchunk = nchunk; f.sums = nullptr;
+                    f.partial = base + w.partial; f.nchunk = staged ? 0 : nchunk; f.sums = staged ? reinterpret_cast<const double*>(base + w.sums) : nullptr;
                     f.gamma = n.scale ? params + n.gamma_off : nullptr; f.beta = beta;
                     f.moving_mean = stats + n.mean_off; f.moving_var = stats + n.var_off;
                     f.scale = ss; f.shift = ss + n.c_pad; f.mean = base + w.mean[i]; f.invstd = base + w.invstd[i];
-                    f.c = n.c; f.count = (double)batch * (double)(n.h * n.w); f.decay = n.decay; f.eps = n.eps;
+                    f.c = n.c; f.count = (double)(staged ? global_batch : batch) * (double)(n.h * n.w); f.decay = n.decay; f.eps = n.eps;
                     TCR_TRY(launch_bn_finalize(f, s));
                 } else {
                     BnFoldArgs f;
@@ -467,8 +489,32 @@ extern "C" int tcr_g2d_forward_train(const tcr_g2d* g, const float* params, floa
 }
 
 // ---- backward -----------------------------------------------------------------------------------------------------------------
-extern "C" int tcr_g2d_backward(const tcr_g2d* g, const float* params, const float* x, int batch, uint64_t seed, int64_t sample_offset,
-                                void* workspace, size_t workspace_bytes, float* grads, void* stream) {
+extern "C" int tcr_g2d_num_stages(const tcr_g2d* g) { return g ? (int)tcr::bn_nodes(*g).size() + 1 : 0; }
+
+extern "C" int tcr_g2d_forward_train_stage(const tcr_g2d* g, const float* params, float* stats, const float* x, const float* labels, int batch,
+                                           int global_batch, uint64_t seed, int64_t sample_offset, float label_smoothing, void* workspace,
+                                           size_t workspace_bytes, float* logits, float* probs, float* loss_out, int stage, void* stream) {
+    TCR_REQUIRE(labels && loss_out && stage >= 0, "tcr_g2d_forward_train_stage: bad argument");
+    return g2d_forward(g, params, stats, x, labels, batch, global_batch, true, seed, sample_offset, label_smoothing, workspace, workspace_bytes,
+                       logits, probs, loss_out, stream, stage);
+}
+
+// float64 sums handed over after stage `stage` (< tcr_g2d_num_stages() - 1): 2 x C of the stage's BN node (backward: reverse graph order)
+extern "C" int tcr_g2d_stage_sums(const tcr_g2d* g, int backward, int stage, void* workspace, int batch, double** sums_dev, int64_t* n_doubles) {
+    TCR_REQUIRE(g && g->finalized && workspace && sums_dev && n_doubles, "tcr_g2d_stage_sums: bad argument");
+    const std::vector<int> bns = tcr::bn_nodes(*g);
+    TCR_REQUIRE(stage >= 0 && stage < (int)bns.size(), "tcr_g2d_stage_sums: stage %d has no hand-off", stage);
+    const G2dWorkspace w = carve2d(*g, batch, true);
+    const int node = backward ? bns[bns.size() - 1 - stage] : bns[stage];
+    *sums_dev = reinterpret_cast<double*>(static_cast<float*>(workspace) + w.sums);
+    *n_doubles = 2 * (int64_t)g->nodes[node].c;
+    return TCR_OK;
+}
+
+// stage < 0: the whole backward.  stage >= 0 (cross-replica BN): from BN node #(stage - 1) (in REVERSE graph order)'s finalize -- stage 0:
+// the loss gradient -- down to the next BN node's sums.
+static int g2d_backward(const tcr_g2d* g, const float* params, const float* x, int batch, int global_batch, uint64_t seed, int64_t sample_offset,
+                        void* workspace, size_t workspace_bytes, float* grads, void* stream, int stage) {
     TCR_REQUIRE(g && g->finalized && params && x && workspace && grads && batch > 0, "tcr_g2d_backward: bad argument");
     const G2dWorkspace w = carve2d(*g, batch, true);
     if ((size_t)w.total * sizeof(float) > workspace_bytes) {
@@ -477,19 +523,26 @@ extern "C" int tcr_g2d_backward(const tcr_g2d* g, const float* params, const flo
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* base = static_cast<float*>(workspace);
+    const bool staged = stage >= 0;
+    std::vector<int> rbn;
+    if (staged) { rbn = bn_nodes(*g); std::reverse(rbn.begin(), rbn.end()); }
+    TCR_REQUIRE(!staged || stage <= (int)rbn.size(), "tcr_g2d_backward_stage: bad stage %d", stage);
+    if (stage <= 0) {
     if (hipMemsetAsync(grads, 0, (size_t)g->param_floats * sizeof(float), s) != hipSuccess ||
         hipMemsetAsync(base + w.grad_begin, 0, (size_t)(w.grad_end - w.grad_begin) * sizeof(float), s) != hipSuccess) {
         set_error("tcr_g2d_backward: hipMemsetAsync failed");
         return TCR_ERR_HIP;
     }
-    {   // seed: d loss / d logits
+    }
+    if (stage <= 0) {   // seed: d loss / d logits
         Elt2dArgs a;
         std::memset(&a, 0, sizeof(a));
         a.a = base + w.dlogits; a.out = base + w.grad[g->logits];
         a.planes = (int64_t)batch * g->num_classes; a.c = g->num_classes; a.plane = 1; a.pp = pp_of(1, 1);
         TCR_TRY(launch_eltwise2d(2, a, s));
     }
-    for (int i = (int)g->nodes.size() - 1; i >= 0; --i) {
+    const int istart = staged && stage > 0 ? rbn[stage - 1] : (int)g->nodes.size() - 1;
+    for (int i = istart; i >= 0; --i) {
         const G2dNode& n = g->nodes[i];
         float* G = base + w.grad[i];
         const float* out = base + w.out[i];
@@ -529,16 +582,24 @@ extern "C" int tcr_g2d_backward(const tcr_g2d* g, const float* params, const flo
                 r.mean = base + w.mean[i]; r.invstd = base + w.invstd[i]; r.partial = base + w.partial;
                 r.npos = batch * n.h * n.w; r.c = n.c; r.t = n.h * n.w; r.tp = pp; r.bcast = 0;
                 int nchunk = 0;
-                TCR_TRY(launch_chan_reduce(1, r, &nchunk, s));
+                const bool resume = staged && stage > 0 && i == rbn[stage - 1];       // (its sums were handed over)
+                if (!resume) {
+                    TCR_TRY(launch_chan_reduce(1, r, &nchunk, s));
+                    if (staged) {
+                        TCR_TRY(launch_chan_sums(base + w.partial, nchunk, n.c, reinterpret_cast<double*>(base + w.sums), s));
+                        return TCR_OK;
+                    }
+                }
                 float* kc = base + w.kcoef;
                 const int64_t ks = al64(g->cmax);
                 BnBwdFinalizeArgs f;
-                f.partial = base + w.partial; f.nchunk = nchunk; f.sums = nullptr;
+                f.partial = base + w.partial; f.nchunk = staged ? 0 : nchunk; f.sums = staged ? reinterpret_cast<const double*>(base + w.sums) : nullptr;
                 f.gamma = n.scale ? params + n.gamma_off : nullptr; f.invstd = base + w.invstd[i];
                 f.dgamma = n.scale ? grads + n.gamma_off : nullptr;
                 f.dbeta = n.center ? grads + n.beta_off : base + w.scratch_c;
                 f.k1 = kc; f.k2 = kc + ks; f.k3 = kc + 2 * ks;
-                f.c = n.c; f.count = (double)batch * (double)(n.h * n.w); f.grad_scale = 1.0f;
+                f.c = n.c; f.count = (double)(staged ? global_batch : batch) * (double)(n.h * n.w);
+                f.grad_scale = staged ? (float)((double)batch / (double)global_batch) : 1.0f;
                 TCR_TRY(launch_bn_bwd_finalize(f, s));
                 if (gin0) {
                     BnBwdApplyArgs a;
@@ -588,4 +649,15 @@ extern "C" int tcr_g2d_backward(const tcr_g2d* g, const float* params, const flo
         }
     }
     return TCR_OK;
+}
+
+extern "C" int tcr_g2d_backward(const tcr_g2d* g, const float* params, const float* x, int batch, uint64_t seed, int64_t sample_offset,
+                                void* workspace, size_t workspace_bytes, float* grads, void* stream) {
+    return g2d_backward(g, params, x, batch, batch, seed, sample_offset, workspace, workspace_bytes, grads, stream, -1);
+}
+
+extern "C" int tcr_g2d_backward_stage(const tcr_g2d* g, const float* params, const float* x, int batch, int global_batch, uint64_t seed,
+                                      int64_t sample_offset, void* workspace, size_t workspace_bytes, float* grads, int stage, void* stream) {
+    TCR_REQUIRE(stage >= 0 && global_batch >= batch, "tcr_g2d_backward_stage: bad argument");
+    return g2d_backward(g, params, x, batch, global_batch, seed, sample_offset, workspace, workspace_bytes, grads, stream, stage);
 }

@@ -181,6 +181,7 @@ class TCResNet(_Base):
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self._kver, self._fold_key, self._fold_ss, self._fold_event, self._fold_stream, self._fold_readers = 0, None, None, None, None, {}
         self._wave_feat: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self.handoff = "level"         # cross-replica BN hand-off granularity: "level" (default) or "unit" (tcr_net_*_stage)
         self.reset_bn()
 
     def __del__(self):
@@ -398,6 +399,12 @@ class TCResNet(_Base):
                   logits.data_ptr(), probs.data_ptr(), loss.data_ptr())
         if sync_hook is None:
             self.lib.check(self.lib.tcr_net_forward_train(*common, self._stream()), "tcr_net_forward_train")
+        elif self.handoff == "unit":      # one hand-off per BN unit (tcr_net_*_stage)
+            ns = self.lib.tcr_net_num_stages(self._h, 0)
+            for st in range(ns):
+                self.lib.check(self.lib.tcr_net_forward_train_stage(*common, st, self._stream()), "tcr_net_forward_train_stage")
+                if st < ns - 1:
+                    sync_hook(self._stage_sums(0, st, ws, b))
         else:           # cross-replica BN: one hand-off per dependency level (a block's shortcut conv rides with its first conv)
             nl = self.lib.tcr_net_num_levels(self._h, 0)
             for lv in range(nl):
@@ -429,6 +436,14 @@ class TCResNet(_Base):
         if sync_hook is None:
             self.lib.check(self.lib.tcr_net_backward(self._h, self.params.data_ptr(), feat.data_ptr(), b, ws.data_ptr(),
                                                      ws.numel() * 4, self.grads.data_ptr(), self._stream()), "tcr_net_backward")
+        elif self.handoff == "unit":
+            ns = self.lib.tcr_net_num_stages(self._h, 1)
+            for st in range(ns):
+                self.lib.check(self.lib.tcr_net_backward_stage(self._h, self.params.data_ptr(), feat.data_ptr(), b, gb,
+                                                               ws.data_ptr(), ws.numel() * 4, self.grads.data_ptr(), st,
+                                                               self._stream()), "tcr_net_backward_stage")
+                if st < ns - 1:
+                    sync_hook(self._stage_sums(1, st, ws, b))
         else:
             nl = self.lib.tcr_net_num_levels(self._h, 1)
             for lv in range(nl):
@@ -875,25 +890,44 @@ class Graph2D(_Base):
                       global_batch: Optional[int] = None, label_smoothing: float = 0.0, sync_hook=None):
         """Train-mode forward; returns (logits, probs, loss_sum) like TCResNet.forward_train.  Dropout probabilities belong to the
         graph (they are fixed where the reference builds it), so `keep_prob` is not read here."""
-        if sync_hook is not None:
-            raise NotImplementedError("cross-replica BN statistics are built for TC-ResNet only; these replicas use per-replica BN")
         self._check_tensor(labels, "labels")
         x = self.input_from_features(feat)
         b = x.shape[0]
+        gb = int(global_batch or b)
         ws = self.workspace(b, True)
         logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
         probs = torch.empty_like(logits)
         loss = torch.zeros(2, dtype=torch.float32, device=self.device)
-        self.lib.check(self.lib.tcr_g2d_forward_train(self._h, self.params.data_ptr(), self.stats.data_ptr(), x.data_ptr(), labels.data_ptr(), b,
-                                                      int(global_batch or b), int(seed), int(sample_offset), float(label_smoothing),
-                                                      ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), loss.data_ptr(),
-                                                      self._stream()), "tcr_g2d_forward_train")
-        self._last = (x, b, int(seed), int(sample_offset))
+        common = (self._h, self.params.data_ptr(), self.stats.data_ptr(), x.data_ptr(), labels.data_ptr(), b, gb, int(seed), int(sample_offset),
+                  float(label_smoothing), ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), loss.data_ptr())
+        if sync_hook is None:
+            self.lib.check(self.lib.tcr_g2d_forward_train(*common, self._stream()), "tcr_g2d_forward_train")
+        else:           # cross-replica BN: the forward stops behind every BN node's statistics (tcr_g2d_*_stage)
+            ns = self.lib.tcr_g2d_num_stages(self._h)
+            for st in range(ns):
+                self.lib.check(self.lib.tcr_g2d_forward_train_stage(*common, st, self._stream()), "tcr_g2d_forward_train_stage")
+                if st < ns - 1:
+                    sync_hook(self._stage_sums(0, st, ws, b))
+        self._last = (x, b, int(seed), int(sample_offset), gb, sync_hook)
         return logits, probs, loss[0]
 
+    def _stage_sums(self, backward: int, stage: int, ws: torch.Tensor, batch: int) -> torch.Tensor:
+        ptr, n = C.c_void_p(), C.c_int64()
+        self.lib.check(self.lib.tcr_g2d_stage_sums(self._h, backward, stage, ws.data_ptr(), batch, C.byref(ptr), C.byref(n)), "tcr_g2d_stage_sums")
+        off = (ptr.value - ws.data_ptr()) // 4
+        return ws[off:off + 2 * n.value].view(torch.float64)
+
     def backward(self) -> torch.Tensor:
-        x, b, seed, off = self._last
+        x, b, seed, off, gb, sync_hook = self._last
         ws = self.workspace(b, True)
-        self.lib.check(self.lib.tcr_g2d_backward(self._h, self.params.data_ptr(), x.data_ptr(), b, seed, off, ws.data_ptr(), ws.numel() * 4,
-                                                 self.grads.data_ptr(), self._stream()), "tcr_g2d_backward")
+        if sync_hook is None:
+            self.lib.check(self.lib.tcr_g2d_backward(self._h, self.params.data_ptr(), x.data_ptr(), b, seed, off, ws.data_ptr(), ws.numel() * 4,
+                                                     self.grads.data_ptr(), self._stream()), "tcr_g2d_backward")
+        else:
+            ns = self.lib.tcr_g2d_num_stages(self._h)
+            for st in range(ns):
+                self.lib.check(self.lib.tcr_g2d_backward_stage(self._h, self.params.data_ptr(), x.data_ptr(), b, gb, seed, off, ws.data_ptr(),
+                                                               ws.numel() * 4, self.grads.data_ptr(), st, self._stream()), "tcr_g2d_backward_stage")
+                if st < ns - 1:
+                    sync_hook(self._stage_sums(1, st, ws, b))
         return self.grads

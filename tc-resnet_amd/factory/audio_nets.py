@@ -125,11 +125,12 @@ class AudioNetModel(TFModel):
         if self._loss_sum is not None:
             model_loss = self._mean_loss
         else:
-            y = labels
-            ls = float(getattr(self.args, "label_smoothing", 0.0))
-            if ls > 0:
-                y = y * (1.0 - ls) + ls / y.shape[-1]
-            model_loss = -(y * torch.log_softmax(logits, dim=-1)).sum(dim=-1).mean()
+            eng, b = self.engine, int(logits.shape[0])
+            scratch = torch.empty(b + 1, dtype=torch.float32, device=logits.device)
+            lg, lb = logits.contiguous(), labels.to(torch.float32).contiguous()
+            eng.lib.check(eng.lib.tcr_xent_loss_sum(lg.data_ptr(), lb.data_ptr(), b, int(logits.shape[1]), float(getattr(self.args, "label_smoothing", 0.0)),
+                                                    scratch.data_ptr(), scratch[b:].data_ptr(), eng._stream()), "tcr_xent_loss_sum")
+            model_loss = scratch[b] / float(b)
         total = model_loss + self.engine.l2_loss(self.args.weight_decay)
         return total, model_loss, {}
 

@@ -384,7 +384,7 @@ def check_small_batch(lib, batch, name="TCResNet8", width=1.0, tag="4020", seeds
     return worst
 
 
-def check_staged_equals_unstaged(lib, name, width, batch, tag="4020", keep_prob=0.5):
+def check_staged_equals_unstaged(lib, name, width, batch, tag="4020", keep_prob=0.5, handoff="level"):
     """One replica: forward_train / backward run stage by stage through the sync-BN hand-off API with an identity hook must be
     BITWISE the unstaged path (logits, loss, every gradient, moving statistics)."""
     cfg = R.FRONTEND_4020 if tag == "4020" else R.FRONTEND_3010
@@ -401,13 +401,15 @@ def check_staged_equals_unstaged(lib, name, width, batch, tag="4020", keep_prob=
     seen = []
     for hook in (None, lambda sums: seen.append((sums.dtype, sums.numel()))):
         net = make_net(lib, name, width, fe.n_frames, p, s)
+        net.handoff = handoff
         logits, probs, loss = net.forward_train(feat, labels, keep_prob=keep_prob, seed=11, sync_hook=hook)
         g = net.backward().clone()
         outs.append((logits.clone(), probs.clone(), loss.clone(), g, net.stats.clone()))
     # one hand-off per dependency level each way: conv0, and per block (shortcut + first conv) | second conv
     nblocks = len(R.tcresnet_channels(name, float(width))) - 1
     assert lib.tcr_net_num_levels(net._h, 0) - 1 == 1 + 2 * nblocks == lib.tcr_net_num_levels(net._h, 1) - 1
-    assert len(seen) == 2 * (1 + 2 * nblocks) and all(dt == torch.float64 for dt, _ in seen)
+    nbn = len([c for c in arch.convs() if c.bn])
+    assert len(seen) == (2 * (1 + 2 * nblocks) if handoff == "level" else 2 * nbn) and all(dt == torch.float64 for dt, _ in seen)
     for a, b, what in zip(outs[0], outs[1], ("logits", "probs", "loss", "grads", "moving stats")):
         assert torch.equal(a, b), f"staged {what} differ from the unstaged run (max |d| {float((a - b).abs().max())})"
     assert torch.isfinite(outs[0][3]).all()

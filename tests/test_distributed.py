@@ -50,6 +50,36 @@ def _setup_dscnn(lib, size="S"):
     return fe, net
 
 
+def _setup_graph(lib, variant):
+    """A graph-engine family (Res15Narrow: 19 channels, dilated 3 x 3 convs, BN without scale) on a small 16 x 10 feature plane."""
+    import tcresnet_amd as T
+    from tcresnet_amd import runtime
+    from tcresnet_amd.audio_nets import res, tc_resnet
+    dev = "cuda" if lib.kind == "hip" else "cpu"
+    runtime.set_default(lib, dev)
+    tc_resnet.reset_engines()
+    fe = T.Frontend(window_size_samples=960, window_stride_samples=960, num_mfccs=10, lib=lib, device=None if dev == "cpu" else dev)
+    net = res.get_engine(variant, fe.n_frames, 10, 12)
+    net.init_variables(3)
+    rng = np.random.RandomState(4)
+    sd = {k: v for k, v in net.state_dict().items() if k in net.tensors}
+    for k, v in sd.items():
+        if net.tensors[k].kind in (1, 4):
+            sd[k] = rng.uniform(0.5, 1.5, v.shape).astype(np.float32)
+        elif net.tensors[k].kind in (2, 3):
+            sd[k] = rng.uniform(-0.5, 0.5, v.shape).astype(np.float32)
+    net.load_state_dict(sd)
+    return fe, net
+
+
+def _make(lib, name, width):
+    if name == "DSCNN":
+        return _setup_dscnn(lib, width)
+    if name.startswith("Res"):
+        return _setup_graph(lib, name)
+    return _setup(lib, name, width)
+
+
 def _worker(rank, world, port, sync_bn, out_dir, kind, name, width, b):
     import sys
     sys.path.insert(0, ROOT)
@@ -57,7 +87,7 @@ def _worker(rank, world, port, sync_bn, out_dir, kind, name, width, b):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = _lib_of(kind)
-    fe, net = _setup_dscnn(lib, width) if name == "DSCNN" else _setup(lib, name, width)
+    fe, net = _make(lib, name, width)
     wav = torch.from_numpy(R.synth_waveforms(b, seed=77, start=rank * b)).to(fe.device)
     lab = torch.from_numpy(R.synth_labels(b, start=rank * b)).to(fe.device)
     dp = DataParallel(net, sync_bn=sync_bn)
@@ -69,7 +99,8 @@ def _worker(rank, world, port, sync_bn, out_dir, kind, name, width, b):
     torch.cuda.synchronize() if fe.device.type == "cuda" else None
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), grads=g.cpu().numpy(), logits=logits.cpu().numpy(), loss=float(mean_loss),
              params=net.params.cpu().numpy(), stats=net.stats.cpu().numpy(), collectives=dp.collectives,
-             handoffs=(2 * lib.tcr_dscnn_num_units(net._h) if name == "DSCNN" else lib.tcr_net_num_levels(net._h, 0) + lib.tcr_net_num_levels(net._h, 1) - 2))
+             handoffs=(2 * lib.tcr_dscnn_num_units(net._h) if name == "DSCNN" else 2 * (lib.tcr_g2d_num_stages(net._h) - 1) if name.startswith("Res")
+                       else lib.tcr_net_num_levels(net._h, 0) + lib.tcr_net_num_levels(net._h, 1) - 2))
     dist.destroy_process_group()
 
 
@@ -98,7 +129,7 @@ def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b, grad_tol=2e-5):
     if sync_bn:
         assert np.array_equal(r[0]["stats"], r[1]["stats"])
     # single process, global batch of 2b, same dropout stream (masks are indexed by global sample id)
-    fe, net = _setup_dscnn(lib, width) if name == "DSCNN" else _setup(lib, name, width)
+    fe, net = _make(lib, name, width)
     wav = torch.from_numpy(R.synth_waveforms(2 * b, seed=77)).to(fe.device)
     lab = torch.from_numpy(R.synth_labels(2 * b)).to(fe.device)
     logits, probs, loss_sum = net.forward_train(fe(wav), lab, keep_prob=0.5, seed=3)
@@ -119,6 +150,17 @@ def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b, grad_tol=2e-5):
 @pytest.mark.parametrize("sync_bn", [True, False])
 def test_two_replicas_match_global_batch(emu_lib, tmp_path, sync_bn):
     _two_replicas(emu_lib, "emu", tmp_path, sync_bn, "TCResNet8", 1.0, 3)
+
+
+def test_two_replicas_match_global_batch_graph_engine(emu_lib, tmp_path):
+    """A graph-engine family with cross-replica BN statistics (tcr_g2d_*_stage): two replicas == the single-device global batch."""
+    from tcresnet_amd import runtime
+    from tcresnet_amd.audio_nets import tc_resnet
+    try:
+        _two_replicas(emu_lib, "emu", tmp_path, True, "Res15Narrow", None, 2, grad_tol=5e-5)
+    finally:
+        runtime.set_default(None, None)
+        tc_resnet.reset_engines()
 
 
 def test_two_replicas_match_global_batch_dscnn(emu_lib, tmp_path):

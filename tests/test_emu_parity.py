@@ -121,6 +121,7 @@ def test_small_batches_against_live_oracle(emu_lib, batch):
 
 def test_staged_sync_bn_api_is_bitwise_the_unstaged_path(emu_lib):
     Cm.check_staged_equals_unstaged(emu_lib, "TCResNet8", 1.0, batch=5)
+    Cm.check_staged_equals_unstaged(emu_lib, "TCResNet8", 1.0, batch=5, handoff="unit")
 
 
 def test_wide_net_training(emu_lib):
@@ -135,7 +136,7 @@ def test_backward_phases_opt_in(emu_lib):
         emu_lib.tcr_tune(9, 1)
         Cm.check_train(emu_lib, "tcresnet8_1.0_4020.npz", "TCResNet8", 1.0, steps=1)
         Cm.check_train(emu_lib, "tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, steps=1)
-        Cm.check_staged_equals_unstaged(emu_lib, "TCResNet8", 1.0, batch=5)
+        Cm.check_staged_equals_unstaged(emu_lib, "TCResNet8", 1.0, batch=5, handoff="unit")     # (the level hand-off runs the per-layer backward)
     finally:
         emu_lib.tcr_tune(9, 0)
 

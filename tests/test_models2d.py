@@ -222,3 +222,27 @@ def test_kws_checkpoint_holds_matmul_weights_in_their_tf_shape(rt, tmp_path):
         if bad[fc[0]].shape != sd[fc[0]].shape:
             with pytest.raises(ValueError, match="Total size"):
                 Ckpt(other, logger=logging.getLogger("t")).load(prefix + "bad")
+
+
+def test_graph_engine_cross_replica_bn_staged_equals_unstaged(rt):
+    """Graph engine through the cross-replica BN hand-off API (tcr_g2d_*_stage) with an identity hook at one replica: BITWISE the
+    unstaged run (logits, loss, every gradient, moving statistics); one hand-off per BN node each way, float64 sums."""
+    from tcresnet_amd.audio_nets import res
+    variant = "Res15Narrow" if rt.kind == "emu" else "Res8"
+    t, f, b = (12, 10, 3) if rt.kind == "emu" else (98, 40, 8)
+    eng = res.get_engine(variant, t, f, 12)
+    sd = _randomise(eng, 4)
+    dev = Cm.device_of(rt)
+    x = np.random.RandomState(2).uniform(-2.0, 2.0, (b, t, f)).astype(np.float32)
+    planar = T.features_to_planar(torch.from_numpy(x).to(dev), lib=rt)
+    labels = torch.from_numpy(R.synth_labels(b).astype(np.float32)).to(dev)
+    outs, seen = [], []
+    for hook in (None, lambda sums: seen.append((sums.dtype, sums.numel()))):
+        eng.load_state_dict(sd)
+        logits, probs, loss = eng.forward_train(planar, labels, seed=5, sync_hook=hook)
+        g = eng.backward().clone()
+        outs.append((logits.clone(), probs.clone(), loss.clone(), g, eng.stats.clone()))
+    nbn = rt.tcr_g2d_num_stages(eng._h) - 1
+    assert nbn > 0 and len(seen) == 2 * nbn and all(dt == torch.float64 for dt, _ in seen)
+    for a, c, what in zip(outs[0], outs[1], ("logits", "probs", "loss", "grads", "moving stats")):
+        assert torch.equal(a, c), f"staged {what} differ from the unstaged run (max |d| {float((a - c).abs().max())})"
