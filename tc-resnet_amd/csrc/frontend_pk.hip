@@ -536,7 +536,11 @@ int launch_frontend_pk(int nc, const FrontendArgs& a0, hipStream_t s) {
         const int fpr = 4096 / nc, max_rounds = 64 / fpr, slots = 2 * device_cus();
         int best = max_rounds;
         float best_cost = 3.4e38f;
-        for (int r = max_rounds; r >= (max_rounds + 1) / 2; --r) {
+        // small batches (fewer chunks than half the slots even at one round per chunk... the latency regime): down to ONE round per
+        // chunk, so that an utterance's frames spread over several workgroups instead of queueing in one (batch 1: 7 workgroups x 1
+        // round instead of 1 workgroup x 7 rounds)
+        const int r_min = ceil_div(a.total_frames, fpr) <= slots / 2 ? 1 : (max_rounds + 1) / 2;
+        for (int r = max_rounds; r >= r_min; --r) {
             const int chunks = ceil_div(a.total_frames, r * fpr);
             const int full = chunks / slots, rest = chunks % slots;
             const float gens = (float)full + (rest == 0 ? 0.f : (2 * rest <= slots ? 0.6f : 1.f));
