@@ -268,6 +268,10 @@ int tcr_dscnn_backward(const tcr_dscnn* net, const float* params, const float* f
  * to take the float64 oracle's gradient on the kernels' side of ReLU inputs within round-off of zero. */
 int tcr_dscnn_num_units(const tcr_dscnn* net);
 int tcr_dscnn_unit_output(const tcr_dscnn* net, int unit, int batch, int64_t* offset, int* channels, int* positions, int* padded);
+/* The default training path never writes that activation (its consumers apply BN + ReLU to the unit's raw conv output as they read it,
+ * TCR_TUNE_DS_TRAIN): this call computes it from the raw output and the batch statistics the last training forward left in the workspace,
+ * into the slot tcr_dscnn_unit_output() names.  Replaces nothing in the reference (test / inspection hook for `endpoints`). */
+int tcr_dscnn_materialize_unit(const tcr_dscnn* net, int unit, int batch, void* workspace, size_t workspace_bytes, void* stream);
 int tcr_dscnn_num_stages(const tcr_dscnn* net);
 int tcr_dscnn_stage_sums(const tcr_dscnn* net, int backward, int stage, void* workspace, int batch, double** sums_dev, int64_t* n_doubles);
 int tcr_dscnn_forward_train_stage(const tcr_dscnn* net, const float* params, float* stats, const float* feat, const float* labels,
@@ -406,7 +410,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_BWD_MASK = 12,   /* BN backward: 0 a unit's own ReLU mask recomputed from its raw conv output ([fmaf(y, scale, shift) > 0], bitwise the activation's; default), 1 read back from the stored activation, 2: as 0 with the scalar (one element per thread) elementwise BN kernels instead of the 16-byte ones (bitwise the same), 3: also the scalar per-channel reduction kernel (another summation order), 4: the 16-byte reduction kernel also where its grid would be small (tests) */
        TCR_TUNE_FE_GRID = 13,    /* front-end: cap on the number of persistent workgroups (0: two per CU). 256 = one per CU, which leaves half of every CU's LDS and registers to a co-resident network kernel on another stream */
        TCR_TUNE_FUSED_GRID = 14, /* fused eval network: cap on the number of persistent workgroups (0: as many as the LDS allows per CU) */
-       TCR_TUNE_COUNT = 15 };
+       TCR_TUNE_DS_TRAIN = 15,   /* DS-CNN training: 0 normalised activations never materialised where every consumer has the form (172 / 276-channel nets): consumers apply BN + ReLU to the raw conv outputs, batch statistics and backward sums come from conv / data-gradient epilogues (default); 1 the materialising path (statistics reduce -> finalize -> normalise, backward reduce); 2: as 0, but every unit's BN backward by a bn_bwd_apply pass (default 0: conv_1's filter gradient computes dy where it reads it); 3: as 0, the depthwise units' kernels too */
+       TCR_TUNE_COUNT = 16 };
 int tcr_tune(int knob, int value);
 
 #ifdef __cplusplus

@@ -102,6 +102,7 @@ _PROTOTYPES = {
     "tcr_dscnn_backward": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P, _P]),
     "tcr_dscnn_num_units": (C.c_int, [_P]),
     "tcr_dscnn_unit_output": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tcr_dscnn_materialize_unit": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "tcr_dscnn_num_stages": (C.c_int, [_P]),
     "tcr_dscnn_stage_sums": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "tcr_dscnn_forward_train_stage": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, C.c_size_t, _P, _P, _P, C.c_int, _P]),

@@ -237,6 +237,11 @@ int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t 
 // order: chunk k goes to slice k % nparts, the slices are then added in order), spread over the whole workgroup; or
 // the pre-reduced sums (sync BN).  Returns through s_out[which * cb + (ch - c0)]; ends with a barrier.
 constexpr int kBnCB = 32;           // channels per finalize workgroup (64 columns x 8 slices of chunks)
+// Conv epilogues (EpiSums) leave one row per workgroup / per utterance -- thousands, not <= 512: two channels per workgroup
+// there (4 columns x 128 slices, sixteen times the workgroups), so that a thread adds ~32 rows, sixteen loads in flight (with the
+// 32-channel geometry a finalize over 4160 rows took 47 us, in the backward's dependency chain).  The slice order is a function
+// of the row count only, the same in every kernel that reduces the rows (finalize, chan_sums).
+int bn_finalize_cb(int nchunk) { return nchunk > 1024 ? 2 : kBnCB; }
 
 __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk, const double* sums, int nc, int c0, int cb,
                                                 double* s_slices, double* s_out) {
@@ -252,6 +257,13 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk
             const float* src = partial + (size_t)which * nc + ch;
             const size_t rstride = (size_t)2 * nc;
             int k = part;
+            for (; k + 15 * nparts < nchunk; k += 16 * nparts) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(k + u * nparts) * rstride];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += (double)v[u];
+            }
             for (; k + 7 * nparts < nchunk; k += 8 * nparts) {
                 float v[8];
 #pragma unroll
@@ -280,10 +292,10 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk
 // sums[2][C] (double) = the per-workgroup partial rows added up exactly as the finalize kernels do it themselves (same
 // channel blocks, same slice order), so that "reduce, hand the sums to the host, finalize" is bitwise the unstaged path.
 // The host all-reduces these doubles across replicas (sync BN) before the finalize kernels.
-__global__ __launch_bounds__(512) void chan_sums_kernel(const float* __restrict__ partial, int nchunk, int c, double* __restrict__ sums) {
+__global__ __launch_bounds__(512) void chan_sums_kernel(const float* __restrict__ partial, int nchunk, int c, double* __restrict__ sums, int cbw) {
     __shared__ double s_slices[512];
     __shared__ double s_tot[2 * kBnCB];
-    const int c0 = blockIdx.x * kBnCB, cb = min(kBnCB, c - c0);
+    const int c0 = blockIdx.x * cbw, cb = min(cbw, c - c0);
     reduce_partials(partial, nchunk, nullptr, c, c0, cb, s_slices, s_tot);
     for (int i = threadIdx.x; i < 2 * cb; i += blockDim.x) {
         const int which = i / cb;
@@ -292,14 +304,15 @@ __global__ __launch_bounds__(512) void chan_sums_kernel(const float* __restrict_
 }
 
 int launch_chan_sums(const float* partial, int nchunk, int c, double* sums, hipStream_t s) {
-    hipLaunchKernelGGL(chan_sums_kernel, dim3(ceil_div(c, kBnCB)), dim3(512), 0, s, partial, nchunk, c, sums);
+    const int cbw = bn_finalize_cb(nchunk);
+    hipLaunchKernelGGL(chan_sums_kernel, dim3(ceil_div(c, cbw)), dim3(512), 0, s, partial, nchunk, c, sums, cbw);
     return check_launch("chan_sums_kernel");
 }
 
 __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a) {
     __shared__ double s_slices[512];
     __shared__ double s_tot[2 * kBnCB];
-    const int c0 = blockIdx.x * kBnCB, cb = min(kBnCB, a.c - c0);
+    const int c0 = blockIdx.x * a.cbw, cb = min(a.cbw, a.c - c0);
     reduce_partials(a.partial, a.nchunk, a.sums, a.c, c0, cb, s_slices, s_tot);
     for (int i = threadIdx.x; i < cb; i += blockDim.x) {
         const int c = c0 + i;
@@ -322,8 +335,10 @@ __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a
     }
 }
 
-int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(a.c, kBnCB)), dim3(512), 0, s, a);
+int launch_bn_finalize(const BnFinalizeArgs& a0, hipStream_t s) {
+    BnFinalizeArgs a = a0;
+    a.cbw = bn_finalize_cb(a.nchunk);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(a.c, a.cbw)), dim3(512), 0, s, a);
     return check_launch("bn_finalize_kernel");
 }
 
@@ -399,7 +414,7 @@ int launch_bn_apply(const BnApplyArgs& a0, hipStream_t s) {
 __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const BnBwdFinalizeArgs a) {
     __shared__ double s_slices[512];
     __shared__ double s_tot[2 * kBnCB];
-    const int c0 = blockIdx.x * kBnCB, cb = min(kBnCB, a.c - c0);
+    const int c0 = blockIdx.x * a.cbw, cb = min(a.cbw, a.c - c0);
     reduce_partials(a.partial, a.nchunk, a.sums, a.c, c0, cb, s_slices, s_tot);
     for (int i = threadIdx.x; i < cb; i += blockDim.x) {
         const int c = c0 + i;
@@ -412,8 +427,10 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const BnBwdFinaliz
     }
 }
 
-int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(a.c, kBnCB)), dim3(512), 0, s, a);
+int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a0, hipStream_t s) {
+    BnBwdFinalizeArgs a = a0;
+    a.cbw = bn_finalize_cb(a.nchunk);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(a.c, a.cbw)), dim3(512), 0, s, a);
     return check_launch("bn_bwd_finalize_kernel");
 }
 

@@ -11,6 +11,7 @@
 // the matrix-core kernels of mfma.hip / head.hip; the depthwise 3x3 is a small VALU stencil.  Conv bias and
 // eval-mode BN are folded into one per-channel scale/shift applied in the producing kernel's epilogue.
 // Internal layout: planar [b][c][HALO + h*W + w] (row length tcr_padded_len(H*W)).
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,6 +32,7 @@ struct DsConv1Args {
     int cout, h_in, w_in, tp_in, oh, ow, pp;
     int kh, sh, sw, pad_t, pad_l;
     int relu;               // scale == nullptr: y = acc + shift (conv bias, train-mode raw output)
+    EpiSums sums;           // (dscnn_conv1_kernel) forward sums of y, y^2 from the epilogue: one partial row per 256 positions
 };
 
 // Epilogue of both conv_1 kernels.  One 64-bit row pointer per position tile and one 32-bit channel offset per
@@ -135,7 +137,41 @@ __global__ __launch_bounds__(256) void dscnn_conv1_kernel(const DsConv1Args a) {
         for (int nt = 0; nt < 4; ++nt) bf[nt] = bn[nt];
     }
     conv1_store<MT>(a, acc, pos0, cot0, r, q);
+    if (a.sums.partial) {
+        // BN batch statistics of the tile while it is in registers (train-mode raw output: y = acc + bias): a channel's 16
+        // positions of a column tile are the 16 lanes of a DPP row; the four waves (4 x 64 positions, same channels) meet in LDS
+        __shared__ float s_red[4][2][MT * 16];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = min((cot0 + m) * 16 + q * 4 + reg, a.cout - 1);
+                const float sc = a.scale ? a.scale[cc] : 1.0f, sf = a.shift[cc];
+                float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float v = fmaf(acc[m][nt][reg], sc, sf);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (pos0 + nt * 16 + r >= a.npos) v = 0.f;
+                    q1 += v;
+                    q2 = fmaf(v, v, q2);
+                }
+                q1 = row16_sum(q1);
+                q2 = row16_sum(q2);
+                if (r == 0) { s_red[wave][0][m * 16 + q * 4 + reg] = q1; s_red[wave][1][m * 16 + q * 4 + reg] = q2; }
+            }
+        __syncthreads();
+        if (threadIdx.x < 2 * MT * 16) {
+            const int which = threadIdx.x / (MT * 16), j = threadIdx.x - which * (MT * 16);
+            const int co = cot0 * 16 + j;
+            if (co < a.cout)
+                a.sums.partial[((size_t)blockIdx.x * 2 + which) * a.cout + co] =
+                    (s_red[0][which][j] + s_red[1][which][j]) + (s_red[2][which][j] + s_red[3][which][j]);
+        }
+    }
 }
+
+static int dscnn_conv1_sum_rows(int npos) { return ceil_div(npos, 256); }
 
 static int launch_dscnn_conv1(const DsConv1Args& a, hipStream_t s) {
     const int tiles = ceil_div(a.cout, 16);
@@ -153,6 +189,12 @@ struct DsDwArgs {
     int64_t total;          // B * C * OH * OW
     int c, h_in, w_in, ppi, oh, ow, ppo, sh, sw, pad_t, pad_l;
     int relu;
+    // LDS kernels (DS-CNN training): x is the producing unit's RAW conv output -- the image is built from
+    // relu(x * in_scale[c] + in_shift[c]) (bn_apply's expression; the padding stays zero) --, and the epilogue leaves the sums of
+    // y, y^2 per plane: partial[n][2][C], one row per utterance (EpiSums, forward form)
+    const float* in_scale = nullptr;
+    const float* in_shift = nullptr;
+    EpiSums sums;
 };
 
 __global__ __launch_bounds__(256) void dscnn_depthwise_kernel(const DsDwArgs a) {
@@ -202,6 +244,8 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds_kernel(const DsDwArgs
     const float* xr = a.x + (size_t)row * a.ppi + kHalo;
     float* im = img + plane * isz;
     const float inv_c = 1.0f / (float)img_c;
+    const bool aff = a.in_scale != nullptr;
+    const float isc = aff ? a.in_scale[c] : 1.0f, isf = aff ? a.in_shift[c] : 0.f;
     // batches of 8 independent (clamped, unconditional) loads per lane: a rolled loop waits out one global round trip
     // per 16 image elements
     for (int j0 = t16; j0 < isz; j0 += 16 * 8) {
@@ -212,7 +256,8 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds_kernel(const DsDwArgs
             const int rr = fast_div(j, img_c, inv_c), cc = j - rr * img_c;
             const int h = rr - a.pad_t, w = cc - a.pad_l;
             const bool in = h >= 0 && h < a.h_in && w >= 0 && w < a.w_in;
-            const float xv = xr[in ? h * a.w_in + w : 0];
+            float xv = xr[in ? h * a.w_in + w : 0];
+            if (aff) xv = fmaxf(fmaf(xv, isc, isf), 0.f);
             v[i] = in ? xv : 0.f;
         }
 #pragma unroll
@@ -228,6 +273,7 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds_kernel(const DsDwArgs
     const int P = a.oh * a.ow;
     const float inv_ow = 1.0f / (float)a.ow;
     float* yr = a.y + (size_t)row * a.ppo + kHalo;
+    float q1 = 0.f, q2 = 0.f;
     for (int pos0 = t16; pos0 < P; pos0 += 16 * 5) {        // (13 x 5 maps: one trip, the 45 LDS reads of a lane in flight together)
         float s[5];
 #pragma unroll
@@ -243,8 +289,22 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds_kernel(const DsDwArgs
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const float v = fmaf(s[i], sc, sh);
-            if (pos0 + 16 * i < P) yr[pos0 + 16 * i] = a.relu ? fmaxf(v, 0.f) : v;
+            float v = fmaf(s[i], sc, sh);
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (pos0 + 16 * i < P) {
+                yr[pos0 + 16 * i] = v;
+                q1 += v;
+                q2 = fmaf(v, v, q2);
+            }
+        }
+    }
+    if (a.sums.partial) {       // (a plane's 16 lanes are one DPP row; `live` is uniform over it)
+        q1 = row16_sum(q1);
+        q2 = row16_sum(q2);
+        if (t16 == 0) {
+            const size_t n = (size_t)(row / a.c);
+            a.sums.partial[(n * 2 + 0) * a.c + c] = q1;
+            a.sums.partial[(n * 2 + 1) * a.c + c] = q2;
         }
     }
 }
@@ -384,19 +444,22 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds2_kernel(const DsDwArg
     int row[2];
     bool live[2];
     float v[2][8];
+    const bool aff = a.in_scale != nullptr;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
         const int rr0 = (int)blockIdx.x * 32 + g + 16 * pl;
         live[pl] = rr0 < rows;
         row[pl] = min(rr0, rows - 1);
         const float* xr = a.x + (size_t)row[pl] * a.ppi + kHalo;
+        const float isc = aff ? a.in_scale[row[pl] % a.c] : 1.0f, isf = aff ? a.in_shift[row[pl] % a.c] : 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int j = min(t16 + 16 * i, isz - 1);
             const int rr = fast_div(j, img_c, inv_c), cc = j - rr * img_c;
             const int h = rr - a.pad_t, w = cc - a.pad_l;
             const bool in = h >= 0 && h < a.h_in && w >= 0 && w < a.w_in;
-            const float xv = xr[in ? h * a.w_in + w : 0];
+            float xv = xr[in ? h * a.w_in + w : 0];
+            if (aff) xv = fmaxf(fmaf(xv, isc, isf), 0.f);
             v[pl][i] = in ? xv : 0.f;
         }
     }
@@ -418,6 +481,7 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds2_kernel(const DsDwArg
         const float sc = a.scale ? a.scale[c] : 1.0f, sh = a.shift[c];
         const float* im = img + (g + 16 * pl) * isz;
         float* yr = a.y + (size_t)row[pl] * a.ppo + kHalo;
+        float q1 = 0.f, q2 = 0.f;
         for (int pos0 = t16; pos0 < P; pos0 += 16 * 5) {
             float s[5];
 #pragma unroll
@@ -433,8 +497,22 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds2_kernel(const DsDwArg
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                const float o = fmaf(s[i], sc, sh);
-                if (pos0 + 16 * i < P) yr[pos0 + 16 * i] = a.relu ? fmaxf(o, 0.f) : o;
+                float o = fmaf(s[i], sc, sh);
+                if (a.relu) o = fmaxf(o, 0.f);
+                if (pos0 + 16 * i < P) {
+                    yr[pos0 + 16 * i] = o;
+                    q1 += o;
+                    q2 = fmaf(o, o, q2);
+                }
+            }
+        }
+        if (a.sums.partial) {       // (a plane's 16 lanes are one DPP row; live[pl] is uniform over it)
+            q1 = row16_sum(q1);
+            q2 = row16_sum(q2);
+            if (t16 == 0) {
+                const size_t n = (size_t)(row[pl] / a.c);
+                a.sums.partial[(n * 2 + 0) * a.c + c] = q1;
+                a.sums.partial[(n * 2 + 1) * a.c + c] = q2;
             }
         }
     }
@@ -452,20 +530,32 @@ static int launch_dscnn_depthwise(const DsDwArgs& d, int batch, hipStream_t s) {
         hipLaunchKernelGGL(dscnn_depthwise_lds_kernel, dim3(ceil_div(rows, 16)), dim3(256), lds, s, d, rows, img_r, img_c);
         return check_launch("dscnn_depthwise_lds_kernel");
     }
+    if (d.in_scale || d.sums.partial) { set_error("dscnn depthwise: in-affine / epilogue sums need the LDS kernels"); return TCR_ERR_ARG; }
     hipLaunchKernelGGL(dscnn_depthwise_kernel, dim3((unsigned)ceil_div64((int64_t)batch * d.c, 4)), dim3(256), 0, s, d);
     return check_launch("dscnn_depthwise_kernel");
 }
 
+static bool dscnn_depthwise_lds_covers(int oh, int ow, int sh, int sw) {
+    return (size_t)16 * ((oh - 1) * sh + 3) * ((ow - 1) * sw + 3) * sizeof(float) <= 64 * 1024;
+}
+
 // pooled[b][c][HALO] = mean over the P positions of plane (b, c); feeds head_fwd_kernel with T = 1 when the map is large
 // (DS-CNN: 13 x 5 = 65).
-__global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ pooled, int64_t rows, int p, int pp) {
+__global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ pooled, int64_t rows, int p, int pp,
+                                                         const float* __restrict__ in_scale = nullptr, const float* __restrict__ in_shift = nullptr, int c = 1) {
     // 16 lanes per plane (16 planes per workgroup: more rows in flight than one wavefront per 65-element plane); the 16
     // partial sums are combined with a fixed xor tree
     const int t16 = threadIdx.x & 15;
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const float* xr = x + (row < rows ? row : rows - 1) * pp + kHalo;
     float s = 0.f;
-    for (int i = t16; i < p; i += 16) s += xr[i];
+    if (in_scale) {             // x is a raw train-mode conv output: pool relu(x * in_scale[ch] + in_shift[ch])
+        const int ch = (int)((row < rows ? row : rows - 1) % c);
+        const float sc = in_scale[ch], sf = in_shift[ch];
+        for (int i = t16; i < p; i += 16) s += fmaxf(fmaf(xr[i], sc, sf), 0.f);
+    } else {
+        for (int i = t16; i < p; i += 16) s += xr[i];
+    }
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m);
     if (t16 == 0 && row < rows) pooled[row * (1 + 2 * kHalo) + kHalo] = s / (float)p;
@@ -491,9 +581,10 @@ struct tcr_dscnn {
     int64_t param_floats, stat_floats, ss_floats;
     int c_pad;
     std::vector<tcr_tensor_info> tensors;
-    // backward: filter-gradient kernels on a second stream (see tcr_net in net.cpp); dz is double-buffered for it
+    // backward: filter-gradient kernels on a second stream (see tcr_net in net.cpp); the gradient buffers rotate through a pool of four for it
     mutable hipStream_t side = nullptr;
-    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done[2] = {nullptr, nullptr};
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    mutable bool ev_rec[4] = {false, false, false, false};      // ev_done[i] was recorded in the current backward
     ~tcr_dscnn() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -708,8 +799,38 @@ static std::vector<DsUnit> ds_units(const tcr_dscnn& net) {
     return u;
 }
 
+// "Lazy" training (the default wherever every consumer has the form): a unit's normalised activation relu(raw * scale + shift) is
+// never written -- its consumers (next conv, both filter-gradient kernels, the pooling) apply the affine + ReLU to the RAW conv output
+// as they stage / read it --, BN batch statistics come from the conv epilogues (EpiSums) and the backward sums of a unit from the
+// epilogue of the data-gradient kernel that produces its activation gradient: 5 of the ~14 tensor passes per unit disappear
+// (statistics reduce, normalise read + write, backward reduce's two reads).  TCR_TUNE_DS_TRAIN = 1: the materialising path.
+static bool ds_lazy(const tcr_dscnn& net) {
+    if (tune_get(TCR_TUNE_DS_TRAIN) == 1) return false;
+    for (const DsLayer& l : net.layers) {
+        if (!l.separable) continue;
+        const int pp = tcr_padded_len(l.oh * l.ow);
+        if (!conv1x1_lds_covers(l.cin, l.cout) || !conv1x1_lds_covers(l.cout, l.cin) || !pw_wgrad_lds_covers(l.cin, l.cout, pp)) return false;
+        if (!dscnn_depthwise_lds_covers(l.oh, l.ow, l.sh, l.sw) || !dscnn_dw_dgrad_lds_covers(l.h_in, l.w_in, l.pad_t, l.pad_l)) return false;
+    }
+    return true;
+}
+
+// partial rows of unit u's forward statistics (lazy: from its conv's epilogue)
+static int ds_fwd_rows(const DsUnit& u, int batch, bool lazy) {
+    if (!lazy) return chan_reduce_launch_chunks(batch * u.P, u.P);
+    return u.kind == DS_PW ? conv1x1_sum_rows(batch * u.P) : (u.kind == DS_DW ? batch : dscnn_conv1_sum_rows(batch * u.P));
+}
+
+// partial rows of unit ui's backward sums (lazy: from the epilogue of the data gradient of unit ui + 1; the last unit's come from
+// the reduction kernel -- its activation gradient is the broadcast pooled one)
+static int ds_bwd_rows(const std::vector<DsUnit>& units, int ui, int batch, bool lazy) {
+    const DsUnit& u = units[ui];
+    if (!lazy || ui + 1 == (int)units.size()) return chan_reduce_launch_chunks(batch * u.P, u.P);
+    return units[ui + 1].kind == DS_PW ? conv1x1_sum_rows(batch * u.P) : batch;
+}
+
 struct DsTrainWs {
-    int64_t ss, kcoef, partial, sums, pooled, dropped, dscale, dlogits, loss_utt, dpool, fc_partial, scratch, wt, ga, dz, dz2, total;
+    int64_t ss, kcoef, partial, sums, pooled, dropped, dscale, dlogits, loss_utt, dpool, fc_partial, scratch, wt, gbuf[4], total;
     std::vector<int64_t> raw, act, mean, invstd;
 };
 
@@ -721,7 +842,7 @@ static DsTrainWs ds_carve(const tcr_dscnn& net, int batch) {
     const int cp = net.c_pad, nc = net.cfg.num_classes;
     const int cl = net.layers.back().cout;
     w.ss = take(net.ss_floats);
-    w.kcoef = take(3 * (int64_t)cp);
+    w.kcoef = take((int64_t)units.size() * 3 * cp);     // k1..k3 per unit (read by the side stream's kernels after the main stream has moved on)
     w.sums = take(2 * 2 * (int64_t)cp);         // doubles: cross-replica BN hand-off
     int maxpos = 0;
     int64_t max_act = 0, scratch = 0;
@@ -740,7 +861,9 @@ static DsTrainWs ds_carve(const tcr_dscnn& net, int batch) {
         else sc = (int64_t)wgrad_partial_floats(1, l.cin, l.cout, batch);
         scratch = sc > scratch ? sc : scratch;
     }
-    w.partial = take((int64_t)chan_reduce_chunks(maxpos) * 2 * cp);
+    int64_t rows = chan_reduce_chunks(maxpos);          // (also covers the epilogue sums: a row per utterance / per 64 or 256 positions)
+    rows = std::max<int64_t>(rows, std::max<int64_t>(batch, conv1x1_sum_rows(maxpos)));
+    w.partial = take(rows * 2 * cp);
     w.pooled = take((int64_t)batch * cl * tcr_padded_len(1));
     w.dropped = take((int64_t)batch * cl);
     w.dscale = take((int64_t)batch * cl);
@@ -750,9 +873,7 @@ static DsTrainWs ds_carve(const tcr_dscnn& net, int batch) {
     w.fc_partial = take((int64_t)fc_wgrad_chunks(batch) * cl * nc);
     w.scratch = take(scratch);
     w.wt = take((int64_t)net.cfg.depth * net.cfg.depth);
-    w.ga = take(max_act);
-    w.dz = take(max_act);
-    w.dz2 = take(max_act);
+    for (int i = 0; i < 4; ++i) w.gbuf[i] = take(max_act + 64);       // (+ pad: 16-byte loads of a row's last positions)
     w.total = o;
     return w;
 }
@@ -784,19 +905,21 @@ static int ds_forward_train_stages(const tcr_dscnn* net, const float* params, fl
     const int nu = (int)units.size();
     TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_dscnn_forward_train: bad stage range [%d, %d)", stage_begin, stage_end);
     const double bn_batch = sync ? (double)global_batch : (double)batch;
+    const bool lazy = ds_lazy(*net);
     // finalize + normalise of unit ui (its partial rows / cross-replica sums are ready)
     auto post = [&](int ui) -> int {
         const DsUnit& u = units[ui];
         const int pp = tcr_padded_len(u.P);
         float* ss = base + w.ss + u.ss_off;
         BnFinalizeArgs f;
-        f.partial = base + w.partial; f.nchunk = sync ? 0 : chan_reduce_launch_chunks(batch * u.P, u.P);
+        f.partial = base + w.partial; f.nchunk = sync ? 0 : ds_fwd_rows(u, batch, lazy);
         f.sums = reinterpret_cast<const double*>(base + w.sums);
         f.gamma = nullptr; f.beta = params + u.beta_off;
         f.moving_mean = stats + u.mean_off; f.moving_var = stats + u.var_off;
         f.scale = ss; f.shift = ss + cp; f.mean = base + w.mean[ui]; f.invstd = base + w.invstd[ui];
         f.c = u.c; f.count = bn_batch * (double)u.P; f.decay = net->cfg.bn_decay; f.eps = net->cfg.bn_eps;
         TCR_TRY(launch_bn_finalize(f, s));
+        if (lazy) return TCR_OK;                    // (consumers apply scale / shift + ReLU to the raw output themselves)
         BnApplyArgs ap;
         ap.y = base + w.raw[ui]; ap.scale = ss; ap.shift = ss + cp; ap.res = nullptr; ap.out = base + w.act[ui];
         ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.relu = 1;
@@ -804,16 +927,21 @@ static int ds_forward_train_stages(const tcr_dscnn* net, const float* params, fl
     };
     for (int ui = stage_begin; ui < stage_end && ui < nu; ++ui) {
         if (ui > 0) TCR_TRY(post(ui - 1));
-        const float* x = ui > 0 ? base + w.act[ui - 1] : nullptr;      // activation feeding the unit (nullptr: the features)
+        const float* x = ui > 0 ? base + (lazy ? w.raw[ui - 1] : w.act[ui - 1]) : nullptr;      // activation feeding the unit (nullptr: the features)
+        const float* in_scale = (lazy && ui > 0) ? base + w.ss + units[ui - 1].ss_off : nullptr;    // lazy: the producing unit's raw output + its BN affine
+        const float* in_shift = in_scale ? in_scale + cp : nullptr;
         const DsUnit& u = units[ui];
         const DsLayer& l = net->layers[u.layer];
         const int pp = tcr_padded_len(u.P);
         float* raw = base + w.raw[ui];
+        EpiSums es;
+        if (lazy) es.partial = base + w.partial;
         if (u.kind == DS_CONV1) {
             DsConv1Args a;
             a.feat = feat; a.w = params + u.w_off; a.scale = nullptr; a.shift = params + u.b_off; a.y = raw;
             a.npos = batch * u.P; a.cout = l.cout; a.h_in = l.h_in; a.w_in = l.w_in; a.tp_in = tcr_padded_len(l.h_in);
             a.oh = l.oh; a.ow = l.ow; a.pp = pp; a.kh = l.kh; a.sh = l.sh; a.sw = l.sw; a.pad_t = l.pad_t; a.pad_l = l.pad_l; a.relu = 0;
+            a.sums = es;
             TCR_TRY(launch_dscnn_conv1(a, s));
         } else if (u.kind == DS_DW) {
             DsDwArgs d;
@@ -821,28 +949,34 @@ static int ds_forward_train_stages(const tcr_dscnn* net, const float* params, fl
             d.total = (int64_t)batch * l.cin * u.P; d.c = l.cin; d.h_in = l.h_in; d.w_in = l.w_in;
             d.ppi = tcr_padded_len(l.h_in * l.w_in); d.oh = l.oh; d.ow = l.ow; d.ppo = pp;
             d.sh = l.sh; d.sw = l.sw; d.pad_t = l.pad_t; d.pad_l = l.pad_l; d.relu = 0;
+            d.in_scale = in_scale; d.in_shift = in_shift; d.sums = es;
             TCR_TRY(launch_dscnn_depthwise(d, batch, s));
         } else {
             Conv1x1Args c1;
             c1.x = x; c1.w = params + u.w_off; c1.y = raw; c1.scale = nullptr; c1.shift = params + u.b_off;
             c1.npos = batch * u.P; c1.cin = l.cin; c1.cout = l.cout; c1.tpi = pp; c1.tout = u.P; c1.tpo = pp; c1.stride = 1; c1.relu = 0;
+            c1.in_scale = in_scale; c1.in_shift = in_shift; c1.sums = es;
             TCR_TRY(launch_conv1x1(c1, MF_AFFINE, s));
         }
         // batch statistics of the raw output (the finalize + normalise run at the start of the next stage)
-        ChanReduceArgs r;
-        std::memset(&r, 0, sizeof(r));
-        r.y = raw; r.partial = base + w.partial; r.npos = batch * u.P; r.c = u.c; r.t = u.P; r.tp = pp;
-        int nchunk = 0;
-        TCR_TRY(launch_chan_reduce(0, r, &nchunk, s));
+        int nchunk = ds_fwd_rows(u, batch, lazy);
+        if (!lazy) {
+            ChanReduceArgs r;
+            std::memset(&r, 0, sizeof(r));
+            r.y = raw; r.partial = base + w.partial; r.npos = batch * u.P; r.c = u.c; r.t = u.P; r.tp = pp;
+            TCR_TRY(launch_chan_reduce(0, r, &nchunk, s));
+        }
         if (sync) TCR_TRY(launch_chan_sums(base + w.partial, nchunk, u.c, reinterpret_cast<double*>(base + w.sums), s));
     }
     if (stage_end <= nu) return TCR_OK;
     TCR_TRY(post(nu - 1));
-    const float* x = base + w.act[nu - 1];
+    const float* x = base + (lazy ? w.raw[nu - 1] : w.act[nu - 1]);
+    const float* pool_scale = lazy ? base + w.ss + units[nu - 1].ss_off : nullptr;
     const DsLayer& last = net->layers.back();
     const int P = last.oh * last.ow;
     const int64_t rows = (int64_t)batch * last.cout;
-    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, x, base + w.pooled, rows, P, tcr_padded_len(P));
+    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, x, base + w.pooled, rows, P, tcr_padded_len(P),
+                       pool_scale, pool_scale ? pool_scale + cp : (const float*)nullptr, last.cout);
     TCR_TRY(check_launch("plane_mean_kernel"));
     HeadArgs h;
     std::memset(&h, 0, sizeof(h));
@@ -885,6 +1019,22 @@ extern "C" int tcr_dscnn_unit_output(const tcr_dscnn* net, int unit, int batch, 
     return TCR_OK;
 }
 
+extern "C" int tcr_dscnn_materialize_unit(const tcr_dscnn* net, int unit, int batch, void* workspace, size_t workspace_bytes, void* stream) {
+    TCR_REQUIRE(net && workspace && batch > 0, "tcr_dscnn_materialize_unit: bad argument");
+    const std::vector<DsUnit> units = ds_units(*net);
+    TCR_REQUIRE(unit >= 0 && unit < (int)units.size(), "tcr_dscnn_materialize_unit: unit %d of %d", unit, (int)units.size());
+    const DsTrainWs w = ds_carve(*net, batch);
+    if ((size_t)w.total * sizeof(float) > workspace_bytes) { set_error("tcr_dscnn_materialize_unit: workspace too small"); return TCR_ERR_WORKSPACE; }
+    float* base = static_cast<float*>(workspace);
+    const DsUnit& u = units[unit];
+    const int pp = tcr_padded_len(u.P);
+    const float* ss = base + w.ss + u.ss_off;
+    BnApplyArgs ap;
+    ap.y = base + w.raw[unit]; ap.scale = ss; ap.shift = ss + net->c_pad; ap.res = nullptr; ap.out = base + w.act[unit];
+    ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.relu = 1;
+    return launch_bn_apply(ap, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int tcr_dscnn_stage_sums(const tcr_dscnn* net, int backward, int stage, void* workspace, int batch, double** sums_dev,
                                     int64_t* n_doubles) {
     TCR_REQUIRE(net && workspace && sums_dev && n_doubles, "tcr_dscnn_stage_sums: null argument");
@@ -916,6 +1066,7 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
     const int nu = (int)units.size();
     TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_dscnn_backward: bad stage range [%d, %d)", stage_begin, stage_end);
     const double bn_batch = sync ? (double)global_batch : (double)batch;
+    const bool lazy = ds_lazy(*net);
     if (stage_begin == 0) {
         // zero the arena: padding and the conv biases (exactly-zero gradient, see above)
         if (hipMemsetAsync(grads, 0, (size_t)net->param_floats * sizeof(float), s) != hipSuccess) {
@@ -927,31 +1078,57 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         TCR_TRY(launch_head_bwd(base + w.dlogits, params + net->fcw_off, base + w.dscale, base + w.dpool, batch, cl, nc, s));
     }
 
-    // Filter gradients run on a second stream, overlapped with the (HBM-bound) BN-backward / data-gradient chain of the units
-    // below.  They read dz, so dz alternates between two buffers and a buffer is rewritten only after the filter-gradient
-    // kernel that read it has finished (ev_done).
+    // Filter gradients run on a second stream, overlapped with the BN-backward / data-gradient chain of the units below.
+    // Gradient buffers come from a pool of four, handed out round-robin: a unit's materialised dy (`D`), the activation gradient
+    // its data-gradient kernel writes for the unit below (`gout`).  The side stream reads D -- or, for units whose BN backward is
+    // applied on the fly (BnBwdFly: depthwise and conv_1 in lazy mode), the incoming activation gradient `gin` --, so the main
+    // stream waits for the buffer's last side-stream reader (ev_done) before it writes a buffer again.  The hand-out order is a
+    // function of the unit list only, so a staged run (one host call per stage) recomputes it.
     hipStream_t side = s;
     if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) {
         if (!net->side) {
             bool ok = hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) == hipSuccess &&
                       hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) == hipSuccess;
-            for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&net->ev_done[i], hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&net->ev_done[i], hipEventDisableTiming) == hipSuccess;
             if (!ok) { set_error("tcr_dscnn_backward: cannot create the filter-gradient stream"); return TCR_ERR_HIP; }
         }
         side = net->side;
     }
-    float* ga = base + w.ga;
-    float* kc = base + w.kcoef;
-    // per-channel sums of unit ui's BN backward (da: the gradient wrt its activation -- the pooled head's for the last unit, else
-    // the data gradient the previous stage left in `ga`)
-    auto pre = [&](int ui) -> int {
+    if (stage_begin == 0) for (bool& r : net->ev_rec) r = false;
+    // on the fly: conv_1 (its dy has one reader, and the step ends with it: 0.69 ms of bn_bwd_apply gone from the tail).  The
+    // depthwise units measured SLOWER that way (their bn_bwd_apply pass runs in the shadow of the pointwise filter gradient on the
+    // side stream; computing dy in the data-gradient kernel lengthens the main chain: 2.03 vs 1.90 ms per block) -- knob 3 turns it on
+    const int fly_knob = tune_get(TCR_TUNE_DS_TRAIN);
+    auto unit_fly = [&](int ui) {
+        if (!lazy || fly_knob == 2 || ui == nu - 1) return false;
+        return units[ui].kind == DS_CONV1 || (fly_knob == 3 && units[ui].kind == DS_DW);
+    };
+    // buffer plan: stage st (unit nu - st) reads gin[st], materialises into dbuf[st] (-1: on the fly), writes gout[st] (-1: conv_1)
+    std::vector<int> gin(nu + 1, -1), dbuf(nu + 1, -1), gout(nu + 1, -1);
+    {
+        int next = 0, cur = -1;
+        for (int st = 1; st <= nu; ++st) {
+            const int ui = nu - st;
+            gin[st] = cur;
+            if (!unit_fly(ui)) dbuf[st] = next++ % 4;
+            if (ui > 0) { gout[st] = next++ % 4; cur = gout[st]; }
+        }
+    }
+    // the main stream is about to WRITE pool buffer i: its last side-stream reader must be done
+    auto claim = [&](int i) -> int {
+        if (side != s && net->ev_rec[i] && hipStreamWaitEvent(s, net->ev_done[i], 0) != hipSuccess) { set_error("tcr_dscnn_backward: stream wait failed"); return TCR_ERR_HIP; }
+        return TCR_OK;
+    };
+    // per-channel sums of unit ui's BN backward by the reduction kernel (materialising path; lazy: only the last unit, whose
+    // activation gradient is the broadcast pooled one)
+    auto pre = [&](int ui, const float* da) -> int {
         const DsUnit& u = units[ui];
         const int pp = tcr_padded_len(u.P);
         ChanReduceArgs r;
         std::memset(&r, 0, sizeof(r));
-        r.y = base + w.raw[ui]; r.da = ui == nu - 1 ? base + w.dpool : ga; r.m1 = base + w.act[ui]; r.m2 = nullptr;
-        if (tune_get(TCR_TUNE_BWD_MASK) != 1) {     // the unit's own ReLU mask from its raw output (one tensor read less)
+        r.y = base + w.raw[ui]; r.da = da; r.m1 = base + w.act[ui]; r.m2 = nullptr;
+        if (lazy || tune_get(TCR_TUNE_BWD_MASK) != 1) {     // the unit's own ReLU mask from its raw output (one tensor read less; lazy: there is no stored activation)
             r.m1 = nullptr; r.self_scale = base + w.ss + u.ss_off; r.self_shift = r.self_scale + cp;
         }
         r.mean = base + w.mean[ui]; r.invstd = base + w.invstd[ui];
@@ -961,70 +1138,95 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         if (sync) TCR_TRY(launch_chan_sums(base + w.partial, nchunk, u.c, reinterpret_cast<double*>(base + w.sums), s));
         return TCR_OK;
     };
-    if (stage_begin == 0) TCR_TRY(pre(nu - 1));
+    if (stage_begin == 0) TCR_TRY(pre(nu - 1, base + w.dpool));
     for (int st = stage_begin > 0 ? stage_begin : 1; st < stage_end; ++st) {
         const int ui = nu - st;                     // the unit whose sums the previous stage produced
-        const int flip = (st - 1) & 1;
-        // dz alternates between two buffers; a buffer is rewritten only after the filter-gradient kernel that read it two units ago
-        // has finished.  (Staged runs return to the host between stages: the event of the SAME parity is the one to wait for.)
-        float* dz = base + (flip ? w.dz2 : w.dz);
-        if (side != s && st >= 3 && hipStreamWaitEvent(s, net->ev_done[flip], 0) != hipSuccess) {
-            set_error("tcr_dscnn_backward: stream wait failed");
-            return TCR_ERR_HIP;
-        }
         const DsUnit& u = units[ui];
         const DsLayer& l = net->layers[u.layer];
         const int pp = tcr_padded_len(u.P);
         const float* raw = base + w.raw[ui];
         const float* act = base + w.act[ui];
-        const float* da = ui == nu - 1 ? base + w.dpool : ga;
+        const float* da = ui == nu - 1 ? base + w.dpool : base + w.gbuf[gin[st]];
         const int bcast = ui == nu - 1 ? 1 : 0;
+        const bool fly = unit_fly(ui);
+        float* kc = base + w.kcoef + (int64_t)ui * 3 * cp;
         BnBwdFinalizeArgs f;
-        f.partial = base + w.partial; f.nchunk = sync ? 0 : chan_reduce_launch_chunks(batch * u.P, u.P);
+        f.partial = base + w.partial; f.nchunk = sync ? 0 : ds_bwd_rows(units, ui, batch, lazy);
         f.sums = reinterpret_cast<const double*>(base + w.sums); f.gamma = nullptr; f.invstd = base + w.invstd[ui];
         f.dgamma = nullptr; f.dbeta = grads + u.beta_off;
         f.k1 = kc; f.k2 = kc + cp; f.k3 = kc + 2 * cp;
         f.c = u.c; f.count = bn_batch * (double)u.P; f.grad_scale = (float)((double)batch / bn_batch);
         TCR_TRY(launch_bn_bwd_finalize(f, s));
-        BnBwdApplyArgs ap;
-        ap.accumulate = 0;
-        ap.y = raw; ap.da = da; ap.m1 = act; ap.m2 = nullptr; ap.mean = base + w.mean[ui];
-        if (tune_get(TCR_TUNE_BWD_MASK) != 1) { ap.m1 = nullptr; ap.self_scale = base + w.ss + u.ss_off; ap.self_shift = ap.self_scale + cp; }
-        ap.k1 = f.k1; ap.k2 = f.k2; ap.k3 = f.k3; ap.dy = dz;
-        ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.bcast = bcast;
-        TCR_TRY(launch_bn_bwd_apply(ap, s));
+        const float* self_scale = base + w.ss + u.ss_off;
+        const float* dz = nullptr;              // the unit's dy, materialised ...
+        BnBwdFly bf;                            // ... or computed by its readers
+        if (fly) {
+            bf.da = da; bf.raw = raw; bf.mean = base + w.mean[ui]; bf.k1 = f.k1; bf.k2 = f.k2; bf.k3 = f.k3;
+            bf.self_scale = self_scale; bf.self_shift = self_scale + cp;
+        } else {
+            TCR_TRY(claim(dbuf[st]));
+            float* dzw = base + w.gbuf[dbuf[st]];
+            BnBwdApplyArgs ap;
+            ap.accumulate = 0;
+            ap.y = raw; ap.da = da; ap.m1 = act; ap.m2 = nullptr; ap.mean = base + w.mean[ui];
+            if (lazy || tune_get(TCR_TUNE_BWD_MASK) != 1) { ap.m1 = nullptr; ap.self_scale = self_scale; ap.self_shift = self_scale + cp; }
+            ap.k1 = f.k1; ap.k2 = f.k2; ap.k3 = f.k3; ap.dy = dzw;
+            ap.total = (int64_t)batch * u.c * pp; ap.c = u.c; ap.t = u.P; ap.tp = pp; ap.bcast = bcast;
+            TCR_TRY(launch_bn_bwd_apply(ap, s));
+            dz = dzw;
+        }
         if (side != s && (hipEventRecord(net->ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, net->ev_fork, 0) != hipSuccess)) {
             set_error("tcr_dscnn_backward: stream fork failed");
             return TCR_ERR_HIP;
         }
-        const float* xin = ui > 0 ? base + w.act[ui - 1] : nullptr;
+        float* ga = nullptr;
+        if (ui > 0) { TCR_TRY(claim(gout[st])); ga = base + w.gbuf[gout[st]]; }
+        const float* xin = ui > 0 ? base + (lazy ? w.raw[ui - 1] : w.act[ui - 1]) : nullptr;
+        const float* x_scale = (lazy && ui > 0) ? base + w.ss + units[ui - 1].ss_off : nullptr;     // lazy: xin is a raw output + its BN affine
+        const float* x_shift = x_scale ? x_scale + cp : nullptr;
+        EpiSums es;             // lazy: the data gradient's epilogue takes the backward sums of unit ui - 1
+        if (lazy && ui > 0) {
+            es.partial = base + w.partial; es.raw = base + w.raw[ui - 1]; es.mean = base + w.mean[ui - 1]; es.invstd = base + w.invstd[ui - 1];
+            es.self_scale = x_scale; es.self_shift = x_shift;
+        }
         if (u.kind == DS_PW) {
-            TCR_TRY(launch_conv_wgrad(1, 1, 0, xin, dz, grads + u.w_off, base + w.scratch, batch, l.cin, l.cout, pp, u.P, pp, side));
+            TCR_TRY(launch_conv_wgrad(1, 1, 0, xin, dz, grads + u.w_off, base + w.scratch, batch, l.cin, l.cout, pp, u.P, pp, side, x_scale, x_shift));
             TCR_TRY(launch_transpose_weights(params + u.w_off, base + w.wt, 1, l.cin, l.cout, s));
             Conv1x1Args c1;
             c1.x = dz; c1.w = base + w.wt; c1.y = ga; c1.scale = nullptr; c1.shift = nullptr;
             c1.npos = batch * u.P; c1.cin = l.cout; c1.cout = l.cin; c1.tpi = pp; c1.tout = u.P; c1.tpo = pp; c1.stride = 1; c1.relu = 0;
+            c1.sums = es;
             TCR_TRY(launch_conv1x1(c1, MF_RAW, s));
         } else if (u.kind == DS_DW) {
             const int ppi = tcr_padded_len(l.h_in * l.w_in);
             DsDwWgradArgs g;
             g.x = xin; g.dz = dz; g.partial = base + w.scratch; g.batch = batch; g.c = u.c; g.h_in = l.h_in; g.w_in = l.w_in; g.ppi = ppi;
             g.oh = l.oh; g.ow = l.ow; g.ppo = pp; g.sh = l.sh; g.sw = l.sw; g.pad_t = l.pad_t; g.pad_l = l.pad_l; g.utt_per_block = 0;
+            g.x_scale = x_scale; g.x_shift = x_shift; g.fly = bf;
             TCR_TRY(launch_dscnn_dw_wgrad(g, grads + u.w_off, side));
             DsDwBwdArgs d;
             d.dz = dz; d.w = params + u.w_off; d.dx = ga; d.planes = (int64_t)batch * u.c; d.c = u.c; d.h_in = l.h_in; d.w_in = l.w_in;
             d.ppi = ppi; d.oh = l.oh; d.ow = l.ow; d.ppo = pp; d.sh = l.sh; d.sw = l.sw; d.pad_t = l.pad_t; d.pad_l = l.pad_l;
+            d.sums = es; d.fly = bf;
             TCR_TRY(launch_dscnn_dw_dgrad(d, s));
         } else {
             DsConv1WgradArgs g;
-            std::memset(&g, 0, sizeof(g));
             g.feat = feat; g.dz = dz; g.partial = base + w.scratch; g.batch = batch; g.cout = l.cout;
+            g.cout_pad = 0; g.taps = 0; g.taps_pad = 0; g.utt_per_block = 0;
             g.h_in = l.h_in; g.w_in = l.w_in; g.tp_in = tcr_padded_len(l.h_in); g.oh = l.oh; g.ow = l.ow; g.pp = pp;
-            g.kh = l.kh; g.sh = l.sh; g.sw = l.sw; g.pad_t = l.pad_t; g.pad_l = l.pad_l;
+            g.kh = l.kh; g.sh = l.sh; g.sw = l.sw; g.pad_t = l.pad_t; g.pad_l = l.pad_l; g.fly = bf;
             TCR_TRY(launch_dscnn_conv1_wgrad(g, grads + u.w_off, side));
         }
-        if (side != s && hipEventRecord(net->ev_done[flip], side) != hipSuccess) { set_error("tcr_dscnn_backward: event record failed"); return TCR_ERR_HIP; }
-        if (ui > 0) TCR_TRY(pre(ui - 1));
+        // the buffer the side stream's kernel of this unit reads: its dy, or the incoming activation gradient
+        const int side_reads = fly ? gin[st] : dbuf[st];
+        if (side != s && side_reads >= 0) {
+            if (hipEventRecord(net->ev_done[side_reads], side) != hipSuccess) { set_error("tcr_dscnn_backward: event record failed"); return TCR_ERR_HIP; }
+            net->ev_rec[side_reads] = true;
+        }
+        if (ui > 0) {
+            if (!lazy) TCR_TRY(pre(ui - 1, ga));
+            else if (sync) TCR_TRY(launch_chan_sums(base + w.partial, ds_bwd_rows(units, ui - 1, batch, lazy), units[ui - 1].c, reinterpret_cast<double*>(base + w.sums), s));
+        }
     }
     if (stage_end == nu + 1 && side != s && (hipEventRecord(net->ev_join, side) != hipSuccess || hipStreamWaitEvent(s, net->ev_join, 0) != hipSuccess)) {
         set_error("tcr_dscnn_backward: stream join failed");

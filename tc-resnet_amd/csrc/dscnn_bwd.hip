@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_lds_kernel(const DsDwBwdAr
     const bool live = row_raw < a.planes;
     const int c = (int)(row % a.c);
     const int ir = a.h_in + 2, ic = a.w_in + 2, isz = ir * ic;
-    const float* dz = a.dz + row * a.ppo + kHalo;
+    const bool fly = a.fly.da != nullptr;
+    const float* dz = (fly ? a.fly.da : a.dz) + row * a.ppo + kHalo;
+    const float* rz = fly ? a.fly.raw + row * a.ppo + kHalo : dz;
+    const float f_k1 = fly ? a.fly.k1[c] : 0.f, f_k2 = fly ? a.fly.k2[c] : 0.f, f_k3 = fly ? a.fly.k3[c] : 0.f, f_mu = fly ? a.fly.mean[c] : 0.f;
+    const float f_sc = fly ? a.fly.self_scale[c] : 0.f, f_sh = fly ? a.fly.self_shift[c] : 0.f;
     float* im = img + plane * isz;
     const float inv_c = 1.0f / (float)ic;
     for (int j0 = t16; j0 < isz; j0 += 16 * 8) {
@@ -76,7 +80,12 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_lds_kernel(const DsDwBwdAr
             const int hh = rr - (2 - a.pad_t), ww = cc - (2 - a.pad_l);
             const int oh = hh / sh, ow = ww / sw;
             const bool in = hh >= 0 && ww >= 0 && oh * sh == hh && ow * sw == ww && oh < a.oh && ow < a.ow;
-            const float g = dz[in ? oh * a.ow + ow : 0];
+            float g = dz[in ? oh * a.ow + ow : 0];
+            if (fly) {          // BN backward of this unit where dy is read (BnBwdFly)
+                const float yv = rz[in ? oh * a.ow + ow : 0];
+                if (!(fmaf(yv, f_sc, f_sh) > 0.f)) g = 0.f;
+                g = f_k1 * (g - f_k2 - (yv - f_mu) * f_k3);
+            }
             v[i] = in ? g : 0.f;
         }
 #pragma unroll
@@ -91,8 +100,19 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_lds_kernel(const DsDwBwdAr
     const int pin = a.h_in * a.w_in;
     const float inv_w = 1.0f / (float)a.w_in;
     float* dx = a.dx + row * a.ppi + kHalo;
+    // EpiSums (backward form): dx is the gradient wrt the activation of the BN unit that feeds this depthwise conv; its sum dz,
+    // sum dz * xhat are taken here, from that unit's raw output at the same addresses -- one partial row per utterance
+    const bool sums = a.sums.partial != nullptr;
+    const float* rawr = sums ? a.sums.raw + row * a.ppi + kHalo : nullptr;
+    const float mu = sums ? a.sums.mean[c] : 0.f, is = sums ? a.sums.invstd[c] : 0.f;
+    const float ssc = sums ? a.sums.self_scale[c] : 0.f, ssh = sums ? a.sums.self_shift[c] : 0.f;
+    float q1 = 0.f, q2 = 0.f;
     for (int pos0 = t16; pos0 < pin; pos0 += 16 * 5) {
-        float s[5];
+        float s[5], rw[5];
+        if (sums) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) rw[i] = rawr[min(pos0 + 16 * i, pin - 1)];
+        }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int pos = min(pos0 + 16 * i, pin - 1);
@@ -106,19 +126,40 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_lds_kernel(const DsDwBwdAr
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i)
-            if (pos0 + 16 * i < pin) dx[pos0 + 16 * i] = s[i];
+            if (pos0 + 16 * i < pin) {
+                dx[pos0 + 16 * i] = s[i];
+                if (sums) {
+                    const float dz = fmaf(rw[i], ssc, ssh) > 0.f ? s[i] : 0.f;
+                    q1 += dz;
+                    q2 = fmaf(dz, (rw[i] - mu) * is, q2);
+                }
+            }
     }
+    if (sums) {                 // (a plane's 16 lanes are one DPP row; `live` is uniform over it)
+        q1 = row16_sum(q1);
+        q2 = row16_sum(q2);
+        if (t16 == 0) {
+            const size_t n = (size_t)(row / a.c);
+            a.sums.partial[(n * 2 + 0) * a.c + c] = q1;
+            a.sums.partial[(n * 2 + 1) * a.c + c] = q2;
+        }
+    }
+}
+
+bool dscnn_dw_dgrad_lds_covers(int h_in, int w_in, int pad_t, int pad_l) {
+    return (size_t)16 * (h_in + 2) * (w_in + 2) * sizeof(float) <= 64 * 1024 && pad_t <= 2 && pad_l <= 2;
 }
 
 int launch_dscnn_dw_dgrad(const DsDwBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)16 * (a.h_in + 2) * (a.w_in + 2) * sizeof(float);
-    if (lds <= 64 * 1024 && a.pad_t <= 2 && a.pad_l <= 2) {
+    if (dscnn_dw_dgrad_lds_covers(a.h_in, a.w_in, a.pad_t, a.pad_l)) {
         const dim3 lgrid((unsigned)ceil_div64(a.planes, 16));
         if (a.sh == 1 && a.sw == 1) hipLaunchKernelGGL((dscnn_dw_dgrad_lds_kernel<1, 1>), lgrid, dim3(256), lds, s, a);
         else if (a.sh == 2 && a.sw == 2) hipLaunchKernelGGL((dscnn_dw_dgrad_lds_kernel<2, 2>), lgrid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((dscnn_dw_dgrad_lds_kernel<0, 0>), lgrid, dim3(256), lds, s, a);
         return check_launch("dscnn_dw_dgrad_lds_kernel");
     }
+    if (a.sums.partial || a.fly.da) { set_error("dscnn depthwise data gradient: epilogue sums / on-the-fly BN backward need the LDS kernel"); return TCR_ERR_ARG; }
     const dim3 grid((unsigned)ceil_div64(a.planes, 4));
     if (a.sh == 1 && a.sw == 1) hipLaunchKernelGGL((dscnn_dw_dgrad_kernel<1, 1>), grid, dim3(256), 0, s, a);
     else if (a.sh == 2 && a.sw == 2) hipLaunchKernelGGL((dscnn_dw_dgrad_kernel<2, 2>), grid, dim3(256), 0, s, a);
@@ -139,11 +180,22 @@ __global__ __launch_bounds__(256) void dscnn_dw_wgrad_kernel(const DsDwWgradArgs
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
     const float inv_p = 1.0f / (float)P, inv_ow = 1.0f / (float)a.ow;
+    const bool aff = a.x_scale != nullptr;
+    const float xsc = aff ? a.x_scale[c] : 1.0f, xsf = aff ? a.x_shift[c] : 0.f;
+    const bool fly = a.fly.da != nullptr;
+    const float* gsrc = fly ? a.fly.da : a.dz;
+    const float f_k1 = fly ? a.fly.k1[c] : 0.f, f_k2 = fly ? a.fly.k2[c] : 0.f, f_k3 = fly ? a.fly.k3[c] : 0.f, f_mu = fly ? a.fly.mean[c] : 0.f;
+    const float f_sc = fly ? a.fly.self_scale[c] : 0.f, f_sh = fly ? a.fly.self_shift[c] : 0.f;
     for (int idx = lane; idx < cnt * P; idx += 64) {
         const int dn = fast_div(idx, P, inv_p), pos = idx - dn * P;
         const int oh = fast_div(pos, a.ow, inv_ow), ow = pos - oh * a.ow;
         const size_t plane = (size_t)(n0 + dn) * a.c + c;
-        const float g = a.dz[plane * a.ppo + kHalo + pos];
+        float g = gsrc[plane * a.ppo + kHalo + pos];
+        if (fly) {              // BN backward of this unit where dy is read (BnBwdFly)
+            const float yv = a.fly.raw[plane * a.ppo + kHalo + pos];
+            if (!(fmaf(yv, f_sc, f_sh) > 0.f)) g = 0.f;
+            g = f_k1 * (g - f_k2 - (yv - f_mu) * f_k3);
+        }
         const float* xr = a.x + plane * a.ppi + kHalo;
 #pragma unroll
         for (int di = 0; di < 3; ++di) {
@@ -151,7 +203,9 @@ __global__ __launch_bounds__(256) void dscnn_dw_wgrad_kernel(const DsDwWgradArgs
 #pragma unroll
             for (int dj = 0; dj < 3; ++dj) {
                 const int w = ow * a.sw + dj - a.pad_l;
-                const float xv = (h >= 0 && h < a.h_in && w >= 0 && w < a.w_in) ? xr[h * a.w_in + w] : 0.f;
+                const bool in = h >= 0 && h < a.h_in && w >= 0 && w < a.w_in;
+                float xv = in ? xr[h * a.w_in + w] : 0.f;
+                if (aff) xv = in ? fmaxf(fmaf(xv, xsc, xsf), 0.f) : 0.f;
                 acc[di * 3 + dj] = fmaf(xv, g, acc[di * 3 + dj]);
             }
         }
@@ -181,9 +235,15 @@ int launch_dscnn_dw_wgrad(DsDwWgradArgs a, float* dw, hipStream_t s) {
 }
 
 // conv_1 filter gradient: dW[i][j][co] = sum_{n,oh,ow} feat[n][ow*sw + j - pad_l][oh*sh + i - pad_t] * dz[n][co][oh][ow].
-// A = feature patches (tap tile x 4 positions, gathered from the small L1/L2-resident feature map), B = dz
-// (4 positions x 16 output channels), D = [tap][co].  A wave owns all tap tiles (3 x 16 >= 10 x 4) and NCO
-// channel tiles, so dz -- the large operand -- is read exactly once; workgroups split the batch (split-K).
+// A = feature patches (tap tile x 4 positions), B = dz (4 positions x 16 output channels), D = [tap][co].  A wave owns all tap
+// tiles (3 x 16 >= 10 x 4) and NCO channel tiles, so dz -- the large operand -- is read exactly once; workgroups split the batch
+// (split-K).  The MFMA k dimension holds positions 4 q + c of a 16-position block in step c, so a lane's four k-steps take ONE
+// 16-byte load per channel row (16 rows x 64 contiguous bytes per instruction; the first version gathered 16 rows x 16 bytes per
+// k-step and was bound by the L1's address processing: 1.0 ms for 1.2 GB), and the utterance's small feature map is staged in a
+// wave-private LDS copy, so the 12 patch gathers per block are ds_reads.  BnBwdFly: dz is computed here from the activation
+// gradient and the unit's raw output (conv_1's dy has no other reader: no bn_bwd_apply pass, 3.6 GB less per step).
+struct __attribute__((packed, aligned(4))) f32x4u { float v[4]; };
+
 template <int NCO>
 __global__ __launch_bounds__(256) void dscnn_conv1_wgrad_kernel(const DsConv1WgradArgs a) {
     constexpr int MT = 3;
@@ -191,6 +251,8 @@ __global__ __launch_bounds__(256) void dscnn_conv1_wgrad_kernel(const DsConv1Wgr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int co0 = blockIdx.y * NCO * 16;
+    const int fsz = a.w_in * a.tp_in;
+    float* sf = reinterpret_cast<float*>(dyn_lds()) + wave * fsz;      // [w_in][tp_in] of the wave's current utterance
 
     f32x4 acc[MT][NCO];
 #pragma unroll
@@ -206,37 +268,70 @@ __global__ __launch_bounds__(256) void dscnn_conv1_wgrad_kernel(const DsConv1Wgr
         ti[t] = tap >> 2;               // kernel row  (kw == 4)
         tj[t] = tap & 3;                // kernel column
     }
+    const bool fly = a.fly.da != nullptr;
     bool cov[NCO];
-    int coc[NCO];
+    size_t crow[NCO];
+    float f_k1[NCO], f_k2[NCO], f_k3[NCO], f_mu[NCO], f_sc[NCO], f_sh[NCO];
 #pragma unroll
     for (int m = 0; m < NCO; ++m) {
         const int co = co0 + m * 16 + r;
         cov[m] = co < a.cout;
-        coc[m] = cov[m] ? co : 0;
+        const int cc = cov[m] ? co : 0;
+        crow[m] = (size_t)cc * a.pp + kHalo;
+        f_k1[m] = fly ? a.fly.k1[cc] : 0.f; f_k2[m] = fly ? a.fly.k2[cc] : 0.f; f_k3[m] = fly ? a.fly.k3[cc] : 0.f;
+        f_mu[m] = fly ? a.fly.mean[cc] : 0.f; f_sc[m] = fly ? a.fly.self_scale[cc] : 0.f; f_sh[m] = fly ? a.fly.self_shift[cc] : 0.f;
     }
+    const int P = a.oh * a.ow;
+    const float inv_ow = 1.0f / (float)a.ow;
     const int n_begin = blockIdx.x * a.utt_per_block;
     const int n_end = min(n_begin + a.utt_per_block, a.batch);
     for (int n = n_begin + wave; n < n_end; n += 4) {
-        const float* fr = a.feat + (size_t)n * a.w_in * a.tp_in + kHalo;
-        const float* dr = a.dz + (size_t)n * a.cout * a.pp + kHalo;
-        for (int oh = 0; oh < a.oh; ++oh) {
-            for (int ow0 = 0; ow0 < a.ow; ow0 += 4) {
-                const int ow = ow0 + q;
-                const bool pv = ow < a.ow;
-                float bf[NCO], af[MT];
+        wave_sync();                                                    // (the previous utterance's gathers are done)
+        const float* fr = a.feat + (size_t)n * fsz;
+        for (int i = lane; i < fsz; i += 64) sf[i] = fr[i];
+        wave_sync();
+        const size_t nb = (size_t)n * a.cout * a.pp;
+        const float* dr = (fly ? a.fly.da : a.dz) + nb;
+        const float* rr = fly ? a.fly.raw + nb : dr;
+        for (int p0 = 0; p0 < P; p0 += 16) {
+            const int pb = p0 + 4 * q;
+            // B operands: four consecutive positions of each channel row in one (unaligned) 16-byte load; positions past the map are
+            // masked below (the load itself stays inside the workspace: rows carry halos, the gradient buffers a tail pad)
+            float bv[NCO][4];
 #pragma unroll
-                for (int m = 0; m < NCO; ++m) bf[m] = (pv && cov[m]) ? dr[(size_t)coc[m] * a.pp + oh * a.ow + ow] : 0.f;
+            for (int m = 0; m < NCO; ++m) {
+                const f32x4u d4 = *reinterpret_cast<const f32x4u*>(dr + crow[m] + pb);
+                if (fly) {
+                    const f32x4u y4 = *reinterpret_cast<const f32x4u*>(rr + crow[m] + pb);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float g = d4.v[c];
+                        if (!(fmaf(y4.v[c], f_sc[m], f_sh[m]) > 0.f)) g = 0.f;
+                        g = f_k1[m] * (g - f_k2[m] - (y4.v[c] - f_mu[m]) * f_k3[m]);
+                        bv[m][c] = (cov[m] && pb + c < P) ? g : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bv[m][c] = (cov[m] && pb + c < P) ? d4.v[c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int p = min(pb + c, P - 1);
+                const bool pv = pb + c < P;
+                const int oh = fast_div(p, a.ow, inv_ow), ow = p - oh * a.ow;
+                const int hb = oh * a.sh - a.pad_t, wb = ow * a.sw - a.pad_l;
+                float af[MT];
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    const int h = oh * a.sh + ti[t] - a.pad_t;
-                    const int wc = ow * a.sw + tj[t] - a.pad_l;
+                    const int h = hb + ti[t], wc = wb + tj[t];
                     const bool v = pv && tv[t] && h >= 0 && h < a.h_in && wc >= 0 && wc < a.w_in;
-                    af[t] = v ? fr[(size_t)wc * a.tp_in + h] : 0.f;
+                    af[t] = v ? sf[wc * a.tp_in + kHalo + h] : 0.f;
                 }
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int m = 0; m < NCO; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bf[m], acc[t][m], 0, 0, 0);
+                    for (int m = 0; m < NCO; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bv[m][c], acc[t][m], 0, 0, 0);
             }
         }
     }
@@ -273,7 +368,9 @@ int launch_dscnn_conv1_wgrad(DsConv1WgradArgs a, float* dw, hipStream_t s) {
     if (a.taps_pad > 48) { set_error("conv_1 wgrad: %d x 4 kernel exceeds the 48-tap tile", a.kh); return TCR_ERR_ARG; }
     a.utt_per_block = ceil_div(a.batch, wgrad_chunks(a.batch));
     const dim3 grid(ceil_div(a.batch, a.utt_per_block), ceil_div(a.cout_pad / 16, 2));
-    hipLaunchKernelGGL((dscnn_conv1_wgrad_kernel<2>), grid, dim3(256), 0, s, a);
+    const size_t lds = (size_t)4 * a.w_in * a.tp_in * sizeof(float);     // a wave-private copy of its utterance's feature map
+    if (lds > 48 * 1024) { set_error("conv_1 wgrad: a %d x %d feature map does not fit the LDS copies", a.w_in, a.tp_in); return TCR_ERR_ARG; }
+    hipLaunchKernelGGL((dscnn_conv1_wgrad_kernel<2>), grid, dim3(256), lds, s, a);
     TCR_TRY(check_launch("dscnn_conv1_wgrad_kernel"));
     // dW[tap][0][co]: k = 1, "Cin" = taps
     return launch_wgrad_reduce(a.partial, dw, (int)grid.x, 1, a.taps, a.cout, a.taps_pad, a.cout_pad, a.cout, 0, s);

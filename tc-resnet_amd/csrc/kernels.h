@@ -50,6 +50,23 @@ int launch_transpose_weights(const float* w, float* wt, int k, int cin, int cout
 // ---- mfma.hip : matrix-core contractions ----------------------------------------------------
 enum { MF_RAW = 0, MF_AFFINE = 1 };
 
+// Per-channel sums taken in a conv kernel's EPILOGUE, while the output tile is still in registers (DS-CNN training: no
+// separate reduction pass over the tensor):
+//   forward  (raw == nullptr): q1 = y, q2 = y * y of the kernel's own output                  (chan_reduce MODE 0)
+//   backward (raw != nullptr): the kernel writes dA, the gradient wrt a BN unit's activation; with raw = that unit's raw
+//       conv output (same layout as the kernel's output), dz = dA * [fmaf(raw, self_scale, self_shift) > 0],
+//       q1 = dz, q2 = dz * (raw - mean) * invstd                                              (chan_reduce MODE 1)
+// partial: [rows][2][C] rows of per-workgroup sums (how many rows: the kernel's *_sum_rows()), added up in double, in a
+// fixed order, by the finalize kernels of bn.hip.
+struct EpiSums {
+    float* partial = nullptr;
+    const float* raw = nullptr;
+    const float* mean = nullptr;
+    const float* invstd = nullptr;
+    const float* self_scale = nullptr;
+    const float* self_shift = nullptr;
+};
+
 struct Conv1x1Args {
     const float* x;         // [B][Cin][Tpi]
     const float* w;         // [Cin][Cout]
@@ -57,9 +74,17 @@ struct Conv1x1Args {
     const float* scale;
     const float* shift;
     int npos, cin, cout, tpi, tout, tpo, stride, relu;
+    // LDS-tiled kernel only (DS-CNN training): x is a RAW train-mode conv output and the kernel stages relu(x * in_scale[ci] +
+    // in_shift[ci]) -- the producing unit's BN + ReLU, bitwise bn_apply's expression -- so that tensor is never materialised
+    const float* in_scale = nullptr;
+    const float* in_shift = nullptr;
+    EpiSums sums;
 };
 
 int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s);
+bool conv1x1_lds_covers(int cin, int cout);                 // launch_conv1x1 takes the LDS-tiled kernel (in_scale / sums honoured)
+int conv1x1_sum_rows(int npos);                             // partial rows its epilogue writes
+bool pw_wgrad_lds_covers(int cin, int cout, int tp);        // launch_conv_wgrad(1, 1, ...) takes pw_wgrad_lds_kernel (x_scale / x_shift honoured)
 // implicit-GEMM k x 1 conv on the matrix cores; returns 1 (nothing launched) when the shape does not fit
 int launch_conv_mfma(int k, int stride, const ConvArgs& a, int epi, hipStream_t s);
 // dx = dgrad of a (k, stride) conv, computed as stride-1 MFMA convs over dy with re-arranged weights (scratch `wt`);
@@ -75,8 +100,10 @@ size_t wgrad_partial_floats(int k, int cin, int cout, int batch);
 int wgrad_chunks(int batch);
 int launch_wgrad_reduce(const float* partial, float* dw, int nchunk, int k, int cin, int cout, int cin_pad, int cout_pad,
                         int cout_all, int co_base, hipStream_t s);
+// x_scale / x_shift (pointwise LDS kernel only): x is a raw conv output, the operand is relu(x * x_scale[ci] + x_shift[ci])
 int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
-                      int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s);
+                      int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s,
+                      const float* x_scale = nullptr, const float* x_shift = nullptr);
 // Training engines that give every layer its own partial-slab scratch launch only the split-K kernel per layer
 // (launch_conv_wgrad_partial) and sum all layers' slabs in ONE launch at the end of backward (launch_wgrad_reduce_multi);
 // likewise the re-arranged data-gradient weights of every layer are produced by one launch up front.
@@ -264,6 +291,7 @@ struct BnFinalizeArgs {
     int c;
     double count;
     float decay, eps;
+    int cbw = 0;                // (set by the launcher: channels per workgroup, bn_finalize_cb(nchunk))
 };
 
 struct BnApplyArgs {
@@ -292,6 +320,7 @@ struct BnBwdFinalizeArgs {
     double count;           // elements per channel over the batch the statistics span
     float grad_scale;       // sync BN: sums are global on every replica, and the arena all-reduce will add the
                             // replicas' copies up again -> store dgamma/dbeta divided by the replica count
+    int cbw = 0;            // (set by the launcher)
 };
 
 struct BnBwdApplyArgs {
@@ -317,6 +346,7 @@ int chan_reduce_chunks(int npos);
 int chan_reduce_launch_chunks(int npos, int t);      // t: frames per utterance (chunks are whole utterances where one fits)
 int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t s);
 int launch_chan_sums(const float* partial, int nchunk, int c, double* sums, hipStream_t s);
+int bn_finalize_cb(int nchunk);         // channels per finalize workgroup for nchunk partial rows
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 int launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
@@ -354,14 +384,32 @@ int launch_sum_vector(const float* in, int n, float* out, hipStream_t s);
 int launch_bias_grad(const float* dlogits, int batch, int nc, float* db, hipStream_t s);
 
 // ---- dscnn_bwd.hip : backward kernels of the depthwise-separable baseline ----------------------
+// BN backward of the unit whose conv the kernel differentiates, applied WHERE dy IS READ instead of by a bn_bwd_apply pass that
+// writes it (units whose dy has few readers: depthwise, conv_1): with da = the gradient wrt the unit's activation, raw = its raw
+// conv output,   dy = k1 * (dz - k2 - (raw - mean) * k3),   dz = da * [fmaf(raw, self_scale, self_shift) > 0]
+// (bn_bwd_apply_kernel's expression).  da == nullptr: off, the kernel's dz argument is dy itself.
+struct BnBwdFly {
+    const float* da = nullptr;
+    const float* raw = nullptr;
+    const float* mean = nullptr;
+    const float* k1 = nullptr;
+    const float* k2 = nullptr;
+    const float* k3 = nullptr;
+    const float* self_scale = nullptr;
+    const float* self_shift = nullptr;
+};
+
 struct DsDwBwdArgs {
     const float* dz;        // [B][C][Ppo] gradient wrt the depthwise conv output
     const float* w;         // [3][3][C][1]
     float* dx;              // [B][C][Ppi]
     int64_t planes;         // B * C
     int c, h_in, w_in, ppi, oh, ow, ppo, sh, sw, pad_t, pad_l;
+    EpiSums sums;           // backward sums of the unit whose activation gradient dx is (LDS kernel only; rows = B: [n][2][C])
+    BnBwdFly fly;           // (LDS kernel only)
 };
 int launch_dscnn_dw_dgrad(const DsDwBwdArgs& a, hipStream_t s);
+bool dscnn_dw_dgrad_lds_covers(int h_in, int w_in, int pad_t, int pad_l);
 
 struct DsDwWgradArgs {
     const float* x;         // [B][C][Ppi] input of the depthwise conv
@@ -369,6 +417,9 @@ struct DsDwWgradArgs {
     float* partial;         // [nchunk][9][C]
     int batch, c, h_in, w_in, ppi, oh, ow, ppo, sh, sw, pad_t, pad_l;
     int utt_per_block;
+    const float* x_scale = nullptr;     // x is a raw conv output: the operand is relu(x * x_scale[c] + x_shift[c])
+    const float* x_shift = nullptr;
+    BnBwdFly fly;
 };
 size_t dscnn_dw_wgrad_partial_floats(int batch, int c);
 int launch_dscnn_dw_wgrad(DsDwWgradArgs a, float* dw, hipStream_t s);
@@ -380,6 +431,7 @@ struct DsConv1WgradArgs {
     int batch, cout, cout_pad, taps, taps_pad;
     int h_in, w_in, tp_in, oh, ow, pp, kh, sh, sw, pad_t, pad_l;
     int utt_per_block;
+    BnBwdFly fly;
 };
 size_t dscnn_conv1_wgrad_partial_floats(int batch, int kh, int cout);
 int launch_dscnn_conv1_wgrad(DsConv1WgradArgs a, float* dw, hipStream_t s);

@@ -121,7 +121,12 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
 // per chunk, and wave (wm, wn) keeps an (16 MT) x (16 NT) accumulator block: MT + NT conflict-free ds_read_b32 per
 // MT x NT MFMAs, x read once.  LDS rows are padded so that the four k-rows of a fragment read land in disjoint bank
 // quarters.  NT (positions per workgroup) is picked by the launcher so that the grid fills whole dispatch waves.
-template <int MT, int NT, int EPI>
+// MODE (DS-CNN training, so that no BN pass streams the tensors again): 1 = x is the producing unit's RAW conv output, staged as
+// relu(x * in_scale[ci] + in_shift[ci]) (bitwise bn_apply's expression), and the epilogue leaves the per-channel sums of y, y^2
+// (EpiSums, forward form); 2 = data gradient whose epilogue leaves the backward sums of the unit it writes the gradient of
+// (EpiSums, backward form: that unit's raw output is read at the tile's own addresses).  Sums: the 16 positions of a tile column
+// block live in the 16 lanes of a DPP row -> row16_sum; the two position halves (wn) meet in LDS; one partial row per workgroup.
+template <int MT, int NT, int EPI, int MODE>
 __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
     constexpr int KC = 12;                  // input channels per chunk = 3 MFMA k-steps
     constexpr int MW = 32 * MT;             // output channels covered (2 wave rows)
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
 
     // ---- staging roles ----
     const bool xuse = tid < RS * XN;
-    const int xpos = tid % XN, xrow0 = min(tid / XN, RS - 1);   // rows xrow0 + RS * j
+    const int xpos = tid % XN, xrow0 = XN == 64 ? wave : min(tid / XN, RS - 1);   // rows xrow0 + RS * j  (XN = 64: wave-uniform -> scalar loads of in_scale / in_shift)
     const float* xsrc;
     {
         const int p = min(pos0 + xpos, a.npos - 1);
@@ -161,11 +166,15 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
         wcol[j] = 4 * (idx % W4);
         wval[j] = wcol[j] < a.cout;                         // (Cout % 4 == 0: launcher)
     }
-    float xr[XPT];
+    float xr[XPT], xsc[XPT], xsf[XPT];
     f32x4 wr[WPT];
     auto load_chunk = [&](int c0) {
 #pragma unroll
-        for (int j = 0; j < XPT; ++j) xr[j] = xsrc[(size_t)min(c0 + xrow0 + RS * j, a.cin - 1) * a.tpi];
+        for (int j = 0; j < XPT; ++j) {
+            const int row = min(c0 + xrow0 + RS * j, a.cin - 1);
+            xr[j] = xsrc[(size_t)row * a.tpi];
+            if (MODE == 1) { xsc[j] = a.in_scale[row]; xsf[j] = a.in_shift[row]; }
+        }
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
             const float* src = a.w + (size_t)min(c0 + wrow[j], a.cin - 1) * a.cout + min(wcol[j], a.cout - 4);
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
     auto store_chunk = [&](int buf) {
         if (xuse) {
 #pragma unroll
-            for (int j = 0; j < XPT; ++j) s_x[buf][(xrow0 + RS * j) * XLD + xpos] = xr[j];
+            for (int j = 0; j < XPT; ++j) s_x[buf][(xrow0 + RS * j) * XLD + xpos] = MODE == 1 ? fmaxf(fmaf(xr[j], xsc[j], xsf[j]), 0.f) : xr[j];
         }
 #pragma unroll
         for (int j = 0; j < WPT; ++j)
@@ -221,51 +230,140 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
 
     // (lean addressing: see conv_mfma_store)
     const float inv_tout = 1.0f / (float)a.tout;
+    if (MODE == 0) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int p = pos0 + (wn * NT + nt) * 16 + r;
-        if (p >= a.npos) continue;
-        const int n = a.npos < (1 << 23) ? fast_div(p, a.tout, inv_tout) : p / a.tout, t = p - n * a.tout;
-        float* yb = a.y + (size_t)n * a.cout * a.tpo + kHalo + t;
-        const bool first = t == 0, last = t == a.tout - 1;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int p = pos0 + (wn * NT + nt) * 16 + r;
+            if (p >= a.npos) continue;
+            const int n = a.npos < (1 << 23) ? fast_div(p, a.tout, inv_tout) : p / a.tout, t = p - n * a.tout;
+            float* yb = a.y + (size_t)n * a.cout * a.tpo + kHalo + t;
+            const bool first = t == 0, last = t == a.tout - 1;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int co0 = (wm * MT + m) * 16;
-            if (co0 >= a.cout) break;
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = (wm * MT + m) * 16;
+                if (co0 >= a.cout) break;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int co = co0 + q * 4 + reg;
-                if (co >= a.cout) continue;
-                float v = acc[m][nt][reg];
-                if (EPI == MF_AFFINE) {
-                    v = fmaf(v, a.scale ? a.scale[co] : 1.0f, a.shift[co]);
-                    if (a.relu) v = fmaxf(v, 0.f);
-                }
-                float* o = yb + co * a.tpo;
-                o[0] = v;
-                if (EPI == MF_AFFINE) {
-                    if (first) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
-                    if (last) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int co = co0 + q * 4 + reg;
+                    if (co >= a.cout) continue;
+                    float v = acc[m][nt][reg];
+                    if (EPI == MF_AFFINE) {
+                        v = fmaf(v, a.scale ? a.scale[co] : 1.0f, a.shift[co]);
+                        if (a.relu) v = fmaxf(v, 0.f);
+                    }
+                    float* o = yb + co * a.tpo;
+                    o[0] = v;
+                    if (EPI == MF_AFFINE) {
+                        if (first) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
+                        if (last) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+                    }
                 }
             }
         }
+        return;
+    }
+    // MODE 1 / 2: channel-outer order, so that a channel's contributions of both column tiles meet in one pair of registers
+    size_t yo[NT];
+    bool pv[NT], first[NT], last[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = pos0 + (wn * NT + nt) * 16 + r;
+        pv[nt] = p < a.npos;
+        const int pc = min(p, a.npos - 1);
+        const int n = a.npos < (1 << 23) ? fast_div(pc, a.tout, inv_tout) : pc / a.tout, t = pc - n * a.tout;
+        yo[nt] = (size_t)n * a.cout * a.tpo + kHalo + t;
+        first[nt] = t == 0; last[nt] = t == a.tout - 1;
+    }
+    float* s_sum = &s_w[0][0];              // [wn][which][MW] (the loop's last barrier is behind every LDS read of the tiles)
+    static_assert(2 * 2 * MW <= KC * WLD, "sums fit the first weight buffer");
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co0 = (wm * MT + m) * 16;
+        if (co0 >= a.cout) break;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int co = co0 + q * 4 + reg;
+            const bool cok = co < a.cout;                       // (uniform over a DPP row: its lanes share q)
+            const int cc = min(co, a.cout - 1);
+            float sc1 = 1.0f, sf1 = 0.f, mu = 0.f, is = 0.f, ssc = 0.f, ssh = 0.f;
+            if (EPI == MF_AFFINE) { sc1 = a.scale ? a.scale[cc] : 1.0f; sf1 = a.shift[cc]; }
+            if (MODE == 2) { mu = a.sums.mean[cc]; is = a.sums.invstd[cc]; ssc = a.sums.self_scale[cc]; ssh = a.sums.self_shift[cc]; }
+            float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool ok = cok && pv[nt];
+                float v = acc[m][nt][reg];
+                if (EPI == MF_AFFINE) {
+                    v = fmaf(v, sc1, sf1);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                }
+                const size_t off = yo[nt] + (size_t)(cc * a.tpo);
+                if (ok) {
+                    float* o = a.y + off;
+                    o[0] = v;
+                    if (EPI == MF_AFFINE) {
+                        if (first[nt]) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
+                        if (last[nt]) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+                    }
+                }
+                if (MODE == 1) {
+                    const float yv = ok ? v : 0.f;
+                    q1 += yv;
+                    q2 = fmaf(yv, yv, q2);
+                } else {
+                    const float rawv = a.sums.raw[off];         // (clamped address: always valid)
+                    const float dz = (ok && fmaf(rawv, ssc, ssh) > 0.f) ? v : 0.f;
+                    q1 += dz;
+                    q2 = fmaf(dz, (rawv - mu) * is, q2);
+                }
+            }
+            q1 = row16_sum(q1);
+            q2 = row16_sum(q2);
+            if (r == 0 && cok) { s_sum[(wn * 2 + 0) * MW + co] = q1; s_sum[(wn * 2 + 1) * MW + co] = q2; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * a.cout; i += 256) {
+        const int which = i >= a.cout ? 1 : 0, c = i - which * a.cout;
+        a.sums.partial[((size_t)blockIdx.x * 2 + which) * a.cout + c] = s_sum[which * MW + c] + s_sum[(2 + which) * MW + c];
     }
 }
+
+bool conv1x1_lds_covers(int cin, int cout) {
+    const int tiles = ceil_div(cout, 16);
+    return tiles >= 7 && tiles <= 18 && (cin & 3) == 0 && (cout & 3) == 0 && tune_get(TCR_TUNE_CONV_B) != 3;
+}
+
+int conv1x1_sum_rows(int npos) { return ceil_div(npos, 64); }
 
 int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
     const int tiles = ceil_div(a.cout, 16);
     const int knob = tune_get(TCR_TUNE_CONV_B);
-    if (tiles >= 7 && tiles <= 18 && (a.cin & 3) == 0 && (a.cout & 3) == 0 && knob != 3) {
+    const bool extras = a.in_scale || a.sums.partial;
+    if (conv1x1_lds_covers(a.cin, a.cout)) {
         const int mt = tiles > 12 ? 9 : 6;
         // 2 column tiles per wave = 64 positions per workgroup (3 tiles: 236 VGPRs, 2 waves per SIMD, slower; 4: slower still)
         const dim3 lgrid(ceil_div(a.npos, 64));
+        if (extras) {
+            // training forms: (in-affine + forward sums) with the bias epilogue, or (backward sums) on the raw data gradient
+            const bool fwd = epi == MF_AFFINE && a.in_scale && a.in_shift && a.sums.partial && !a.sums.raw;
+            const bool bwd = epi == MF_RAW && !a.in_scale && a.sums.partial && a.sums.raw && a.sums.mean && a.sums.invstd && a.sums.self_scale && a.sums.self_shift && a.stride == 1;
+            if (!fwd && !bwd) { set_error("conv1x1: unsupported combination of in-affine / epilogue sums"); return TCR_ERR_ARG; }
+#define TCR_LT(MT_)                                                                                                     \
+    if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE, 1>), lgrid, dim3(256), 0, s, a);                \
+    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 2>), lgrid, dim3(256), 0, s, a)
+            if (mt == 9) { TCR_LT(9); } else { TCR_LT(6); }
+#undef TCR_LT
+            return check_launch("conv1x1_lds_kernel");
+        }
 #define TCR_LL(MT_)                                                                                                     \
-    if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW>), lgrid, dim3(256), 0, s, a);            \
-    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE>), lgrid, dim3(256), 0, s, a)
+    if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 0>), lgrid, dim3(256), 0, s, a);         \
+    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE, 0>), lgrid, dim3(256), 0, s, a)
         if (mt == 9) { TCR_LL(9); } else { TCR_LL(6); }
 #undef TCR_LL
         return check_launch("conv1x1_lds_kernel");
     }
+    if (extras) { set_error("conv1x1: in-affine / epilogue sums need the LDS-tiled kernel (%d -> %d channels)", a.cin, a.cout); return TCR_ERR_ARG; }
     const int mt = tiles >= 12 ? 6 : (tiles >= 3 ? 3 : tiles);       // (9 tiles per wave spill: 1.5x slower)       // wide layers: 96 channels per wave halve the re-reads of x
     const dim3 grid(ceil_div(a.npos, 256), ceil_div(tiles, mt));
 #define TCR_L1(MT_)                                                                                         \
@@ -943,6 +1041,11 @@ struct PwWgradArgs {
     const float* dz;        // [B][Cout][Pp]
     float* partial;         // [nchunk][Cin_pad][Cout_pad]
     int batch, cin, cout, cin_pad, cout_pad, p, pp, utt_per_block;
+    int nchunk, nby, nbz;   // launch geometry (see the workgroup -> (chunk, block) map in the kernel)
+    // x is a RAW train-mode conv output (halo unwritten): the A operand is relu(x * x_scale[ci] + x_shift[ci]) for positions < p,
+    // 0 past them -- applied to the fragment as it leaves LDS (a lane's three rows are fixed: six registers)
+    const float* x_scale;
+    const float* x_shift;
 };
 
 __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) {
@@ -953,7 +1056,16 @@ __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int ci0 = blockIdx.y * BT, co0 = blockIdx.z * BT;
+    // XCD-aware workgroup -> tile map.  The nby x nbz blocks of dW that share a chunk of utterances read the same x / dz rows, and
+    // workgroups go to the eight XCDs (each with its own L2) round-robin by linear id: a 3-D grid put the nine blocks of a chunk on
+    // different XCDs, far apart in time -- every operand came from HBM three times (10.1 GB per step for 3.3 GB of tensors).  Here
+    // the workgroups of XCD k (ids k, k + 8, ...) take chunk 8 (j / nb) + k, block j % nb: a chunk's blocks are dispatched back to
+    // back onto ONE XCD and walk the same utterances together, so all but the first read of a row hit that XCD's L2.
+    const int nb = a.nby * a.nbz;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int chunk = (jj / nb) * 8 + xcd, blk = jj % nb;
+    if (chunk >= a.nchunk) return;
+    const int ci0 = (blk % a.nby) * BT, co0 = (blk / a.nby) * BT;
     const int xrows = min(BT, a.cin - ci0), drows = min(BT, a.cout - co0);
     const int xv = xrows * a.pp / 4, dv = drows * a.pp / 4;             // float4 counts (host checks divisibility)
     for (int i = tid; i < 2 * BT * a.pp; i += 256) xs[i] = 0.f;          // rows past the channel count stay zero
@@ -964,12 +1076,17 @@ __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) 
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int ao[3], bo[3];
+    float xsc[3], xsf[3];
+    const bool xaff = a.x_scale != nullptr;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         ao[m] = ((wm + m) * 16 + r) * a.pp + kHalo + q;
         bo[m] = ((wn + m) * 16 + r) * a.pp + kHalo + q;
+        const int ci = ci0 + (wm + m) * 16 + r;
+        xsc[m] = (xaff && ci < a.cin) ? a.x_scale[ci] : 0.f;        // (rows past Cin: relu(0 * 0 + 0) = 0)
+        xsf[m] = (xaff && ci < a.cin) ? a.x_shift[ci] : 0.f;
     }
-    const int n_begin = blockIdx.x * a.utt_per_block;
+    const int n_begin = chunk * a.utt_per_block;
     const int n_end = min(n_begin + a.utt_per_block, a.batch);
     // The next utterance's rows travel global -> registers while the current one is multiplied out of LDS.
     // (Every lane always loads from a valid address -- clamped past the end; 14 named registers rather than an array,
@@ -1002,6 +1119,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) 
             float an[3], bn[3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) { an[m] = xs[ao[m] + k0 + 4]; bn[m] = ds[bo[m] + k0 + 4]; }   // (past the end: next row's halo / pad)
+            if (xaff) {
+                const bool in = k0 + q < a.p;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) af[m] = in ? fmaxf(fmaf(af[m], xsc[m], xsf[m]), 0.f) : 0.f;
+            }
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -1014,7 +1136,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) 
 #undef TCR_PW_ALL
 #undef TCR_PW_ST
 #undef TCR_PW_LD
-    float* dst = a.partial + (size_t)blockIdx.x * a.cin_pad * a.cout_pad;
+    float* dst = a.partial + (size_t)chunk * a.cin_pad * a.cout_pad;
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -1038,9 +1160,12 @@ static bool pw_wgrad_fits(int k, int stride, int cin, int cout, int tpi, int tpo
     return k == 1 && stride == 1 && tpi == tpo && cin > 80 && cout > 80 && cin % 4 == 0 && cout % 4 == 0 && 2 * 96 * tpi <= 14 * 256 * 4;
 }
 
+bool pw_wgrad_lds_covers(int cin, int cout, int tp) { return pw_wgrad_fits(1, 1, cin, cout, tp, tp); }
+
 static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float* scratch, int batch, int cin, int cout, int tpi, int tout,
-                               hipStream_t s) {
+                               hipStream_t s, const float* x_scale, const float* x_shift) {
     PwWgradArgs a;
+    a.x_scale = x_scale; a.x_shift = x_shift;
     a.x = x; a.dz = dy; a.partial = scratch; a.batch = batch; a.cin = cin; a.cout = cout;
     a.cin_pad = ceil_div(cin, 16) * 16; a.cout_pad = ceil_div(cout, 16) * 16; a.p = tout; a.pp = tpi;
     a.utt_per_block = ceil_div(batch, pw_wgrad_chunks(batch));
@@ -1055,10 +1180,11 @@ static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float
         configured = lds;
     }
 #endif
-    const dim3 grid(ceil_div(batch, a.utt_per_block), ceil_div(cin, 96), ceil_div(cout, 96));
+    a.nchunk = ceil_div(batch, a.utt_per_block); a.nby = ceil_div(cin, 96); a.nbz = ceil_div(cout, 96);
+    const dim3 grid(ceil_div(a.nchunk, 8) * 8 * a.nby * a.nbz);
     hipLaunchKernelGGL(pw_wgrad_lds_kernel, grid, dim3(256), lds, s, a);
     TCR_TRY(check_launch("pw_wgrad_lds_kernel"));
-    return launch_wgrad_reduce(scratch, dw, (int)grid.x, 1, cin, cout, a.cin_pad, a.cout_pad, cout, 0, s);
+    return launch_wgrad_reduce(scratch, dw, a.nchunk, 1, cin, cout, a.cin_pad, a.cout_pad, cout, 0, s);
 }
 
 int wgrad_chunks(int batch) {
@@ -1125,9 +1251,10 @@ int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, con
 // dw: [K][Cin][Cout]; scratch: wgrad_partial_floats(...) floats.  Output channels are processed in
 // slices of at most 80 (5 MFMA column tiles per wave).
 int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
-                      int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s) {
+                      int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s, const float* x_scale, const float* x_shift) {
     if (k != 9 && k != 3 && k != 1) { set_error("conv wgrad: kernel %dx1 has no gfx950 instantiation", k); return TCR_ERR_ARG; }
-    if (pw_wgrad_fits(k, stride, cin, cout, tpi, tpo)) return launch_pw_wgrad_lds(x, dy, dw, scratch, batch, cin, cout, tpi, tout, s);
+    if (pw_wgrad_fits(k, stride, cin, cout, tpi, tpo)) return launch_pw_wgrad_lds(x, dy, dw, scratch, batch, cin, cout, tpi, tout, s, x_scale, x_shift);
+    if (x_scale) { set_error("conv wgrad: an in-affine operand needs the pointwise LDS kernel"); return TCR_ERR_ARG; }
     for (int co_base = 0; co_base < cout; co_base += 80) {
         WgradArgs a;
         a.x = x; a.dy = dy; a.partial = scratch;

@@ -634,6 +634,9 @@ class DSCNN(_Base):
         self.lib.check(self.lib.tcr_dscnn_unit_output(self._h, int(unit), int(batch), C.byref(off), C.byref(c), C.byref(pos), C.byref(pad)),
                        "tcr_dscnn_unit_output")
         ws = self.train_workspace(batch)
+        # the default training path keeps only the unit's raw conv output (TCR_TUNE_DS_TRAIN): normalise it into the activation slot
+        self.lib.check(self.lib.tcr_dscnn_materialize_unit(self._h, int(unit), int(batch), ws.data_ptr(), ws.numel() * 4, self._stream()),
+                       "tcr_dscnn_materialize_unit")
         return ws[off.value: off.value + batch * c.value * pad.value].view(batch, c.value, pad.value)[:, :, HALO:HALO + pos.value]
 
     def _stage_sums(self, backward: int, stage: int, ws: torch.Tensor, batch: int) -> torch.Tensor:

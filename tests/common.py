@@ -436,6 +436,40 @@ def check_dscnn_staged_equals_unstaged(lib, size, batch):
         assert torch.equal(a, b), f"DS-CNN-{size}: staged {what} differ from the unstaged run"
 
 
+def check_dscnn_lazy_equals_materialised(lib, size, batch, seed=6):
+    """DS-CNN training with the normalised activations never materialised (default for the 172 / 276-channel nets: BN + ReLU applied by
+    the consumers to the raw conv outputs, statistics / backward sums from the conv and data-gradient epilogues) against the materialising
+    path (TCR_TUNE_DS_TRAIN = 1).  The arithmetic per element is the same; only the ORDER in which the per-channel sums are added
+    differs, so everything agrees to rounding (gradients: a last-bit change of scale / shift may flip ReLU inputs within ~1e-7 of zero).
+    tcr_dscnn_materialize_unit reproduces the activation the other path stores."""
+    import tcresnet_amd as T
+    dev = device_of(lib)
+    rng = np.random.RandomState(seed)
+    t, f = 49, 10
+    feat = T.features_to_planar(torch.from_numpy(rng.uniform(-2, 2, (batch, t, f)).astype(np.float32)).to(dev), lib=lib)
+    labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
+    outs = []
+    try:
+        for knob in (0, 1):
+            lib.tcr_tune(15, knob)
+            ds = T.DSCNN(size, t, f, 12, lib=lib, device=dev)
+            ds.init_xavier(2)
+            lg, _, loss = ds.forward_train(feat, labels)
+            acts = [ds.unit_output(u, batch).clone() for u in (0, 1, 2, lib.tcr_dscnn_num_units(ds._h) - 1)]
+            outs.append((lg.clone(), float(loss), ds.stats.clone(), ds.backward().clone(), acts))
+    finally:
+        lib.tcr_tune(15, 0)
+    a, b = outs
+    assert float((a[0] - b[0]).abs().max()) < 2e-5 and abs(a[1] - b[1]) < 1e-4 * max(1.0, abs(b[1]))
+    assert float((a[2] - b[2]).abs().max()) < 2e-6 * max(1.0, float(b[2].abs().max()))
+    assert float((a[3] - b[3]).abs().max()) < 5e-3 * max(1.0, float(b[3].abs().max()))
+    gm = float(b[3].abs().max())
+    assert float((a[3] - b[3]).abs().mean()) < 2e-5 * max(1.0, gm), (float((a[3] - b[3]).abs().mean()), gm)
+    for x, y in zip(a[4], b[4]):
+        assert x.shape == y.shape and float((x - y).abs().max()) < 1e-5 * max(1.0, float(y.abs().max()))
+    return outs
+
+
 def check_bn_backward_fused_equals_pair(lib, name, width, batch, seed=3, combos=((0, 0), (1, 0), (96, 0), (0, 1), (1, 1))):
     """BN backward with the finalize folded into the apply pass (default) is BITWISE the finalize + apply pair (TCR_TUNE_BWD_BN_FUSED
     = 1): same channel blocks, same slice order of the partial rows -- so also bitwise the staged (sync BN) path at one replica."""

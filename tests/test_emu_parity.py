@@ -149,6 +149,11 @@ def test_bn_backward_fused_equals_pair(emu_lib):
 
 def test_dscnn_staged_sync_bn_api(emu_lib):
     Cm.check_dscnn_staged_equals_unstaged(emu_lib, "S", 3)
+    Cm.check_dscnn_staged_equals_unstaged(emu_lib, "M", 2)      # the lazy path: hand-offs from the epilogue sums
+
+
+def test_dscnn_lazy_training_path_equals_materialised(emu_lib):
+    Cm.check_dscnn_lazy_equals_materialised(emu_lib, "M", 3)
 
 
 def test_forward_waveform_single_call_is_the_three_call_path(emu_lib):

@@ -451,9 +451,16 @@ def test_bn_backward_fused_equals_pair(hip_lib):
     Cm.check_dscnn_mask_paths_agree(hip_lib, "L", 256)
 
 
-@pytest.mark.parametrize("size,batch", [("S", 96), ("L", 1024)])
+@pytest.mark.parametrize("size,batch", [("S", 96), ("M", 100), ("L", 1024)])
 def test_dscnn_staged_sync_bn_api(hip_lib, size, batch):
     Cm.check_dscnn_staged_equals_unstaged(hip_lib, size, batch)
+
+
+@pytest.mark.parametrize("size,batch", [("M", 67), ("L", 256), ("L", 4096)])
+def test_dscnn_lazy_training_path_equals_materialised(hip_lib, size, batch):
+    """Default DS-CNN training (BN + ReLU applied by the consumers, sums from the conv / data-gradient epilogues; ragged and full batches)
+    against the materialising path behind TCR_TUNE_DS_TRAIN = 1."""
+    Cm.check_dscnn_lazy_equals_materialised(hip_lib, size, batch)
 
 
 def test_forward_waveform_single_call_is_the_three_call_path(hip_lib):
