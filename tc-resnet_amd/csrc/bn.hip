@@ -237,11 +237,14 @@ int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t 
 // order: chunk k goes to slice k % nparts, the slices are then added in order), spread over the whole workgroup; or
 // the pre-reduced sums (sync BN).  Returns through s_out[which * cb + (ch - c0)]; ends with a barrier.
 constexpr int kBnCB = 32;           // channels per finalize workgroup (64 columns x 8 slices of chunks)
-// Conv epilogues (EpiSums) leave one row per workgroup / per utterance -- thousands, not <= 512: two channels per workgroup
-// there (4 columns x 128 slices, sixteen times the workgroups), so that a thread adds ~32 rows, sixteen loads in flight (with the
-// 32-channel geometry a finalize over 4160 rows took 47 us, in the backward's dependency chain).  The slice order is a function
-// of the row count only, the same in every kernel that reduces the rows (finalize, chan_sums).
-int bn_finalize_cb(int nchunk) { return nchunk > 1024 ? 2 : kBnCB; }
+// Conv epilogues (EpiSums) leave one row per workgroup / per utterance -- thousands, not <= 512: four channels per workgroup
+// there (8 columns = one 32-byte sector of a row x 64 slices, eight times the workgroups), so that a thread adds ~65 rows, sixteen
+// loads in flight: 17 us per finalize over 4160 rows.  (Measured: the 32-channel geometry 47 us, in the backward's dependency chain;
+// 2 channels x 128 slices as fast but every sector fetched four times; 8 channels x 64 slices in 1024-thread workgroups 113 us -- a
+// 16-wave workgroup waits for a CU that the side stream's long filter-gradient workgroups have drained.)  The slice order is a
+// function of the row count only, the same in every kernel that reduces the rows (finalize, chan_sums).
+int bn_finalize_cb(int nchunk) { return nchunk > 1024 ? 4 : kBnCB; }
+static int bn_finalize_threads(int) { return 512; }
 
 __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk, const double* sums, int nc, int c0, int cb,
                                                 double* s_slices, double* s_out) {
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(512) void chan_sums_kernel(const float* __restrict_
 
 int launch_chan_sums(const float* partial, int nchunk, int c, double* sums, hipStream_t s) {
     const int cbw = bn_finalize_cb(nchunk);
-    hipLaunchKernelGGL(chan_sums_kernel, dim3(ceil_div(c, cbw)), dim3(512), 0, s, partial, nchunk, c, sums, cbw);
+    hipLaunchKernelGGL(chan_sums_kernel, dim3(ceil_div(c, cbw)), dim3(bn_finalize_threads(nchunk)), 0, s, partial, nchunk, c, sums, cbw);
     return check_launch("chan_sums_kernel");
 }
 
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a
 int launch_bn_finalize(const BnFinalizeArgs& a0, hipStream_t s) {
     BnFinalizeArgs a = a0;
     a.cbw = bn_finalize_cb(a.nchunk);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(a.c, a.cbw)), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(a.c, a.cbw)), dim3(bn_finalize_threads(a.nchunk)), 0, s, a);
     return check_launch("bn_finalize_kernel");
 }
 
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const BnBwdFinaliz
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a0, hipStream_t s) {
     BnBwdFinalizeArgs a = a0;
     a.cbw = bn_finalize_cb(a.nchunk);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(a.c, a.cbw)), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(a.c, a.cbw)), dim3(bn_finalize_threads(a.nchunk)), 0, s, a);
     return check_launch("bn_bwd_finalize_kernel");
 }
 

@@ -240,7 +240,9 @@ int launch_dscnn_dw_wgrad(DsDwWgradArgs a, float* dw, hipStream_t s) {
 // (split-K).  The MFMA k dimension holds positions 4 q + c of a 16-position block in step c, so a lane's four k-steps take ONE
 // 16-byte load per channel row (16 rows x 64 contiguous bytes per instruction; the first version gathered 16 rows x 16 bytes per
 // k-step and was bound by the L1's address processing: 1.0 ms for 1.2 GB), and the utterance's small feature map is staged in a
-// wave-private LDS copy, so the 12 patch gathers per block are ds_reads.  BnBwdFly: dz is computed here from the activation
+// wave-private LDS copy, so the 12 patch gathers per block are ds_reads.  (A version that staged the channel rows of an utterance
+// in LDS as one contiguous block -- two 33 KB blocks, two workgroups per CU, a barrier pair per utterance -- moved the minimum 2.4 GB
+// but took 1.49 ms against 1.14: too few waves to cover its load -> barrier -> compute chain, 4-way bank conflicts on rows 258 floats apart.)  BnBwdFly: dz is computed here from the activation
 // gradient and the unit's raw output (conv_1's dy has no other reader: no bn_bwd_apply pass, 3.6 GB less per step).
 struct __attribute__((packed, aligned(4))) f32x4u { float v[4]; };
 
@@ -293,45 +295,57 @@ __global__ __launch_bounds__(256) void dscnn_conv1_wgrad_kernel(const DsConv1Wgr
         const size_t nb = (size_t)n * a.cout * a.pp;
         const float* dr = (fly ? a.fly.da : a.dz) + nb;
         const float* rr = fly ? a.fly.raw + nb : dr;
-        for (int p0 = 0; p0 < P; p0 += 16) {
-            const int pb = p0 + 4 * q;
-            // B operands: four consecutive positions of each channel row in one (unaligned) 16-byte load; positions past the map are
-            // masked below (the load itself stays inside the workspace: rows carry halos, the gradient buffers a tail pad)
-            float bv[NCO][4];
+        for (int p0 = 0; p0 < P; p0 += 64) {
+            // B operands: FOUR 16-position blocks per trip -- block i holds positions p0 + 16 i + 4 q + c --, each one (unaligned)
+            // 16-byte load per channel row, issued back to back: the four loads of a row consume whole 128-byte lines at once.
+            // (One block per trip left every line half-used until the next trip; with ~18 waves x 64 rows live per CU the lines were
+            // evicted in between: 5.9 GB of HBM traffic for 2.4 GB of tensors.)  Positions past the map are masked below (the loads
+            // stay inside the workspace: rows carry halos, the gradient buffers a tail pad).
+            f32x4u d4[NCO][4], y4[NCO][4];
 #pragma unroll
-            for (int m = 0; m < NCO; ++m) {
-                const f32x4u d4 = *reinterpret_cast<const f32x4u*>(dr + crow[m] + pb);
-                if (fly) {
-                    const f32x4u y4 = *reinterpret_cast<const f32x4u*>(rr + crow[m] + pb);
+            for (int m = 0; m < NCO; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pc = min(p0 + 16 * i + 4 * q, P - 1);       // (a whole block past the map: any valid address, masked below)
+                    d4[m][i] = *reinterpret_cast<const f32x4u*>(dr + crow[m] + pc);
+                    if (fly) y4[m][i] = *reinterpret_cast<const f32x4u*>(rr + crow[m] + pc);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pb = p0 + 16 * i + 4 * q;
+                if (p0 + 16 * i >= P) break;                              // (wave-uniform)
+                float bv[NCO][4];
+#pragma unroll
+                for (int m = 0; m < NCO; ++m) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float g = d4.v[c];
-                        if (!(fmaf(y4.v[c], f_sc[m], f_sh[m]) > 0.f)) g = 0.f;
-                        g = f_k1[m] * (g - f_k2[m] - (y4.v[c] - f_mu[m]) * f_k3[m]);
+                        float g = d4[m][i].v[c];
+                        if (fly) {
+                            const float yv = y4[m][i].v[c];
+                            if (!(fmaf(yv, f_sc[m], f_sh[m]) > 0.f)) g = 0.f;
+                            g = f_k1[m] * (g - f_k2[m] - (yv - f_mu[m]) * f_k3[m]);
+                        }
                         bv[m][c] = (cov[m] && pb + c < P) ? g : 0.f;
                     }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) bv[m][c] = (cov[m] && pb + c < P) ? d4.v[c] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int p = min(pb + c, P - 1);
-                const bool pv = pb + c < P;
-                const int oh = fast_div(p, a.ow, inv_ow), ow = p - oh * a.ow;
-                const int hb = oh * a.sh - a.pad_t, wb = ow * a.sw - a.pad_l;
-                float af[MT];
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const int h = hb + ti[t], wc = wb + tj[t];
-                    const bool v = pv && tv[t] && h >= 0 && h < a.h_in && wc >= 0 && wc < a.w_in;
-                    af[t] = v ? sf[wc * a.tp_in + kHalo + h] : 0.f;
                 }
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                for (int c = 0; c < 4; ++c) {
+                    const int p = min(pb + c, P - 1);
+                    const bool pv = pb + c < P;
+                    const int oh = fast_div(p, a.ow, inv_ow), ow = p - oh * a.ow;
+                    const int hb = oh * a.sh - a.pad_t, wb = ow * a.sw - a.pad_l;
+                    float af[MT];
 #pragma unroll
-                    for (int m = 0; m < NCO; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bv[m][c], acc[t][m], 0, 0, 0);
+                    for (int t = 0; t < MT; ++t) {
+                        const int h = hb + ti[t], wc = wb + tj[t];
+                        const bool v = pv && tv[t] && h >= 0 && h < a.h_in && wc >= 0 && wc < a.w_in;
+                        af[t] = v ? sf[wc * a.tp_in + kHalo + h] : 0.f;
+                    }
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int m = 0; m < NCO; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bv[m][c], acc[t][m], 0, 0, 0);
+                }
             }
         }
     }
