@@ -1067,23 +1067,6 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
     TCR_REQUIRE(stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end, "tcr_dscnn_backward: bad stage range [%d, %d)", stage_begin, stage_end);
     const double bn_batch = sync ? (double)global_batch : (double)batch;
     const bool lazy = ds_lazy(*net);
-    if (stage_begin == 0) {
-        // zero the arena: padding and the conv biases (exactly-zero gradient, see above)
-        if (hipMemsetAsync(grads, 0, (size_t)net->param_floats * sizeof(float), s) != hipSuccess) {
-            set_error("tcr_dscnn_backward: hipMemsetAsync failed");
-            return TCR_ERR_HIP;
-        }
-        TCR_TRY(launch_fc_wgrad(base + w.dropped, base + w.dlogits, base + w.fc_partial, grads + net->fcw_off, batch, cl, nc, s));
-        TCR_TRY(launch_bias_grad(base + w.dlogits, batch, nc, grads + net->fcb_off, s));
-        TCR_TRY(launch_head_bwd(base + w.dlogits, params + net->fcw_off, base + w.dscale, base + w.dpool, batch, cl, nc, s));
-    }
-
-    // Filter gradients run on a second stream, overlapped with the BN-backward / data-gradient chain of the units below.
-    // Gradient buffers come from a pool of four, handed out round-robin: a unit's materialised dy (`D`), the activation gradient
-    // its data-gradient kernel writes for the unit below (`gout`).  The side stream reads D -- or, for units whose BN backward is
-    // applied on the fly (BnBwdFly: depthwise and conv_1 in lazy mode), the incoming activation gradient `gin` --, so the main
-    // stream waits for the buffer's last side-stream reader (ev_done) before it writes a buffer again.  The hand-out order is a
-    // function of the unit list only, so a staged run (one host call per stage) recomputes it.
     hipStream_t side = s;
     if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) {
         if (!net->side) {
@@ -1095,6 +1078,28 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         }
         side = net->side;
     }
+    if (stage_begin == 0) {
+        // zero the arena: padding and the conv biases (exactly-zero gradient, see above)
+        if (hipMemsetAsync(grads, 0, (size_t)net->param_floats * sizeof(float), s) != hipSuccess) {
+            set_error("tcr_dscnn_backward: hipMemsetAsync failed");
+            return TCR_ERR_HIP;
+        }
+        // the classifier's own gradients feed nothing below: on the side stream (0.2 ms of small kernels out of the main chain)
+        if (side != s && (hipEventRecord(net->ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, net->ev_fork, 0) != hipSuccess)) {
+            set_error("tcr_dscnn_backward: stream fork failed");
+            return TCR_ERR_HIP;
+        }
+        TCR_TRY(launch_fc_wgrad(base + w.dropped, base + w.dlogits, base + w.fc_partial, grads + net->fcw_off, batch, cl, nc, side));
+        TCR_TRY(launch_bias_grad(base + w.dlogits, batch, nc, grads + net->fcb_off, side));
+        TCR_TRY(launch_head_bwd(base + w.dlogits, params + net->fcw_off, base + w.dscale, base + w.dpool, batch, cl, nc, s));
+    }
+
+    // Filter gradients run on a second stream, overlapped with the BN-backward / data-gradient chain of the units below.
+    // Gradient buffers come from a pool of four, handed out round-robin: a unit's materialised dy (`D`), the activation gradient
+    // its data-gradient kernel writes for the unit below (`gout`).  The side stream reads D -- or, for units whose BN backward is
+    // applied on the fly (BnBwdFly: depthwise and conv_1 in lazy mode), the incoming activation gradient `gin` --, so the main
+    // stream waits for the buffer's last side-stream reader (ev_done) before it writes a buffer again.  The hand-out order is a
+    // function of the unit list only, so a staged run (one host call per stage) recomputes it.
     if (stage_begin == 0) for (bool& r : net->ev_rec) r = false;
     // on the fly: conv_1 (its dy has one reader, and the step ends with it: 0.69 ms of bn_bwd_apply gone from the tail).  The
     // depthwise units measured SLOWER that way (their bn_bwd_apply pass runs in the shadow of the pointwise filter gradient on the
