@@ -96,8 +96,9 @@ int launch_conv_dgrad_mfma(int k, int stride, int pad_lo, const float* w, float*
 bool conv_dgrad_mfma_covers(int k, int stride, int cout);
 int launch_conv_mfma_with_down(const ConvArgs& a, const float* w_down, float* y_down, const float* scale_down,
                                const float* shift_down, int pad_lo, int epi, hipStream_t s);
-size_t wgrad_partial_floats(int k, int cin, int cout, int batch);
+size_t wgrad_partial_floats(int k, int cin, int cout, int batch, bool fine = false);     // fine: see wgrad_chunks_for
 int wgrad_chunks(int batch);
+int wgrad_chunks_for(int batch, bool fine);
 int launch_wgrad_reduce(const float* partial, float* dw, int nchunk, int k, int cin, int cout, int cin_pad, int cout_pad,
                         int cout_all, int co_base, hipStream_t s);
 // x_scale / x_shift (pointwise LDS kernel only): x is a raw conv output, the operand is relu(x * x_scale[ci] + x_shift[ci])
@@ -119,8 +120,8 @@ struct WgradReduceMulti {
 };
 bool conv_wgrad_deferrable(int k, int cin, int cout);         // single slab (Cout <= 80), slab kernel
 int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, const float* dy, float* scratch, int batch, int cin, int cout,
-                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s);
-WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const float* scratch, float* dw);
+                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine = false);
+WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const float* scratch, float* dw, bool fine = false);
 int launch_wgrad_reduce_multi(const WgradReduceMulti& m, hipStream_t s);
 struct DgradWeightsEntry {
     const float* w;

@@ -1194,11 +1194,21 @@ int wgrad_chunks(int batch) {
     return n;
 }
 
-size_t wgrad_partial_floats(int k, int cin, int cout, int batch) {
+// `fine`: four times the split-K workgroups (>= 4 utterances each).  Measured on the step's LAST filter gradient (the first conv's:
+// 384 workgroups = 1.5 waves per SIMD walking 104 dependent load -> MFMA steps, 49 us alone on the chip): 66 us, and its 512-slab
+// reduction 40 us instead of a share of 18 -- the reduction's four lanes per output walk the slabs serially.  Not used.
+int wgrad_chunks_for(int batch, bool fine) {
+    if (!fine) return wgrad_chunks(batch);
+    int n = ceil_div(batch, 4);
+    if (n > 512) n = 512;
+    return n < 1 ? 1 : n;
+}
+
+size_t wgrad_partial_floats(int k, int cin, int cout, int batch, bool fine) {
     const int cin_pad = ceil_div(cin, 16) * 16;
     const int cs = cout > 80 ? 80 : cout;
     const int cout_pad = ceil_div(cs, 16) * 16;
-    const size_t slab = (size_t)wgrad_chunks(batch) * k * cin_pad * cout_pad;
+    const size_t slab = (size_t)wgrad_chunks_for(batch, fine) * k * cin_pad * cout_pad;
     const size_t pw = (k == 1 && cin > 80 && cout > 80) ? (size_t)pw_wgrad_chunks(batch) * cin_pad * (ceil_div(cout, 16) * 16) : 0;   // pw_wgrad_lds_kernel
     return slab > pw ? slab : pw;
 }
@@ -1217,16 +1227,16 @@ static int launch_wgrad_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s)
 
 bool conv_wgrad_deferrable(int k, int cin, int cout) { return (k == 9 || k == 3 || k == 1) && cout <= 80 && !(k == 1 && cin > 80 && cout > 80); }
 
-WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const float* scratch, float* dw) {
+WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const float* scratch, float* dw, bool fine) {
     WgradReduceEntry e;
     e.partial = scratch; e.dw = dw; e.k = k; e.cin = cin; e.cout = cout;
     e.cin_pad = ceil_div(cin, 16) * 16; e.cout_pad = ceil_div(cout, 16) * 16;
-    e.nchunk = ceil_div(batch, ceil_div(batch, wgrad_chunks(batch)));
+    e.nchunk = ceil_div(batch, ceil_div(batch, wgrad_chunks_for(batch, fine)));
     return e;
 }
 
 int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, const float* dy, float* scratch, int batch, int cin, int cout,
-                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s) {
+                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine) {
     if (!conv_wgrad_deferrable(k, cin, cout)) { set_error("conv wgrad: shape %dx1 %d->%d cannot defer its reduction", k, cin, cout); return TCR_ERR_ARG; }
     WgradArgs a;
     a.x = x; a.dy = dy; a.partial = scratch;
@@ -1235,7 +1245,7 @@ int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, con
     a.cout_pad = ceil_div(cout, 16) * 16;
     a.tpi = tpi; a.tout = tout; a.tpo = tpo; a.stride = stride;
     a.xoff = kHalo - pad_lo;
-    const int nchunk = wgrad_chunks(batch);
+    const int nchunk = wgrad_chunks_for(batch, fine);
     a.utt_per_block = ceil_div(batch, nchunk);
     const dim3 grid(ceil_div(batch, a.utt_per_block), a.cin_pad / 16);
     const int nco = a.cout_pad / 16;
@@ -1244,7 +1254,7 @@ int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, con
     else if (k == 3) rc = launch_wgrad_k<3>(a, nco, grid, s);
     else rc = launch_wgrad_k<1>(a, nco, grid, s);
     TCR_TRY(rc);
-    if (entry) *entry = conv_wgrad_entry(k, cin, cout, batch, scratch, nullptr);
+    if (entry) *entry = conv_wgrad_entry(k, cin, cout, batch, scratch, nullptr, fine);
     return TCR_OK;
 }
 

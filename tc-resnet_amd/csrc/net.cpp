@@ -43,8 +43,11 @@ struct tcr_net {
     // their own split-K slab, so they overlap the data-gradient / BN-backward chain of the layers below (each kernel of a
     // training step is too short to fill the chip on its own).  Created on first use; joined before the slab reduction.
     mutable hipStream_t side = nullptr;
-    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_down = nullptr;
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_down = nullptr, ev_join2 = nullptr;
+    mutable hipStream_t side2 = nullptr;        // the classifier's filter gradient (nothing below depends on it)
     ~tcr_net() {
+        if (ev_join2) (void)hipEventDestroy(ev_join2);
+        if (side2) (void)hipStreamDestroy(side2);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_down) (void)hipEventDestroy(ev_down);
@@ -551,7 +554,9 @@ static int side_stream(const tcr_net& net, hipStream_t* out) {
         if (hipStreamCreateWithFlags(&net.side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&net.ev_down, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&net.ev_down, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&net.ev_join2, hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&net.side2, hipStreamNonBlocking) != hipSuccess) {
             set_error("cannot create the internal side stream");
             return TCR_ERR_HIP;
         }
@@ -1049,14 +1054,15 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     if (!(parts & BWD_WGRAD)) {
         // (not this call)
     } else if (conv_wgrad_deferrable(l.k, l.cin, l.cout)) {     // slabs summed for all layers at once at the end of backward
-        if (c.side != c.s && bn_stream != c.side) {     // fork: the side stream waits for dy, the main stream carries on
+        hipStream_t ws = u.li == 0 ? c.s : c.side;      // (the first conv's: the step's last, on the main stream -- see reduce_slabs)
+        if (ws != c.s && bn_stream != c.side) {         // fork: the side stream waits for dy, the main stream carries on
             if (hipEventRecord(c.net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(c.side, c.net->ev_fork, 0) != hipSuccess) {
                 set_error("tcr_net_backward: stream fork failed");
                 return TCR_ERR_HIP;
             }
         }
         TCR_TRY(launch_conv_wgrad_partial(l.k, l.stride, l.pad_lo, x, dy, c.base + c.w.wg[u.li], c.batch, l.cin, l.cout, tpi, l.tout, tp,
-                                          nullptr, c.side));
+                                          nullptr, ws));
     } else {
         // Wide layers (Cout > 80) reduce their slabs at once through the shared scratch, on the main stream.  When this unit's BN
         // backward ran early on the side stream (a block's shortcut), dy is written THERE: the main stream waits for it first.
@@ -1265,20 +1271,33 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     TCR_REQUIRE(plan || (stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end), "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);
     const float* dpool = c.base + c.w.dpool;
     const bool bwd_phases = !plan && bwd_phases_usable(c, dpool);
-    auto reduce_slabs = [&]() -> int {      // every layer's split-K slabs -> dW, one launch (after the side stream has drained)
-        if (c.side != c.s && (hipEventRecord(net->ev_join, c.side) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join, 0) != hipSuccess)) {
+    // Every layer's split-K slabs -> dW.  The side stream is the longer one at the end of a step (it still holds block 0's filter
+    // gradients when the main chain has finished), so the FIRST conv's filter gradient runs on the main stream (bwd_unit_post) and the
+    // slabs are summed where their producers ran: the first conv's on the main stream, all others behind the side stream's last
+    // kernel; then the join.
+    auto reduce_slabs = [&]() -> int {
+        const bool split = c.side != c.s;
+        auto run = [&](int which, hipStream_t st) -> int {      // 0: every layer but the first conv, 1: the first conv, 2: all
+            WgradReduceMulti rm;
+            rm.n = 0;
+            for (int li : order) {
+                const ConvLayer& l = net->layers[li];
+                if (!conv_wgrad_deferrable(l.k, l.cin, l.cout)) continue;
+                if ((which == 0 && li == 0) || (which == 1 && li != 0)) continue;
+                if (rm.n == kMultiMax) { TCR_TRY(launch_wgrad_reduce_multi(rm, st)); rm.n = 0; }
+                rm.e[rm.n++] = conv_wgrad_entry(l.k, l.cin, l.cout, batch, c.base + c.w.wg[li], grads + l.w_off);
+            }
+            return rm.n ? launch_wgrad_reduce_multi(rm, st) : TCR_OK;
+        };
+        if (!split) return run(2, c.s);
+        TCR_TRY(run(0, c.side));
+        TCR_TRY(run(1, c.s));
+        if (hipEventRecord(net->ev_join, c.side) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join, 0) != hipSuccess ||
+            hipEventRecord(net->ev_join2, net->side2) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join2, 0) != hipSuccess) {
             set_error("tcr_net_backward: stream join failed");
             return TCR_ERR_HIP;
         }
-        WgradReduceMulti rm;
-        rm.n = 0;
-        for (int li : order) {
-            const ConvLayer& l = net->layers[li];
-            if (!conv_wgrad_deferrable(l.k, l.cin, l.cout)) continue;
-            if (rm.n == kMultiMax) { TCR_TRY(launch_wgrad_reduce_multi(rm, c.s)); rm.n = 0; }
-            rm.e[rm.n++] = conv_wgrad_entry(l.k, l.cin, l.cout, batch, c.base + c.w.wg[li], grads + l.w_off);
-        }
-        return launch_wgrad_reduce_multi(rm, c.s);
+        return TCR_OK;
     };
     if (plan) { stage_begin = plan->first ? 0 : 1; stage_end = stage_begin + 1; }
     for (int st = stage_begin; st < stage_end; ++st) {
@@ -1289,8 +1308,14 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
                 return TCR_ERR_HIP;
             }
             const int nc = net->cfg.num_classes;
+            // the classifier's own filter gradient feeds nothing below: on a stream of its own (behind the arena's zero fill)
+            hipStream_t fs = c.side != c.s ? net->side2 : c.s;
+            if (fs != c.s && (hipEventRecord(net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(fs, net->ev_fork, 0) != hipSuccess)) {
+                set_error("tcr_net_backward: stream fork failed");
+                return TCR_ERR_HIP;
+            }
             TCR_TRY(launch_fc_wgrad(c.base + c.w.dropped, c.base + c.w.dlogits, c.base + c.w.fc_partial,
-                                    grads + net->layers[net->fc].w_off, batch, net->feat_c, nc, c.s));
+                                    grads + net->layers[net->fc].w_off, batch, net->feat_c, nc, fs));
             TCR_TRY(launch_head_bwd(c.base + c.w.dlogits, params + net->layers[net->fc].w_off, c.base + c.w.dscale,
                                     c.base + c.w.dpool, batch, net->feat_c, nc, c.s));
             // re-arranged (phase-major, transposed) weights of every data-gradient conv, one launch
