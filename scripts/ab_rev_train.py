@@ -43,3 +43,18 @@ for name, ch in (("TCResNet8", [16, 24, 32, 48]), ("TCResNet14", [24, 36, 36, 48
             def train():
                 net.forward_train(feat, lab, keep_prob=0.5, seed=1); net.backward(); net.sgd_momentum_step(0.1, 0.9, 0.001)
             print(f"  {name} {k}: {timeit(train):9.1f} us", flush=True)
+
+if os.environ.get("AB_DS", "1") == "1":
+    fe3 = T.Frontend(window_size_samples=640, window_stride_samples=320, num_mfccs=10, device=dev)
+    feat3 = fe3(wav)
+    dsn = {}
+    for k, lib in libs.items():
+        ds = T.DSCNN("L", fe3.n_frames, 10, 12, lib=lib, device=dev); ds.init_xavier(0)
+        dsn[k] = ds
+    for rnd in range(3):
+        for k, ds in dsn.items():
+            st = [0]
+            def train_ds():
+                st[0] += 1
+                ds.forward_train(feat3, lab); ds.backward(); ds.adam_step(5e-4, st[0])
+            print(f"  DSCNN-L {k}: train step {timeit(train_ds, n=10, warm=3):9.1f} us   eval forward {timeit(lambda: ds.forward_infer(feat3), n=10, warm=3):9.1f} us", flush=True)
