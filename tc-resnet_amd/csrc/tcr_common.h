@@ -100,19 +100,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 // step).  After steps 1-2 all lanes of a quad agree, so the mirrors pair every quad with the one an xor 4 / xor 8 would:
 // the result is bitwise the xor-butterfly's (same pairs, commutative adds).
 __device__ __forceinline__ float row16_sum(float v) {
-#if defined(TCR_HOST_EMULATION)
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    return v;
-#else
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
     return v;
-#endif
 }
 
 // Stateless counter-based uniform in [0,1): two rounds of a 32-bit mixer over (seed, index).

@@ -294,6 +294,19 @@ template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
     int src = ((l & (width - 1)) >= (int)d) ? l - (int)d : l;
     return emu::shfl(v, src);
 }
+// v_mov_b32 with a DPP operand, for the row-local controls the kernels use (all lanes active, bound_ctrl: a lane without a source
+// would read 0 -- none of these controls leaves one): quad_perm (0x00-0xFF), row_mirror (0x140), row_half_mirror (0x141).
+static inline int __builtin_amdgcn_update_dpp_emu(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+    const int l = emu::lane_id();
+    int from = l;
+    if (ctrl >= 0 && ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+    else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
+    else { fprintf(stderr, "[hip-emu] DPP control 0x%x is not emulated\n", ctrl); abort(); }
+    return emu::shfl(src, from);
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) __builtin_amdgcn_update_dpp_emu(old, src, ctrl, rm, bm, bc)
 static inline void __builtin_amdgcn_wave_barrier_emu() { emu::wave_barrier(); }
 #define __builtin_amdgcn_wave_barrier() __builtin_amdgcn_wave_barrier_emu()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
