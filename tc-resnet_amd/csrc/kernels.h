@@ -104,7 +104,7 @@ int launch_wgrad_reduce(const float* partial, float* dw, int nchunk, int k, int 
 // x_scale / x_shift (pointwise LDS kernel only): x is a raw conv output, the operand is relu(x * x_scale[ci] + x_shift[ci])
 int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
                       int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s,
-                      const float* x_scale = nullptr, const float* x_shift = nullptr);
+                      const float* x_scale = nullptr, const float* x_shift = nullptr, bool x_slack = false);
 // Training engines that give every layer its own partial-slab scratch launch only the split-K kernel per layer
 // (launch_conv_wgrad_partial) and sum all layers' slabs in ONE launch at the end of backward (launch_wgrad_reduce_multi);
 // likewise the re-arranged data-gradient weights of every layer are produced by one launch up front.
@@ -120,7 +120,8 @@ struct WgradReduceMulti {
 };
 bool conv_wgrad_deferrable(int k, int cin, int cout);         // single slab (Cout <= 80), slab kernel
 int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, const float* dy, float* scratch, int batch, int cin, int cout,
-                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine = false);
+                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine = false, bool x_slack = false);
+// x_slack: x and dy are followed by >= 64 readable floats (tensors inside a workspace): allows the 16-byte-load kernel
 WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const float* scratch, float* dw, bool fine = false);
 int launch_wgrad_reduce_multi(const WgradReduceMulti& m, hipStream_t s);
 struct DgradWeightsEntry {

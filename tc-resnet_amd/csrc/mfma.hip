@@ -895,6 +895,7 @@ struct WgradArgs {
     int tpi, tout, tpo, stride;
     int xoff;               // HALO - pad_lo
     int utt_per_block;
+    int pcol = 0;           // first column of this launch inside the [.][Cout_pad] slab rows (a layer split into channel slices that share one slab)
 };
 
 template <int K, int NCO>
@@ -972,7 +973,107 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradArgs a)
         const int row = (i / (NCO * 16)) % 16;
         const int j = i / (NCO * 16 * 16);
         const int cig = blockIdx.y * 16 + row;
-        if (cig < a.cin_pad && col < a.cout_pad) dst[((size_t)j * a.cin_pad + cig) * a.cout_pad + col] = s_acc[i];
+        if (cig < a.cin_pad && a.pcol + col < a.cout_pad) dst[((size_t)j * a.cin_pad + cig) * a.cout_pad + a.pcol + col] = s_acc[i];
+    }
+}
+
+// The same contraction with 16-byte operand loads.  The kernel above issues K + NCO gather loads (16 rows x 16 bytes each) per MFMA
+// k-step and its waves -- one or two per SIMD: K x NCO accumulator tiles -- wait out every one of them: the TCResNet14-1.5 layers ran at
+// a third of their matrix-pipe bound and the side stream that carries them became the step's critical path.  Here a trip covers 16
+// positions: lane (r, q) takes positions t0 + 4 q + c (c = 0..3) of its row -- for dy ONE 16-byte load per channel tile, for x the
+// 3 S + K floats that the K taps of its four positions touch ((3 S + K + 3) / 4 loads; tap j of position c is window[c S + j], a
+// compile-time register) -- and feeds four k-steps (k-step c: lane group q supplies position 4 q + c in both operands); a remainder
+// of at most 12 positions goes through 8-position trips (two positions per lane, two k-steps) so that short rows cost no extra
+// k-steps.  Positions
+// past the row are zeroed by selects in both operands (the loads run past the row into the next row / buffer: the caller guarantees
+// x and dy are followed by readable memory -- workspace tensors; the first conv, whose x is the caller's feature buffer, keeps the
+// kernel above).  Another summation order than the kernel above: results agree to rounding, not bitwise.
+struct __attribute__((packed, aligned(4))) wg_f4u { float v[4]; };
+
+// One trip over BS = 16 (8) positions starting at t0: lane (r, q) holds NPL = BS / 4 consecutive positions t0 + NPL q + c of its row.
+// Rows whose length leaves 1..8 positions behind the 16-position trips finish with an 8-position trip (two k-steps): a 7-frame layer
+// costs 2 k-steps, as with the 4-position steps of the kernel above, not 4.
+template <int K, int S, int NCO, int BS>
+__device__ __forceinline__ void wgrad4_trip(f32x4 (&acc)[K][NCO], const float* xr, const float* dr, const int (&doff)[NCO], const bool (&cov)[NCO],
+                                            bool civ, int q, int t0, int tout) {
+    constexpr int NPL = BS / 4, W = (NPL - 1) * S + K, NW4 = (W + 3) / 4;
+    wg_f4u d4[NCO], w4[NW4];
+#pragma unroll
+    for (int m = 0; m < NCO; ++m) d4[m] = *reinterpret_cast<const wg_f4u*>(dr + doff[m] + t0 + NPL * q);      // (NPL = 2: the upper half is not used)
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) w4[i] = *reinterpret_cast<const wg_f4u*>(xr + (t0 + NPL * q) * S + 4 * i);
+#pragma unroll
+    for (int c = 0; c < NPL; ++c) {
+        if (t0 + c >= tout) break;                              // (wave-uniform: no lane has a position in this k-step)
+        const bool pv = t0 + NPL * q + c < tout;
+        float bf[NCO], af[K];
+#pragma unroll
+        for (int m = 0; m < NCO; ++m) bf[m] = (pv && cov[m]) ? d4[m].v[c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) af[j] = (pv && civ) ? w4[(c * S + j) / 4].v[(c * S + j) % 4] : 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int m = 0; m < NCO; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[m], acc[j][m], 0, 0, 0);
+    }
+}
+
+template <int K, int S, int NCO>
+__global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a) {
+    __shared__ float s_acc[K * 16 * NCO * 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int ci = blockIdx.y * 16 + r;
+    const bool civ = ci < a.cin;
+    const int cic = civ ? ci : a.cin - 1;
+
+    f32x4 acc[K][NCO];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int m = 0; m < NCO; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool cov[NCO];
+    int doff[NCO];
+#pragma unroll
+    for (int m = 0; m < NCO; ++m) {
+        cov[m] = m * 16 + r < a.cout;
+        doff[m] = (a.co_base + (cov[m] ? m * 16 + r : 0)) * a.tpo + kHalo;
+    }
+    const int n_begin = blockIdx.x * a.utt_per_block;
+    const int n_end = min(n_begin + a.utt_per_block, a.batch);
+    const int xlane = cic * a.tpi + a.xoff;
+    for (int n = n_begin + wave; n < n_end; n += 4) {
+        const float* xr = a.x + (size_t)n * a.cin * a.tpi + xlane;
+        const float* dr = a.dy + (size_t)n * a.cout_all * a.tpo;
+        int t0 = 0;
+        for (; a.tout - t0 > 12; t0 += 16) wgrad4_trip<K, S, NCO, 16>(acc, xr, dr, doff, cov, civ, q, t0, a.tout);
+        for (; t0 < a.tout; t0 += 8) wgrad4_trip<K, S, NCO, 8>(acc, xr, dr, doff, cov, civ, q, t0, a.tout);
+    }
+    // combine the 4 waves in LDS (fixed order), then write the slab
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int m = 0; m < NCO; ++m)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int row = q * 4 + reg;        // ci within the tile
+                        const int idx = ((j * 16 + row) * NCO + m) * 16 + r;
+                        if (wv == 0) s_acc[idx] = acc[j][m][reg];
+                        else s_acc[idx] += acc[j][m][reg];
+                    }
+        }
+        __syncthreads();
+    }
+    float* dst = a.partial + (size_t)blockIdx.x * K * a.cin_pad * a.cout_pad;
+    for (int i = threadIdx.x; i < K * 16 * NCO * 16; i += 256) {
+        const int col = i % (NCO * 16);
+        const int row = (i / (NCO * 16)) % 16;
+        const int j = i / (NCO * 16 * 16);
+        const int cig = blockIdx.y * 16 + row;
+        if (cig < a.cin_pad && a.pcol + col < a.cout_pad) dst[((size_t)j * a.cin_pad + cig) * a.cout_pad + a.pcol + col] = s_acc[i];
     }
 }
 
@@ -1213,8 +1314,27 @@ size_t wgrad_partial_floats(int k, int cin, int cout, int batch, bool fine) {
     return slab > pw ? slab : pw;
 }
 
+template <int K, int S>
+static int launch_wgrad4_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s) {
+    switch (nco) {
+        case 1: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 1>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 2>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 3>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 4>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 5>), grid, dim3(256), 0, s, a); break;
+    }
+    return check_launch("conv_wgrad_mfma4_kernel");
+}
+
+// x_slack: x (and dy) are followed by readable memory (workspace tensors) -> the 16-byte-load kernel for the shapes it has
+static bool wgrad4_covers(int k, int stride, bool x_slack) { return x_slack && (k == 9 || k == 1) && (stride == 1 || stride == 2) && tune_get(TCR_TUNE_CONV_B) != 3; }
+
 template <int K>
-static int launch_wgrad_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s) {
+static int launch_wgrad_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s, bool x_slack = false) {
+    if (K != 3 && wgrad4_covers(K, a.stride, x_slack)) {
+        constexpr int KK = K == 3 ? 9 : K;          // (K = 3 never takes this branch)
+        return a.stride == 1 ? launch_wgrad4_k<KK, 1>(a, nco, grid, s) : launch_wgrad4_k<KK, 2>(a, nco, grid, s);
+    }
     switch (nco) {
         case 1: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<K, 1>), grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<K, 2>), grid, dim3(256), 0, s, a); break;
@@ -1236,7 +1356,7 @@ WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const flo
 }
 
 int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, const float* dy, float* scratch, int batch, int cin, int cout,
-                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine) {
+                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine, bool x_slack) {
     if (!conv_wgrad_deferrable(k, cin, cout)) { set_error("conv wgrad: shape %dx1 %d->%d cannot defer its reduction", k, cin, cout); return TCR_ERR_ARG; }
     WgradArgs a;
     a.x = x; a.dy = dy; a.partial = scratch;
@@ -1249,11 +1369,23 @@ int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, con
     a.utt_per_block = ceil_div(batch, nchunk);
     const dim3 grid(ceil_div(batch, a.utt_per_block), a.cin_pad / 16);
     const int nco = a.cout_pad / 16;
-    int rc;
-    if (k == 9) rc = launch_wgrad_k<9>(a, nco, grid, s);
-    else if (k == 3) rc = launch_wgrad_k<3>(a, nco, grid, s);
-    else rc = launch_wgrad_k<1>(a, nco, grid, s);
-    TCR_TRY(rc);
+    // 9-tap layers of 4-5 channel tiles (TCResNet14-1.5's 72 channels): 36-45 accumulator tiles leave ONE wave per SIMD, and the side
+    // stream that carries these kernels was the critical path of that step.  Launches of two tiles each into the same slab run three
+    // waves per SIMD (x is read once per launch: small against the latency hidden).  TCResNet14-1.5 step at batch 4096 by tiles per
+    // launch: 5 -> 3255 us, 3 -> 3012, 2 -> 2960, 1 -> 3116; TCResNet8 (<= 3 tiles per layer): 1048 / 1048 / 1054 / 1118 -- so only
+    // layers of more than three tiles are split (TCR_TUNE_WGRAD_TILES overrides).
+    const int tk = tune_get(TCR_TUNE_WGRAD_TILES);
+    const int tiles_per_launch = (k == 9 && wgrad4_covers(k, stride, x_slack)) ? (tk > 0 ? min(tk, nco) : (nco > 3 ? 2 : nco)) : nco;
+    for (int t0 = 0; t0 < nco; t0 += tiles_per_launch) {
+        WgradArgs b = a;
+        const int nt = min(tiles_per_launch, nco - t0);
+        b.co_base = t0 * 16; b.pcol = t0 * 16; b.cout = min(cout - t0 * 16, nt * 16);
+        int rc;
+        if (k == 9) rc = launch_wgrad_k<9>(b, nt, grid, s, x_slack);
+        else if (k == 3) rc = launch_wgrad_k<3>(b, nt, grid, s);
+        else rc = launch_wgrad_k<1>(b, nt, grid, s, x_slack);
+        TCR_TRY(rc);
+    }
     if (entry) *entry = conv_wgrad_entry(k, cin, cout, batch, scratch, nullptr, fine);
     return TCR_OK;
 }
@@ -1261,7 +1393,7 @@ int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, con
 // dw: [K][Cin][Cout]; scratch: wgrad_partial_floats(...) floats.  Output channels are processed in
 // slices of at most 80 (5 MFMA column tiles per wave).
 int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float* dy, float* dw, float* scratch,
-                      int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s, const float* x_scale, const float* x_shift) {
+                      int batch, int cin, int cout, int tpi, int tout, int tpo, hipStream_t s, const float* x_scale, const float* x_shift, bool x_slack) {
     if (k != 9 && k != 3 && k != 1) { set_error("conv wgrad: kernel %dx1 has no gfx950 instantiation", k); return TCR_ERR_ARG; }
     if (pw_wgrad_fits(k, stride, cin, cout, tpi, tpo)) return launch_pw_wgrad_lds(x, dy, dw, scratch, batch, cin, cout, tpi, tout, s, x_scale, x_shift);
     if (x_scale) { set_error("conv wgrad: an in-affine operand needs the pointwise LDS kernel"); return TCR_ERR_ARG; }
@@ -1281,9 +1413,9 @@ int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float
         const dim3 grid(ceil_div(batch, a.utt_per_block), a.cin_pad / 16);
         const int nco = a.cout_pad / 16;
         int rc;
-        if (k == 9) rc = launch_wgrad_k<9>(a, nco, grid, s);
+        if (k == 9) rc = launch_wgrad_k<9>(a, nco, grid, s, x_slack);
         else if (k == 3) rc = launch_wgrad_k<3>(a, nco, grid, s);
-        else rc = launch_wgrad_k<1>(a, nco, grid, s);
+        else rc = launch_wgrad_k<1>(a, nco, grid, s, x_slack);
         TCR_TRY(rc);
         TCR_TRY(launch_wgrad_reduce(scratch, dw, (int)grid.x, k, cin, a.cout, a.cin_pad, a.cout_pad, cout, co_base, s));
     }

@@ -1062,7 +1062,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
             }
         }
         TCR_TRY(launch_conv_wgrad_partial(l.k, l.stride, l.pad_lo, x, dy, c.base + c.w.wg[u.li], c.batch, l.cin, l.cout, tpi, l.tout, tp,
-                                          nullptr, ws));
+                                          nullptr, ws, false, l.in_act >= 0));
     } else {
         // Wide layers (Cout > 80) reduce their slabs at once through the shared scratch, on the main stream.  When this unit's BN
         // backward ran early on the side stream (a block's shortcut), dy is written THERE: the main stream waits for it first.
@@ -1071,7 +1071,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
             return TCR_ERR_HIP;
         }
         TCR_TRY(launch_conv_wgrad(l.k, l.stride, l.pad_lo, x, dy, grads + l.w_off, c.base + c.w.wgrad_scratch,
-                                  c.batch, l.cin, l.cout, tpi, l.tout, tp, c.s));
+                                  c.batch, l.cin, l.cout, tpi, l.tout, tp, c.s, nullptr, nullptr, l.in_act >= 0));
     }
     if (l.in_act < 0 || !(parts & BWD_DGRAD)) return TCR_OK;        // (no gradient flows into the features)
     // data gradient into gact[in_act]; the shortcut branch of the block adds its contribution in the same pass
