@@ -993,15 +993,22 @@ struct __attribute__((packed, aligned(4))) wg_f4u { float v[4]; };
 // One trip over BS = 16 (8) positions starting at t0: lane (r, q) holds NPL = BS / 4 consecutive positions t0 + NPL q + c of its row.
 // Rows whose length leaves 1..8 positions behind the 16-position trips finish with an 8-position trip (two k-steps): a 7-frame layer
 // costs 2 k-steps, as with the 4-position steps of the kernel above, not 4.
-template <int K, int S, int NCO, int BS>
+template <int K, int S, int NCO, int BS, bool SAFE>
 __device__ __forceinline__ void wgrad4_trip(f32x4 (&acc)[K][NCO], const float* xr, const float* dr, const int (&doff)[NCO], const bool (&cov)[NCO],
-                                            bool civ, int q, int t0, int tout) {
+                                            bool civ, int q, int t0, int tout, bool safe, int xmax) {
     constexpr int NPL = BS / 4, W = (NPL - 1) * S + K, NW4 = (W + 3) / 4;
     wg_f4u d4[NCO], w4[NW4];
 #pragma unroll
     for (int m = 0; m < NCO; ++m) d4[m] = *reinterpret_cast<const wg_f4u*>(dr + doff[m] + t0 + NPL * q);      // (NPL = 2: the upper half is not used)
+    if (!SAFE || !safe) {
 #pragma unroll
-    for (int i = 0; i < NW4; ++i) w4[i] = *reinterpret_cast<const wg_f4u*>(xr + (t0 + NPL * q) * S + 4 * i);
+        for (int i = 0; i < NW4; ++i) w4[i] = *reinterpret_cast<const wg_f4u*>(xr + (t0 + NPL * q) * S + 4 * i);
+    } else {            // (wave-uniform) the last rows of a buffer with nothing behind it: element loads clamped to the row
+#pragma unroll
+        for (int i = 0; i < NW4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w4[i].v[e] = xr[min((t0 + NPL * q) * S + 4 * i + e, xmax)];
+    }
 #pragma unroll
     for (int c = 0; c < NPL; ++c) {
         if (t0 + c >= tout) break;                              // (wave-uniform: no lane has a position in this k-step)
@@ -1018,7 +1025,7 @@ __device__ __forceinline__ void wgrad4_trip(f32x4 (&acc)[K][NCO], const float* x
     }
 }
 
-template <int K, int S, int NCO>
+template <int K, int S, int NCO, bool SAFE>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a) {
     __shared__ float s_acc[K * 16 * NCO * 16];
     const int lane = threadIdx.x & 63;
@@ -1043,12 +1050,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a
     const int n_begin = blockIdx.x * a.utt_per_block;
     const int n_end = min(n_begin + a.utt_per_block, a.batch);
     const int xlane = cic * a.tpi + a.xoff;
+    const int xmax = a.tpi - 1 - a.xoff;            // last element of a row, relative to xr
     for (int n = n_begin + wave; n < n_end; n += 4) {
         const float* xr = a.x + (size_t)n * a.cin * a.tpi + xlane;
         const float* dr = a.dy + (size_t)n * a.cout_all * a.tpo;
+        const bool safe = SAFE && n == a.batch - 1;
         int t0 = 0;
-        for (; a.tout - t0 > 12; t0 += 16) wgrad4_trip<K, S, NCO, 16>(acc, xr, dr, doff, cov, civ, q, t0, a.tout);
-        for (; t0 < a.tout; t0 += 8) wgrad4_trip<K, S, NCO, 8>(acc, xr, dr, doff, cov, civ, q, t0, a.tout);
+        for (; a.tout - t0 > 12; t0 += 16) wgrad4_trip<K, S, NCO, 16, SAFE>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax);
+        for (; t0 < a.tout; t0 += 8) wgrad4_trip<K, S, NCO, 8, SAFE>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax);
     }
     // combine the 4 waves in LDS (fixed order), then write the slab
     for (int wv = 0; wv < 4; ++wv) {
@@ -1314,27 +1323,32 @@ size_t wgrad_partial_floats(int k, int cin, int cout, int batch, bool fine) {
     return slab > pw ? slab : pw;
 }
 
-template <int K, int S>
+template <int K, int S, bool SAFE>
 static int launch_wgrad4_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s) {
     switch (nco) {
-        case 1: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 1>), grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 2>), grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 3>), grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 4>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 5>), grid, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 1, SAFE>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 2, SAFE>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 3, SAFE>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 4, SAFE>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 5, SAFE>), grid, dim3(256), 0, s, a); break;
     }
     return check_launch("conv_wgrad_mfma4_kernel");
 }
 
-// x_slack: x (and dy) are followed by readable memory (workspace tensors) -> the 16-byte-load kernel for the shapes it has
-static bool wgrad4_covers(int k, int stride, bool x_slack) { return x_slack && (k == 9 || k == 1) && (stride == 1 || stride == 2) && tune_get(TCR_TUNE_CONV_B) != 3; }
+// x_slack: x is followed by readable memory (a workspace tensor).  The first conv (3 x 1, stride 1) reads the caller's feature buffer:
+// its instantiation sends the batch's last utterance through element loads clamped to the row (dy is always a workspace tensor).
+static bool wgrad4_covers(int k, int stride, bool x_slack) {
+    return ((k == 9 || k == 1) ? (x_slack && (stride == 1 || stride == 2)) : (k == 3 && stride == 1)) && tune_get(TCR_TUNE_CONV_B) != 3;
+}
 
 template <int K>
-static int launch_wgrad_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s, bool x_slack = false) {
-    if (K != 3 && wgrad4_covers(K, a.stride, x_slack)) {
-        constexpr int KK = K == 3 ? 9 : K;          // (K = 3 never takes this branch)
-        return a.stride == 1 ? launch_wgrad4_k<KK, 1>(a, nco, grid, s) : launch_wgrad4_k<KK, 2>(a, nco, grid, s);
+static int launch_wgrad_k(const WgradArgs& a0, int nco, dim3 grid, hipStream_t s, bool x_slack = false) {
+    if (wgrad4_covers(K, a0.stride, x_slack)) {
+        if (K == 3) return x_slack ? launch_wgrad4_k<3, 1, false>(a0, nco, grid, s) : launch_wgrad4_k<3, 1, true>(a0, nco, grid, s);
+        constexpr int KK = K == 3 ? 9 : K;
+        return a0.stride == 1 ? launch_wgrad4_k<KK, 1, false>(a0, nco, grid, s) : launch_wgrad4_k<KK, 2, false>(a0, nco, grid, s);
     }
+    const WgradArgs& a = a0;
     switch (nco) {
         case 1: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<K, 1>), grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<K, 2>), grid, dim3(256), 0, s, a); break;
@@ -1382,7 +1396,7 @@ int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, con
         b.co_base = t0 * 16; b.pcol = t0 * 16; b.cout = min(cout - t0 * 16, nt * 16);
         int rc;
         if (k == 9) rc = launch_wgrad_k<9>(b, nt, grid, s, x_slack);
-        else if (k == 3) rc = launch_wgrad_k<3>(b, nt, grid, s);
+        else if (k == 3) rc = launch_wgrad_k<3>(b, nt, grid, s, x_slack);
         else rc = launch_wgrad_k<1>(b, nt, grid, s, x_slack);
         TCR_TRY(rc);
     }
@@ -1414,7 +1428,7 @@ int launch_conv_wgrad(int k, int stride, int pad_lo, const float* x, const float
         const int nco = a.cout_pad / 16;
         int rc;
         if (k == 9) rc = launch_wgrad_k<9>(a, nco, grid, s, x_slack);
-        else if (k == 3) rc = launch_wgrad_k<3>(a, nco, grid, s);
+        else if (k == 3) rc = launch_wgrad_k<3>(a, nco, grid, s, x_slack);
         else rc = launch_wgrad_k<1>(a, nco, grid, s, x_slack);
         TCR_TRY(rc);
         TCR_TRY(launch_wgrad_reduce(scratch, dw, (int)grid.x, k, cin, a.cout, a.cin_pad, a.cout_pad, cout, co_base, s));
