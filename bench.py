@@ -217,11 +217,14 @@ def main():
         pf = FeaturePrefetcher(fe, B, overlap=overlap)
         pf.submit(wav)
 
+        early = FeaturePrefetcher.submit_point(net) == "before_forward"      # (measured per net family: pipeline.py)
+
         def train_step():
             step_no[0] += 1
             f = pf.get()
+            if early: pf.submit(wav)
             dp.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
-            pf.submit(wav)       # issued behind the forward: its LDS-resident phases cannot share a CU with the front-end, the backward can
+            if not early: pf.submit(wav)       # wide nets: the forward's LDS-resident phases cannot share a CU with the front-end, the backward can
             dp.backward()
             net.sgd_momentum_step(0.1, 0.9, 0.001)
 
@@ -238,11 +241,14 @@ def main():
         net14.init_xavier(0)
         dp14 = DataParallel(net14)
 
+        early14 = FeaturePrefetcher.submit_point(net14) == "before_forward"
+
         def train14_step():
             step_no[0] += 1
             f = pf.get()
+            if early14: pf.submit(wav)
             dp14.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
-            pf.submit(wav)
+            if not early14: pf.submit(wav)
             dp14.backward()
             net14.sgd_momentum_step(0.1, 0.9, 0.001)
 
@@ -305,11 +311,14 @@ def main():
         pf2 = FeaturePrefetcher(fe2, B, overlap=overlap)
         pf2.submit(wav)
 
+        early2 = FeaturePrefetcher.submit_point(net2) == "before_forward"
+
         def train2_step():
             step_no[0] += 1
             f = pf2.get()
+            if early2: pf2.submit(wav)
             dp2.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
-            pf2.submit(wav)
+            if not early2: pf2.submit(wav)
             dp2.backward()
             net2.sgd_momentum_step(0.1, 0.9, 0.001)
 

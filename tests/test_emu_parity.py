@@ -183,3 +183,11 @@ def test_forward_waveform_single_call_is_the_three_call_path(emu_lib):
     got3 = net.forward_waveform(fe, wav)
     ref3 = net.forward_infer(fe(wav))
     assert torch.equal(got3[0], ref3[0]) and not torch.equal(got3[0], got[0])
+
+
+def test_prefetch_submit_point_policy(emu_lib):
+    """FeaturePrefetcher.submit_point: the narrow nets take the next batch's front-end in front of their forward, the wide ones behind it."""
+    from tcresnet_amd.pipeline import FeaturePrefetcher
+    n8 = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, 49, 12, lib=emu_lib)
+    n14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, 49, 12, lib=emu_lib)
+    assert FeaturePrefetcher.submit_point(n8) == "before_forward" and FeaturePrefetcher.submit_point(n14) == "after_forward"
