@@ -1304,13 +1304,14 @@ int wgrad_chunks(int batch) {
     return n;
 }
 
-// `fine`: four times the split-K workgroups (>= 4 utterances each).  Measured on the step's LAST filter gradient (the first conv's:
-// 384 workgroups = 1.5 waves per SIMD walking 104 dependent load -> MFMA steps, 49 us alone on the chip): 66 us, and its 512-slab
-// reduction 40 us instead of a share of 18 -- the reduction's four lanes per output walk the slabs serially.  Not used.
+// `fine`: twice the split-K workgroups (>= 8 utterances each) -- for the 9-tap layers of one or two input-channel tiles and >= 20 frames
+// (TCResNet8's first blocks): 128 x (1..2) workgroups put at most one wave on a SIMD, and these are the filter gradients still running
+// when the backward's main chain has ended.  (Four times the workgroups on the old kernel, for the step's last filter gradient only:
+// 49 -> 66 us, and its 512-slab reduction 40 us -- the reduction's four lanes per output walk the slabs serially.)
 int wgrad_chunks_for(int batch, bool fine) {
     if (!fine) return wgrad_chunks(batch);
-    int n = ceil_div(batch, 4);
-    if (n > 512) n = 512;
+    int n = ceil_div(batch, 8);
+    if (n > 256) n = 256;
     return n < 1 ? 1 : n;
 }
 

@@ -59,6 +59,11 @@ namespace tcr {
 
 static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// filter gradients that get the finer split-K grid (mfma.hip: wgrad_chunks_for)
+// (measured: TCResNet8 step -1.5 %; with TCResNet14-1.5's 24 -> 36 channel layers included that step was +1.3 %: their larger slabs cost
+//  more in the reduction than the extra waves win)
+static bool wgrad_fine(const ConvLayer& l) { return l.k == 9 && ((l.cin + 15) / 16) * ((l.cout + 15) / 16) <= 4 && l.tout >= 20; }
+
 // ---- workspace carving ------------------------------------------------------------------------
 struct Workspace {
     // offsets in floats; -1 when absent
@@ -99,7 +104,7 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
             w.gact[i] = take(n);
             w.mean[i] = take(l.c_pad);
             w.invstd[i] = take(l.c_pad);
-            w.wg[i] = take((int64_t)wgrad_partial_floats(l.k, l.cin, l.cout, batch));
+            w.wg[i] = take((int64_t)wgrad_partial_floats(l.k, l.cin, l.cout, batch, true));        // (sized for the finer grid; which layers use it: wgrad_fine)
             w.wtl[i] = take((int64_t)l.k * l.cin * l.cout);
         }
         cmax = l.cout > cmax ? l.cout : cmax;
@@ -1062,7 +1067,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
             }
         }
         TCR_TRY(launch_conv_wgrad_partial(l.k, l.stride, l.pad_lo, x, dy, c.base + c.w.wg[u.li], c.batch, l.cin, l.cout, tpi, l.tout, tp,
-                                          nullptr, ws, false, l.in_act >= 0));
+                                          nullptr, ws, wgrad_fine(l), l.in_act >= 0));
     } else {
         // Wide layers (Cout > 80) reduce their slabs at once through the shared scratch, on the main stream.  When this unit's BN
         // backward ran early on the side stream (a block's shortcut), dy is written THERE: the main stream waits for it first.
@@ -1285,7 +1290,7 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
                 if (!conv_wgrad_deferrable(l.k, l.cin, l.cout)) continue;
                 if ((which == 0 && li == 0) || (which == 1 && li != 0)) continue;
                 if (rm.n == kMultiMax) { TCR_TRY(launch_wgrad_reduce_multi(rm, st)); rm.n = 0; }
-                rm.e[rm.n++] = conv_wgrad_entry(l.k, l.cin, l.cout, batch, c.base + c.w.wg[li], grads + l.w_off);
+                rm.e[rm.n++] = conv_wgrad_entry(l.k, l.cin, l.cout, batch, c.base + c.w.wg[li], grads + l.w_off, wgrad_fine(l));
             }
             return rm.n ? launch_wgrad_reduce_multi(rm, st) : TCR_OK;
         };
