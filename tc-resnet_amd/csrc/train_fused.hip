@@ -105,12 +105,9 @@ if (++c4 == C4) { c4 = 0; off = ++j; }                                          
             continue;
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-#pragma unroll
-            for (int msk = 1; msk < 16; msk <<= 1) {
-                s1[reg] += __shfl_xor(s1[reg], msk);
-                s2[reg] += __shfl_xor(s2[reg], msk);
-            }
+        for (int reg = 0; reg < 4; ++reg) {       // (DPP row sums: bitwise the xor-butterfly they replace, without its eight LDS-pipe round trips)
+            s1[reg] = row16_sum(s1[reg]);
+            s2[reg] = row16_sum(s2[reg]);
         }
         if (r == 0) {
 #pragma unroll
@@ -126,11 +123,8 @@ if (++c4 == C4) { c4 = 0; off = ++j; }                                          
     if (own) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-#pragma unroll
-            for (int msk = 1; msk < 16; msk <<= 1) {
-                ps1[reg] += __shfl_xor(ps1[reg], msk);
-                ps2[reg] += __shfl_xor(ps2[reg], msk);
-            }
+            ps1[reg] = row16_sum(ps1[reg]);
+            ps2[reg] = row16_sum(ps2[reg]);
         }
         if (r == 0) {
 #pragma unroll
