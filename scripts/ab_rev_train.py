@@ -29,7 +29,7 @@ def timeit(fn, n=40, warm=10):
     return ts[len(ts) // 2]
 
 
-for name, ch in (("TCResNet8", [16, 24, 32, 48]), ("TCResNet14", [24, 36, 36, 48, 48, 72, 72])):
+for name, ch in (("TCResNet8", [16, 24, 32, 48]), ("TCResNet14", [24, 36, 36, 48, 48, 72, 72])) if os.environ.get("AB_TC", "1") == "1" else ():
     nets, grads = {}, {}
     for k, lib in libs.items():
         net = T.TCResNet(name, ch, 40, fe.n_frames, 12, lib=lib, device=dev)
