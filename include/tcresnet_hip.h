@@ -410,7 +410,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_BWD_MASK = 12,   /* BN backward: 0 a unit's own ReLU mask recomputed from its raw conv output ([fmaf(y, scale, shift) > 0], bitwise the activation's; default), 1 read back from the stored activation, 2: as 0 with the scalar (one element per thread) elementwise BN kernels instead of the 16-byte ones (bitwise the same), 3: also the scalar per-channel reduction kernel (another summation order), 4: the 16-byte reduction kernel also where its grid would be small (tests) */
        TCR_TUNE_FE_GRID = 13,    /* front-end: cap on the number of persistent workgroups (0: two per CU). 256 = one per CU, which leaves half of every CU's LDS and registers to a co-resident network kernel on another stream */
        TCR_TUNE_FUSED_GRID = 14, /* fused eval network: cap on the number of persistent workgroups (0: as many as the LDS allows per CU) */
-       TCR_TUNE_DS_TRAIN = 15,   /* DS-CNN training: 0 normalised activations never materialised where every consumer has the form (172 / 276-channel nets): consumers apply BN + ReLU to the raw conv outputs, batch statistics and backward sums come from conv / data-gradient epilogues (default); 1 the materialising path (statistics reduce -> finalize -> normalise, backward reduce); 2: as 0, but every unit's BN backward by a bn_bwd_apply pass (default 0: conv_1's filter gradient computes dy where it reads it); 3: as 0, the depthwise units' kernels too */
+       TCR_TUNE_DS_TRAIN = 15,   /* DS-CNN training: 0 normalised activations never materialised where every consumer has the form (172 / 276-channel nets): consumers apply BN + ReLU to the raw conv outputs, batch statistics and backward sums come from conv / data-gradient epilogues (default); 1 the materialising path (statistics reduce -> finalize -> normalise, backward reduce); 2: as 0, but every unit's BN backward by a bn_bwd_apply pass (default 0: conv_1's filter gradient computes dy where it reads it); 3: as 0, the depthwise units' kernels too; 4: as 0, and the pointwise units' data-gradient kernel applies the BN backward while staging and writes dy for the filter gradient instead of a bn_bwd_apply pass (measured slower) */
        TCR_TUNE_WGRAD_TILES = 16, /* 9-tap filter gradients (16-byte-load kernel): output-channel tiles per launch (0: default 3; a layer of more tiles is split into launches that share one slab) */
        TCR_TUNE_COUNT = 17 };
 int tcr_tune(int knob, int value);

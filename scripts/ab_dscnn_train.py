@@ -39,7 +39,7 @@ for size in os.environ.get("AB_SIZES", "L,M").split(","):
         ds.forward_train(feat, lab)
     def bwd():
         ds.backward()
-    for knob in (1, 2, 0, 1, 2, 0):
+    for knob in (1, 2, 4, 0, 1, 2, 4, 0):
         lib.tcr_tune(15, knob)
         t_f = timeit(fwd)
         t_b = timeit(bwd)

@@ -1109,6 +1109,11 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         if (!lazy || fly_knob == 2 || ui == nu - 1) return false;
         return units[ui].kind == DS_CONV1 || (fly_knob == 3 && units[ui].kind == DS_DW);
     };
+    // knob 4 -- pointwise units (all but the last, whose activation gradient is the broadcast pooled one): the data-gradient kernel applies
+    // the BN backward while it stages dy and writes dy for the filter gradient (conv1x1_lds_kernel MODE 3), no bn_bwd_apply pass.  Measured
+    // SLOWER (DS-CNN-L step 16.33 vs 16.10 ms, M 7.72 vs 7.64): the filter gradient then starts behind the data gradient instead of
+    // beside it, and the two matrix-pipe kernels overlapping was worth more than the 0.2 ms pass.  Not the default.
+    auto unit_fused_apply = [&](int ui) { return lazy && fly_knob == 4 && units[ui].kind == DS_PW && ui != nu - 1; };
     // buffer plan: stage st (unit nu - st) reads gin[st], materialises into dbuf[st] (-1: on the fly), writes gout[st] (-1: conv_1)
     std::vector<int> gin(nu + 1, -1), dbuf(nu + 1, -1), gout(nu + 1, -1);
     {
@@ -1165,7 +1170,13 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
         const float* self_scale = base + w.ss + u.ss_off;
         const float* dz = nullptr;              // the unit's dy, materialised ...
         BnBwdFly bf;                            // ... or computed by its readers
-        if (fly) {
+        const bool fused_apply = unit_fused_apply(ui);
+        if (fused_apply) {                      // (dy is written by the data-gradient kernel below)
+            TCR_TRY(claim(dbuf[st]));
+            dz = base + w.gbuf[dbuf[st]];
+            bf.raw = raw; bf.mean = base + w.mean[ui]; bf.k1 = f.k1; bf.k2 = f.k2; bf.k3 = f.k3;
+            bf.self_scale = self_scale; bf.self_shift = self_scale + cp;
+        } else if (fly) {
             bf.da = da; bf.raw = raw; bf.mean = base + w.mean[ui]; bf.k1 = f.k1; bf.k2 = f.k2; bf.k3 = f.k3;
             bf.self_scale = self_scale; bf.self_shift = self_scale + cp;
         } else {
@@ -1180,10 +1191,14 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
             TCR_TRY(launch_bn_bwd_apply(ap, s));
             dz = dzw;
         }
-        if (side != s && (hipEventRecord(net->ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, net->ev_fork, 0) != hipSuccess)) {
-            set_error("tcr_dscnn_backward: stream fork failed");
-            return TCR_ERR_HIP;
-        }
+        auto fork = [&]() -> int {
+            if (side != s && (hipEventRecord(net->ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, net->ev_fork, 0) != hipSuccess)) {
+                set_error("tcr_dscnn_backward: stream fork failed");
+                return TCR_ERR_HIP;
+            }
+            return TCR_OK;
+        };
+        if (!fused_apply) TCR_TRY(fork());
         float* ga = nullptr;
         if (ui > 0) { TCR_TRY(claim(gout[st])); ga = base + w.gbuf[gout[st]]; }
         const float* xin = ui > 0 ? base + (lazy ? w.raw[ui - 1] : w.act[ui - 1]) : nullptr;
@@ -1195,13 +1210,18 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
             es.self_scale = x_scale; es.self_shift = x_shift;
         }
         if (u.kind == DS_PW) {
-            TCR_TRY(launch_conv_wgrad(1, 1, 0, xin, dz, grads + u.w_off, base + w.scratch, batch, l.cin, l.cout, pp, u.P, pp, side, x_scale, x_shift));
+            if (!fused_apply) TCR_TRY(launch_conv_wgrad(1, 1, 0, xin, dz, grads + u.w_off, base + w.scratch, batch, l.cin, l.cout, pp, u.P, pp, side, x_scale, x_shift));
             TCR_TRY(launch_transpose_weights(params + u.w_off, base + w.wt, 1, l.cin, l.cout, s));
             Conv1x1Args c1;
-            c1.x = dz; c1.w = base + w.wt; c1.y = ga; c1.scale = nullptr; c1.shift = nullptr;
+            c1.x = fused_apply ? da : dz; c1.w = base + w.wt; c1.y = ga; c1.scale = nullptr; c1.shift = nullptr;
             c1.npos = batch * u.P; c1.cin = l.cout; c1.cout = l.cin; c1.tpi = pp; c1.tout = u.P; c1.tpo = pp; c1.stride = 1; c1.relu = 0;
             c1.sums = es;
+            if (fused_apply) { c1.fly = bf; c1.dy_out = const_cast<float*>(dz); }
             TCR_TRY(launch_conv1x1(c1, MF_RAW, s));
+            if (fused_apply) {              // the filter gradient reads the dy the data gradient has just written
+                TCR_TRY(fork());
+                TCR_TRY(launch_conv_wgrad(1, 1, 0, xin, dz, grads + u.w_off, base + w.scratch, batch, l.cin, l.cout, pp, u.P, pp, side, x_scale, x_shift));
+            }
         } else if (u.kind == DS_DW) {
             const int ppi = tcr_padded_len(l.h_in * l.w_in);
             DsDwWgradArgs g;

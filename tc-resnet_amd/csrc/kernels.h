@@ -67,6 +67,21 @@ struct EpiSums {
     const float* self_shift = nullptr;
 };
 
+// BN backward of the unit whose conv the kernel differentiates, applied WHERE dy IS READ instead of by a bn_bwd_apply pass that
+// writes it (units whose dy has few readers: depthwise, conv_1): with da = the gradient wrt the unit's activation, raw = its raw
+// conv output,   dy = k1 * (dz - k2 - (raw - mean) * k3),   dz = da * [fmaf(raw, self_scale, self_shift) > 0]
+// (bn_bwd_apply_kernel's expression).  da == nullptr: off, the kernel's dz argument is dy itself.
+struct BnBwdFly {
+    const float* da = nullptr;
+    const float* raw = nullptr;
+    const float* mean = nullptr;
+    const float* k1 = nullptr;
+    const float* k2 = nullptr;
+    const float* k3 = nullptr;
+    const float* self_scale = nullptr;
+    const float* self_shift = nullptr;
+};
+
 struct Conv1x1Args {
     const float* x;         // [B][Cin][Tpi]
     const float* w;         // [Cin][Cout]
@@ -79,6 +94,11 @@ struct Conv1x1Args {
     const float* in_scale = nullptr;
     const float* in_shift = nullptr;
     EpiSums sums;
+    // LDS-tiled kernel, data-gradient form with sums: x is the gradient wrt the pointwise unit's ACTIVATION and fly.raw that unit's raw
+    // output (fly.da is not used); the kernel stages dy = BN backward of it (BnBwdFly's expression) and writes it to dy_out
+    // (interior + zeroed halos) for the filter gradient -- no bn_bwd_apply pass in the backward's main chain
+    BnBwdFly fly;
+    float* dy_out = nullptr;
 };
 
 int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s);
@@ -386,21 +406,6 @@ int launch_sum_vector(const float* in, int n, float* out, hipStream_t s);
 int launch_bias_grad(const float* dlogits, int batch, int nc, float* db, hipStream_t s);
 
 // ---- dscnn_bwd.hip : backward kernels of the depthwise-separable baseline ----------------------
-// BN backward of the unit whose conv the kernel differentiates, applied WHERE dy IS READ instead of by a bn_bwd_apply pass that
-// writes it (units whose dy has few readers: depthwise, conv_1): with da = the gradient wrt the unit's activation, raw = its raw
-// conv output,   dy = k1 * (dz - k2 - (raw - mean) * k3),   dz = da * [fmaf(raw, self_scale, self_shift) > 0]
-// (bn_bwd_apply_kernel's expression).  da == nullptr: off, the kernel's dz argument is dy itself.
-struct BnBwdFly {
-    const float* da = nullptr;
-    const float* raw = nullptr;
-    const float* mean = nullptr;
-    const float* k1 = nullptr;
-    const float* k2 = nullptr;
-    const float* k3 = nullptr;
-    const float* self_scale = nullptr;
-    const float* self_shift = nullptr;
-};
-
 struct DsDwBwdArgs {
     const float* dz;        // [B][C][Ppo] gradient wrt the depthwise conv output
     const float* w;         // [3][3][C][1]

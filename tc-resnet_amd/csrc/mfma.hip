@@ -124,7 +124,10 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
 // MODE (DS-CNN training, so that no BN pass streams the tensors again): 1 = x is the producing unit's RAW conv output, staged as
 // relu(x * in_scale[ci] + in_shift[ci]) (bitwise bn_apply's expression), and the epilogue leaves the per-channel sums of y, y^2
 // (EpiSums, forward form); 2 = data gradient whose epilogue leaves the backward sums of the unit it writes the gradient of
-// (EpiSums, backward form: that unit's raw output is read at the tile's own addresses).  Sums: the 16 positions of a tile column
+// (EpiSums, backward form: that unit's raw output is read at the tile's own addresses); 3 = as 2, and x is the gradient wrt the
+// unit's ACTIVATION: its BN backward is applied while x is staged (BnBwdFly; rows are wave-uniform: the six coefficients by scalar
+// loads) and the staged dy is also written to dy_out for the filter gradient -- every element is staged exactly once across the
+// grid --, so the bn_bwd_apply pass (3 tensor passes, 0.2 ms per layer in the backward's main chain) disappears.  Sums: the 16 positions of a tile column
 // block live in the 16 lanes of a DPP row -> row16_sum; the two position halves (wn) meet in LDS; one partial row per workgroup.
 template <int MT, int NT, int EPI, int MODE>
 __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
@@ -151,11 +154,14 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
     const bool xuse = tid < RS * XN;
     const int xpos = tid % XN, xrow0 = XN == 64 ? wave : min(tid / XN, RS - 1);   // rows xrow0 + RS * j  (XN = 64: wave-uniform -> scalar loads of in_scale / in_shift)
     const float* xsrc;
+    bool xvalid, xfirst, xlast;
     {
         const int p = min(pos0 + xpos, a.npos - 1);
         const int n = p / a.tout, t = p - n * a.tout;
         xsrc = a.x + (size_t)n * a.cin * a.tpi + kHalo + t * a.stride;
+        xvalid = pos0 + xpos < a.npos; xfirst = t == 0; xlast = t == a.tout - 1;
     }
+    const ptrdiff_t xrel = xsrc - a.x;                          // (MODE 3: the same element of the unit's raw output / of dy_out)
     int wrow[WPT], wcol[WPT];
     bool wuse[WPT], wval[WPT];
 #pragma unroll
@@ -167,6 +173,8 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
         wval[j] = wcol[j] < a.cout;                         // (Cout % 4 == 0: launcher)
     }
     float xr[XPT], xsc[XPT], xsf[XPT];
+    float yr[XPT], fk1[XPT], fk2[XPT], fk3[XPT], fmu[XPT];     // MODE 3 (xsc / xsf hold the unit's own scale / shift there)
+    int xrw[XPT];
     f32x4 wr[WPT];
     auto load_chunk = [&](int c0) {
 #pragma unroll
@@ -174,6 +182,12 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
             const int row = min(c0 + xrow0 + RS * j, a.cin - 1);
             xr[j] = xsrc[(size_t)row * a.tpi];
             if (MODE == 1) { xsc[j] = a.in_scale[row]; xsf[j] = a.in_shift[row]; }
+            if (MODE == 3) {
+                yr[j] = a.fly.raw[xrel + (ptrdiff_t)row * a.tpi];
+                xsc[j] = a.fly.self_scale[row]; xsf[j] = a.fly.self_shift[row];
+                fk1[j] = a.fly.k1[row]; fk2[j] = a.fly.k2[row]; fk3[j] = a.fly.k3[row]; fmu[j] = a.fly.mean[row];
+                xrw[j] = row;
+            }
         }
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
@@ -185,7 +199,21 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
     auto store_chunk = [&](int buf) {
         if (xuse) {
 #pragma unroll
-            for (int j = 0; j < XPT; ++j) s_x[buf][(xrow0 + RS * j) * XLD + xpos] = MODE == 1 ? fmaxf(fmaf(xr[j], xsc[j], xsf[j]), 0.f) : xr[j];
+            for (int j = 0; j < XPT; ++j) {
+                float v = MODE == 1 ? fmaxf(fmaf(xr[j], xsc[j], xsf[j]), 0.f) : xr[j];
+                if (MODE == 3) {        // dy = k1 (dz - k2 - (raw - mean) k3), dz = dA [fmaf(raw, scale, shift) > 0]  (bn_bwd_apply's expression)
+                    float g = xr[j];
+                    if (!(fmaf(yr[j], xsc[j], xsf[j]) > 0.f)) g = 0.f;
+                    v = fk1[j] * (g - fk2[j] - (yr[j] - fmu[j]) * fk3[j]);
+                    if (xvalid) {
+                        float* o = a.dy_out + xrel + (ptrdiff_t)xrw[j] * a.tpi;
+                        o[0] = v;
+                        if (xfirst) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
+                        if (xlast) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+                    }
+                }
+                s_x[buf][(xrow0 + RS * j) * XLD + xpos] = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < WPT; ++j)
@@ -287,7 +315,7 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
             const int cc = min(co, a.cout - 1);
             float sc1 = 1.0f, sf1 = 0.f, mu = 0.f, is = 0.f, ssc = 0.f, ssh = 0.f;
             if (EPI == MF_AFFINE) { sc1 = a.scale ? a.scale[cc] : 1.0f; sf1 = a.shift[cc]; }
-            if (MODE == 2) { mu = a.sums.mean[cc]; is = a.sums.invstd[cc]; ssc = a.sums.self_scale[cc]; ssh = a.sums.self_shift[cc]; }
+            if (MODE >= 2) { mu = a.sums.mean[cc]; is = a.sums.invstd[cc]; ssc = a.sums.self_scale[cc]; ssh = a.sums.self_shift[cc]; }
             float q1 = 0.f, q2 = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -339,7 +367,7 @@ int conv1x1_sum_rows(int npos) { return ceil_div(npos, 64); }
 int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
     const int tiles = ceil_div(a.cout, 16);
     const int knob = tune_get(TCR_TUNE_CONV_B);
-    const bool extras = a.in_scale || a.sums.partial;
+    const bool extras = a.in_scale || a.sums.partial || a.dy_out;
     if (conv1x1_lds_covers(a.cin, a.cout)) {
         const int mt = tiles > 12 ? 9 : 6;
         // 2 column tiles per wave = 64 positions per workgroup (3 tiles: 236 VGPRs, 2 waves per SIMD, slower; 4: slower still)
@@ -348,9 +376,12 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
             // training forms: (in-affine + forward sums) with the bias epilogue, or (backward sums) on the raw data gradient
             const bool fwd = epi == MF_AFFINE && a.in_scale && a.in_shift && a.sums.partial && !a.sums.raw;
             const bool bwd = epi == MF_RAW && !a.in_scale && a.sums.partial && a.sums.raw && a.sums.mean && a.sums.invstd && a.sums.self_scale && a.sums.self_shift && a.stride == 1;
+            const bool bfly = bwd && a.dy_out && a.fly.raw && a.fly.mean && a.fly.k1 && a.fly.k2 && a.fly.k3 && a.fly.self_scale && a.fly.self_shift && a.tpi == a.tpo;
             if (!fwd && !bwd) { set_error("conv1x1: unsupported combination of in-affine / epilogue sums"); return TCR_ERR_ARG; }
+            if (a.dy_out && !bfly) { set_error("conv1x1: on-the-fly BN backward needs the data-gradient form with sums"); return TCR_ERR_ARG; }
 #define TCR_LT(MT_)                                                                                                     \
     if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE, 1>), lgrid, dim3(256), 0, s, a);                \
+    else if (bfly) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 3>), lgrid, dim3(256), 0, s, a);             \
     else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 2>), lgrid, dim3(256), 0, s, a)
             if (mt == 9) { TCR_LT(9); } else { TCR_LT(6); }
 #undef TCR_LT

@@ -450,7 +450,7 @@ def check_dscnn_lazy_equals_materialised(lib, size, batch, seed=6):
     labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
     outs = []
     try:
-        for knob in (0, 1):
+        for knob in (0, 1, 4):          # 4: the pointwise units' BN backward inside their data-gradient kernel
             lib.tcr_tune(15, knob)
             ds = T.DSCNN(size, t, f, 12, lib=lib, device=dev)
             ds.init_xavier(2)
@@ -459,7 +459,8 @@ def check_dscnn_lazy_equals_materialised(lib, size, batch, seed=6):
             outs.append((lg.clone(), float(loss), ds.stats.clone(), ds.backward().clone(), acts))
     finally:
         lib.tcr_tune(15, 0)
-    a, b = outs
+    a, b, c4 = outs
+    assert torch.equal(a[0], c4[0]) and float((a[3] - c4[3]).abs().max()) < 2e-5 * max(1.0, float(a[3].abs().max()))     # (same forward; dy rounded once either way)
     assert float((a[0] - b[0]).abs().max()) < 2e-5 and abs(a[1] - b[1]) < 1e-4 * max(1.0, abs(b[1]))
     assert float((a[2] - b[2]).abs().max()) < 2e-6 * max(1.0, float(b[2].abs().max()))
     assert float((a[3] - b[3]).abs().max()) < 5e-3 * max(1.0, float(b[3].abs().max()))
