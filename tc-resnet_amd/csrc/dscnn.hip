@@ -1097,7 +1097,7 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
     // Filter gradients run on a second stream, overlapped with the BN-backward / data-gradient chain of the units below.
     // Gradient buffers come from a pool of four, handed out round-robin: a unit's materialised dy (`D`), the activation gradient
     // its data-gradient kernel writes for the unit below (`gout`).  The side stream reads D -- or, for units whose BN backward is
-    // applied on the fly (BnBwdFly: depthwise and conv_1 in lazy mode), the incoming activation gradient `gin` --, so the main
+    // applied on the fly (BnBwdFly: conv_1 in lazy mode; the depthwise units behind knob 3), the incoming activation gradient `gin` --, so the main
     // stream waits for the buffer's last side-stream reader (ev_done) before it writes a buffer again.  The hand-out order is a
     // function of the unit list only, so a staged run (one host call per stage) recomputes it.
     if (stage_begin == 0) for (bool& r : net->ev_rec) r = false;
