@@ -338,6 +338,42 @@ __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a
     }
 }
 
+// two units in one launch (blockIdx.y): a block's shortcut conv and conv_a get their statistics from the same phase kernel
+__global__ __launch_bounds__(512) void bn_finalize2_kernel(const BnFinalizeArgs a, const BnFinalizeArgs b) {
+    __shared__ double s_slices[512];
+    __shared__ double s_tot[2 * kBnCB];
+    const BnFinalizeArgs& u = blockIdx.y == 0 ? a : b;
+    const int c0 = blockIdx.x * u.cbw, cb = min(u.cbw, u.c - c0);
+    if (cb <= 0) return;
+    reduce_partials(u.partial, u.nchunk, u.sums, u.c, c0, cb, s_slices, s_tot);
+    for (int i = threadIdx.x; i < cb; i += blockDim.x) {
+        const int c = c0 + i;
+        const double s1 = s_tot[i], s2 = s_tot[cb + i];
+        const double m = s1 / u.count;
+        double var = s2 / u.count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)m, varf = (float)var;
+        const float inv = 1.0f / sqrtf(varf + u.eps);
+        const float sc = u.gamma ? u.gamma[c] * inv : inv;
+        u.scale[c] = sc;
+        u.shift[c] = fmaf(-meanf, sc, u.beta[c]);
+        u.mean[c] = meanf;
+        u.invstd[c] = inv;
+        const float unbiased = (float)(var * (u.count / (u.count > 1.0 ? u.count - 1.0 : 1.0)));
+        const float om = 1.0f - u.decay;
+        u.moving_mean[c] -= om * (u.moving_mean[c] - meanf);
+        u.moving_var[c] -= om * (u.moving_var[c] - unbiased);
+    }
+}
+
+int launch_bn_finalize2(const BnFinalizeArgs& a0, const BnFinalizeArgs& b0, hipStream_t s) {
+    BnFinalizeArgs a = a0, b = b0;
+    a.cbw = bn_finalize_cb(a.nchunk); b.cbw = bn_finalize_cb(b.nchunk);
+    const int gx = max(ceil_div(a.c, a.cbw), ceil_div(b.c, b.cbw));
+    hipLaunchKernelGGL(bn_finalize2_kernel, dim3(gx, 2), dim3(bn_finalize_threads(a.nchunk)), 0, s, a, b);
+    return check_launch("bn_finalize2_kernel");
+}
+
 int launch_bn_finalize(const BnFinalizeArgs& a0, hipStream_t s) {
     BnFinalizeArgs a = a0;
     a.cbw = bn_finalize_cb(a.nchunk);

@@ -370,6 +370,7 @@ int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t 
 int launch_chan_sums(const float* partial, int nchunk, int c, double* sums, hipStream_t s);
 int bn_finalize_cb(int nchunk);         // channels per finalize workgroup for nchunk partial rows
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
+int launch_bn_finalize2(const BnFinalizeArgs& a, const BnFinalizeArgs& b, hipStream_t s);       // two units, one launch (bitwise two launch_bn_finalize calls)
 int launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s);

@@ -641,9 +641,7 @@ static int fwd_unit_pre(const TrainCtx& c, int li, hipStream_t rs, float* partia
 }
 
 // statistics -> scale/shift, moving-stat update, normalise (+ReLU / +residual)
-static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* res, hipStream_t rs, float* partial, int rows = -1) {
-    // rows >= 0: the partial rows come from a group-resident phase (train_fused.hip), which also normalises on the fly in its
-    // consumer: only the finalize runs here
+static BnFinalizeArgs fwd_finalize_args(const TrainCtx& c, int li, float* stats, float* partial, int rows) {
     const ConvLayer& l = c.net->layers[li];
     float* ss = c.base + c.w.ss + l.ss_off;
     BnFinalizeArgs f;
@@ -656,6 +654,15 @@ static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* r
     f.mean = c.base + c.w.mean[li]; f.invstd = c.base + c.w.invstd[li];
     f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
     f.decay = c.net->cfg.bn_decay; f.eps = c.net->cfg.bn_eps;
+    return f;
+}
+
+static int fwd_unit_post(const TrainCtx& c, int li, float* stats, const float* res, hipStream_t rs, float* partial, int rows = -1) {
+    // rows >= 0: the partial rows come from a group-resident phase (train_fused.hip), which also normalises on the fly in its
+    // consumer: only the finalize runs here
+    const ConvLayer& l = c.net->layers[li];
+    float* ss = c.base + c.w.ss + l.ss_off;
+    const BnFinalizeArgs f = fwd_finalize_args(c, li, stats, partial, rows);
     TCR_TRY(launch_bn_finalize(f, rs));
     if (rows >= 0) return TCR_OK;
     BnApplyArgs a;
@@ -826,7 +833,20 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
         if (st > 0) {
             const int li = net->units[st - 1];
             const int rows = train_phase_rows(phase_of_unit(c, li, &first));
-            TCR_TRY(fwd_unit_post(c, li, stats, nullptr, c.s, partial_of(li), rows));
+            // a block's shortcut conv and conv_a come out of ONE phase kernel and nothing runs between their finalizes: one launch for
+            // the pair (un-staged runs; bitwise the two launches)
+            const bool pair_next = !c.sync_bn && is_down(li) && st + 1 < stage_end;                               // this iteration posts the shortcut unit
+            const bool pair_prev = !c.sync_bn && st >= 2 && is_down(net->units[st - 2]) && st - 1 >= stage_begin;    // ... and this one its conv_a
+            if (pair_next) {
+                // (finalized together with conv_a in the next iteration)
+            } else if (pair_prev) {
+                const int ld = net->units[st - 2];
+                bool f2 = true;
+                const int rows_d = train_phase_rows(phase_of_unit(c, ld, &f2));
+                TCR_TRY(launch_bn_finalize2(fwd_finalize_args(c, ld, stats, partial_of(ld), rows_d), fwd_finalize_args(c, li, stats, partial_of(li), rows), c.s));
+            } else {
+                TCR_TRY(fwd_unit_post(c, li, stats, nullptr, c.s, partial_of(li), rows));
+            }
         }
         if (st < nu) {
             const int li = net->units[st];
