@@ -62,7 +62,8 @@ static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 // filter gradients that get the finer split-K grid (mfma.hip: wgrad_chunks_for)
 // (measured: TCResNet8 step -1.5 %; with TCResNet14-1.5's 24 -> 36 channel layers included that step was +1.3 %: their larger slabs cost
 //  more in the reduction than the extra waves win)
-static bool wgrad_fine(const ConvLayer& l) { return l.k == 9 && ((l.cin + 15) / 16) * ((l.cout + 15) / 16) <= 4 && l.tout >= 20; }
+// (the first conv too: TCResNet8's 40 -> 16 first conv -1.3 % per step; TCResNet14-1.5's 40 -> 24 one, a six-tile slab: +0.5 %, so the same bound)
+static bool wgrad_fine(const ConvLayer& l) { return (l.k == 9 || l.in_act < 0) && ((l.cin + 15) / 16) * ((l.cout + 15) / 16) <= 4 && l.tout >= 20; }
 
 // ---- workspace carving ------------------------------------------------------------------------
 struct Workspace {
