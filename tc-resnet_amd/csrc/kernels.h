@@ -154,6 +154,16 @@ struct DgradWeightsMulti {
     DgradWeightsEntry e[kMultiMax];
 };
 int launch_dgrad_weights_multi(const DgradWeightsMulti& m, hipStream_t s);
+struct BwdPrologueArgs {        // head backward (launch_head_bwd's arguments) + the gradient arena to clear
+    const float* dlogits;
+    const float* wfc;
+    const float* dscale;
+    float* dpool;
+    int batch, c, nc;
+    float* zero;
+    int64_t zero_n;
+};
+int launch_bwd_prologue(const BwdPrologueArgs& h, const DgradWeightsMulti& m, hipStream_t s);      // head backward + arena zero fill + every layer's data-gradient weights, one launch
 
 // ---- fused.hip : whole-network eval forward, activations resident in LDS ---------------------
 constexpr int kFusedMaxLayers = 32;

@@ -849,6 +849,37 @@ __global__ __launch_bounds__(256) void dgrad_weights_multi_kernel(const DgradWei
     dgrad_weights_body(e.w, e.wt, e.k, e.cin, e.cout, e.stride, e.pad_lo, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
+// The backward's first launch (TC-ResNet): blockIdx.y == 0 -- the head's backward (dpool[b][c] = (sum_o dlogits[b][o] Wfc[c][o]) dscale[b][c]:
+// head_bwd_kernel's arithmetic) and the zero fill of the gradient arena; blockIdx.y = 1 + layer -- that layer's re-arranged data-gradient
+// weights.  As three launches (a hipMemsetAsync, head_bwd_kernel, dgrad_weights_multi_kernel) they were ~18 us of kernels plus two ~7 us
+// dispatch gaps between the forward's last kernel and the backward's first reduction.
+__global__ __launch_bounds__(256) void bwd_prologue_kernel(const BwdPrologueArgs h, const DgradWeightsMulti m) {
+    if (blockIdx.y > 0) {
+        const DgradWeightsEntry e = m.e[blockIdx.y - 1];
+        dgrad_weights_body(e.w, e.wt, e.k, e.cin, e.cout, e.stride, e.pad_lo, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+        return;
+    }
+    const int64_t total = (int64_t)h.batch * h.c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % h.c);
+        const int64_t b = i / h.c;
+        float s = 0.f;
+        for (int o = 0; o < h.nc; ++o) s = fmaf(h.dlogits[b * h.nc + o], h.wfc[(size_t)ch * h.nc + o], s);
+        h.dpool[i] = s * h.dscale[i];
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < h.zero_n; i += (int64_t)gridDim.x * 256) h.zero[i] = 0.f;
+}
+
+int launch_bwd_prologue(const BwdPrologueArgs& h, const DgradWeightsMulti& m, hipStream_t s) {
+    int most = 0;
+    for (int i = 0; i < m.n; ++i) most = max(most, m.e[i].k * m.e[i].cin * m.e[i].cout);
+    int64_t blocks = ceil_div64((int64_t)h.batch * h.c, 256);
+    if (blocks < ceil_div(most, 256)) blocks = ceil_div(most, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bwd_prologue_kernel, dim3((unsigned)blocks, 1 + m.n), dim3(256), 0, s, h, m);
+    return check_launch("bwd_prologue_kernel");
+}
+
 int launch_dgrad_weights_multi(const DgradWeightsMulti& m, hipStream_t s) {
     if (m.n <= 0) return TCR_OK;
     int most = 0;

@@ -1328,12 +1328,20 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     if (plan) { stage_begin = plan->first ? 0 : 1; stage_end = stage_begin + 1; }
     for (int st = stage_begin; st < stage_end; ++st) {
         if (st == 0) {
-            // head: zero the arena (padding + fc2, which gets no loss gradient), fc wgrad, pooled gradient
-            if (hipMemsetAsync(grads, 0, (size_t)net->param_floats * sizeof(float), c.s) != hipSuccess) {
-                set_error("tcr_net_backward: hipMemsetAsync failed");
-                return TCR_ERR_HIP;
-            }
+            // ONE launch: the head's backward (pooled gradient), the arena's zero fill (padding + fc2, which gets no loss gradient) and the
+            // re-arranged (phase-major, transposed) weights of every data-gradient conv
             const int nc = net->cfg.num_classes;
+            DgradWeightsMulti dm;
+            dm.n = 0;
+            for (int li : order) {
+                const ConvLayer& l = net->layers[li];
+                if (l.in_act < 0 || !conv_dgrad_mfma_covers(l.k, l.stride, l.cout) || dm.n >= kMultiMax) continue;
+                dm.e[dm.n++] = {params + l.w_off, c.base + c.w.wtl[li], l.k, l.cin, l.cout, l.stride, l.pad_lo};
+            }
+            BwdPrologueArgs hp;
+            hp.dlogits = c.base + c.w.dlogits; hp.wfc = params + net->layers[net->fc].w_off; hp.dscale = c.base + c.w.dscale;
+            hp.dpool = c.base + c.w.dpool; hp.batch = batch; hp.c = net->feat_c; hp.nc = nc; hp.zero = grads; hp.zero_n = net->param_floats;
+            TCR_TRY(launch_bwd_prologue(hp, dm, c.s));
             // the classifier's own filter gradient feeds nothing below: on a stream of its own (behind the arena's zero fill)
             hipStream_t fs = c.side != c.s ? net->side2 : c.s;
             if (fs != c.s && (hipEventRecord(net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(fs, net->ev_fork, 0) != hipSuccess)) {
@@ -1342,17 +1350,6 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
             }
             TCR_TRY(launch_fc_wgrad(c.base + c.w.dropped, c.base + c.w.dlogits, c.base + c.w.fc_partial,
                                     grads + net->layers[net->fc].w_off, batch, net->feat_c, nc, fs));
-            TCR_TRY(launch_head_bwd(c.base + c.w.dlogits, params + net->layers[net->fc].w_off, c.base + c.w.dscale,
-                                    c.base + c.w.dpool, batch, net->feat_c, nc, c.s));
-            // re-arranged (phase-major, transposed) weights of every data-gradient conv, one launch
-            DgradWeightsMulti dm;
-            dm.n = 0;
-            for (int li : order) {
-                const ConvLayer& l = net->layers[li];
-                if (l.in_act < 0 || !conv_dgrad_mfma_covers(l.k, l.stride, l.cout) || dm.n >= kMultiMax) continue;
-                dm.e[dm.n++] = {params + l.w_off, c.base + c.w.wtl[li], l.k, l.cin, l.cout, l.stride, l.pad_lo};
-            }
-            TCR_TRY(launch_dgrad_weights_multi(dm, c.s));
         }
         if (plan) {     // one dependency level: the per-layer kernels on the caller's stream, shortcut units on the second scratch set
             TCR_REQUIRE(c.sync_bn, "tcr_net_backward_level: levels exist for the cross-replica hand-off");
