@@ -490,3 +490,29 @@ def test_forward_waveform_single_call_is_the_three_call_path(hip_lib):
     got3 = net.forward_waveform(fe, wav)
     ref3 = net.forward_infer(fe(wav))
     assert torch.equal(got3[0], ref3[0]) and not torch.equal(got3[0], got[0])
+
+
+@pytest.mark.parametrize("family", ["TCResNet8", "TCResNet14", "DSCNN-L"])
+def test_multi_stream_backward_repeats_bitwise(hip_lib, family):
+    """The backward runs on up to three internal streams (filter gradients, the shortcut units' chains, the classifier's gradient) with
+    rotating gradient buffers; a race would show up as a run-to-run difference: eight repetitions at batch 4096 are bitwise equal."""
+    B = 4096
+    rng = np.random.RandomState(11)
+    labels = torch.from_numpy(R.synth_labels(B).astype(np.float32)).cuda()
+    if family == "DSCNN-L":
+        feat = T.features_to_planar(torch.from_numpy(rng.uniform(-2, 2, (B, 49, 10)).astype(np.float32)).cuda(), lib=hip_lib)
+        net = T.DSCNN("L", 49, 10, 12, device="cuda")
+    else:
+        feat = T.features_to_planar(torch.from_numpy(rng.uniform(-2, 2, (B, 49, 40)).astype(np.float32)).cuda(), lib=hip_lib)
+        net = T.TCResNet(family, R.tcresnet_channels(family, 1.0 if family == "TCResNet8" else 1.5), 40, 49, 12, device="cuda")
+    net.init_xavier(3)
+    stats0 = net.stats.clone()
+    ref = None
+    for _ in range(8):
+        net.stats.copy_(stats0)
+        lg, _, _ = net.forward_train(feat, labels, keep_prob=0.5, seed=5)
+        g = net.backward().clone()
+        if ref is None:
+            ref = (lg.clone(), g)
+        else:
+            assert torch.equal(lg, ref[0]) and torch.equal(g, ref[1])
