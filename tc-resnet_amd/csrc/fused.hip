@@ -556,11 +556,7 @@ __device__ __forceinline__ void fused_head(const FusedArgs& a, float* lds, const
 
 // TCResNet8-1.0 on 40 coefficients with every layer shape fixed at compile time (T0 = 49 or 98 frames): the flagship
 // configurations of BASELINE.json.  Same walk, same LDS plan (FusedArgs), bitwise the generic kernel's results.
-#if defined(TCR_HOST_EMULATION)
-#define TCR_WAVES_PER_SIMD_4
-#else
-#define TCR_WAVES_PER_SIMD_4 __attribute__((amdgpu_waves_per_eu(4, 4)))     // two 8-wave workgroups per CU: <= 128 VGPRs
-#endif
+#define TCR_WAVES_PER_SIMD_4 TCR_WAVES_PER_SIMD(4)     // two 8-wave workgroups per CU: <= 128 VGPRs
 // WD < 0: the round-2 layer (A/B arm, TCR_TUNE_NET_FUSED = 4).  HALO: some consumer convolves this layer's rows (K > 1) and so reads
 // their zero halo; the shortcut convs' outputs (only ever a residual term) and the last block output (only pooled) skip the zero pass.
 template <int NW, int K, int S, int CIN, int COUT, int TIN, int WD, bool HAS_RES, bool HALO = true>
@@ -910,14 +906,12 @@ int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, 
     TCR_FK(4, 4) TCR_FK(4, 8) TCR_FK(4, 16) TCR_FK(8, 4) TCR_FK(8, 8) TCR_FK(8, 16) TCR_FK(16, 4) TCR_FK(16, 8) TCR_FK(16, 16)
 #undef TCR_FK
     if (!kern) { set_error("fused kernel: no instantiation for %d waves / ring %d", waves, ring); return TCR_ERR_ARG; }
-#if !defined(TCR_HOST_EMULATION)
     if (lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
             (void)hipGetLastError();
             return 1;       // caller falls back to the per-layer kernels
         }
     }
-#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds_bytes, s, a);
     return check_launch("net_fused_kernel");
 }

@@ -1342,7 +1342,6 @@ static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float
     a.cin_pad = ceil_div(cin, 16) * 16; a.cout_pad = ceil_div(cout, 16) * 16; a.p = tout; a.pp = tpi;
     a.utt_per_block = ceil_div(batch, pw_wgrad_chunks(batch));
     const size_t lds = ((size_t)2 * 96 * tpi + 16) * sizeof(float);      // (+ pad: the one-step operand lookahead)
-#if !defined(TCR_HOST_EMULATION)
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -1351,7 +1350,6 @@ static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float
         }
         configured = lds;
     }
-#endif
     a.nchunk = ceil_div(batch, a.utt_per_block); a.nby = ceil_div(cin, 96); a.nbz = ceil_div(cout, 96);
     const dim3 grid(ceil_div(a.nchunk, 8) * 8 * a.nby * a.nbz);
     hipLaunchKernelGGL(pw_wgrad_lds_kernel, grid, dim3(256), lds, s, a);

@@ -11,6 +11,12 @@
 
 namespace tcr {
 
+// Pins a kernel to n waves per SIMD (the register allocator's budget: 512 / n VGPRs + AGPRs).  An attribute of the gfx950 compiler;
+// a host build of the kernel sources (tests/emu) pre-defines the macro as empty.
+#ifndef TCR_WAVES_PER_SIMD
+#define TCR_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+
 constexpr int kHalo = TCR_HALO;
 constexpr int kWave = 64;
 

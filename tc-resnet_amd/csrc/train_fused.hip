@@ -261,14 +261,12 @@ int launch_train_phase(TrainPhaseArgs a, int* rows_out, hipStream_t s) {
     if (!configure_phase(a, &lds, &grid)) return 1;
     if (rows_out) *rows_out = grid;
     void (*kern)(const TrainPhaseArgs) = a.nw == 4 ? train_phase_kernel<4, 4> : train_phase_kernel<8, 4>;
-#if !defined(TCR_HOST_EMULATION)
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
         }
     }
-#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(a.nw * 64), lds, s, a);
     return check_launch("train_phase_kernel");
 }

@@ -304,7 +304,6 @@ int launch_train_bwd_phase(TrainBwdPhaseArgs a, int* rows_out, hipStream_t s) {
     if (!configure_bwd_phase(a, &lds, &grid)) return 1;
     if (rows_out) *rows_out = grid;
     void (*kern)(const TrainBwdPhaseArgs) = a.nw == 4 ? train_bwd_phase_kernel<4, 4> : train_bwd_phase_kernel<8, 4>;
-#if !defined(TCR_HOST_EMULATION)
     static size_t configured[2] = {0, 0};
     size_t& cfg = configured[a.nw == 4 ? 0 : 1];
     if (lds > 64 * 1024 && lds > cfg) {
@@ -314,7 +313,6 @@ int launch_train_bwd_phase(TrainBwdPhaseArgs a, int* rows_out, hipStream_t s) {
         }
         cfg = lds;
     }
-#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(a.nw * 64), lds, s, a);
     return check_launch("train_bwd_phase_kernel");
 }

@@ -31,6 +31,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
+#define TCR_WAVES_PER_SIMD(n)           // (a register-budget attribute of the gfx950 compiler: nothing to emulate)
 #define __constant__ static const
 
 struct dim3 {
@@ -58,6 +59,8 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }    // (the emulator's dynamic LDS is one fixed 160 KB buffer)
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 #define hipEventDisableTiming 0x2
