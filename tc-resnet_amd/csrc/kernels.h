@@ -112,7 +112,8 @@ int launch_conv_mfma(int k, int stride, const ConvArgs& a, int epi, hipStream_t 
 // wt_ready: `wt` already holds the re-arranged weights (launch_dgrad_weights_multi)
 int launch_conv_dgrad_mfma(int k, int stride, int pad_lo, const float* w, float* wt, const float* dy, float* dx, const float* add,
                            const float* add_mask, int add_bcast, int batch, int cin, int cout, int tin, int tout, hipStream_t s,
-                           bool wt_ready = false);
+                           bool wt_ready = false, unsigned add_phases = ~0u);      // add_phases: bit r = output phase r takes `add`
+unsigned conv_dgrad_phases(int k, int stride, int pad_lo, int tin);
 bool conv_dgrad_mfma_covers(int k, int stride, int cout);
 int launch_conv_mfma_with_down(const ConvArgs& a, const float* w_down, float* y_down, const float* scale_down,
                                const float* shift_down, int pad_lo, int epi, hipStream_t s);

@@ -892,9 +892,19 @@ bool conv_dgrad_mfma_covers(int k, int stride, int cout) {
     return !(cout % 4 != 0 || stride < 1 || stride > 2 || k > 9) && tune_get(TCR_TUNE_CONV_PATH) != 1;
 }
 
+// bit r set: output phase r (positions S*u + r of dx) receives taps of this conv
+unsigned conv_dgrad_phases(int k, int stride, int pad_lo, int tin) {
+    unsigned m = 0;
+    for (int r = 0; r < stride; ++r) {
+        const int jmax = (k - 1) - (((k - 1) - ((r + pad_lo) % stride) + stride) % stride);
+        if (jmax >= 0 && tin - r > 0) m |= 1u << r;
+    }
+    return m;
+}
+
 int launch_conv_dgrad_mfma(int k, int stride, int pad_lo, const float* w, float* wt, const float* dy, float* dx, const float* add,
                            const float* add_mask, int add_bcast, int batch, int cin, int cout, int tin, int tout, hipStream_t s,
-                           bool wt_ready) {
+                           bool wt_ready, unsigned add_phases) {
     if (!conv_dgrad_mfma_covers(k, stride, cout)) return 1;
     if (!wt_ready) {
         hipLaunchKernelGGL(dgrad_weights_kernel, dim3(ceil_div(k * cin * cout, 256)), dim3(256), 0, s, w, wt, k, cin, cout, stride, pad_lo);
@@ -916,7 +926,7 @@ int launch_conv_dgrad_mfma(int k, int stride, int pad_lo, const float* w, float*
         a.tpi = tcr_padded_len(tout); a.tout = nu; a.tpo = tcr_padded_len(tin);
         a.xoff = kHalo + d_min; a.relu = 0;
         a.ostride = stride; a.ooff = r;
-        a.add = add; a.add_mask = add_mask; a.add_bcast = add_bcast;
+        if (add_phases >> r & 1u) { a.add = add; a.add_mask = add_mask; a.add_bcast = add_bcast; }
         int rc;
         switch (cnt) {
             case 1: rc = launch_conv_mfma_ks<1, 1>(a, nullptr, EPI_RAW, s); break;

@@ -43,7 +43,7 @@ struct tcr_net {
     // their own split-K slab, so they overlap the data-gradient / BN-backward chain of the layers below (each kernel of a
     // training step is too short to fill the chip on its own).  Created on first use; joined before the slab reduction.
     mutable hipStream_t side = nullptr;
-    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_down = nullptr, ev_join2 = nullptr;
+    mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_down = nullptr, ev_join2 = nullptr, ev_down_dg = nullptr;
     mutable hipStream_t side2 = nullptr;        // the classifier's filter gradient (nothing below depends on it)
     ~tcr_net() {
         if (ev_join2) (void)hipEventDestroy(ev_join2);
@@ -51,6 +51,7 @@ struct tcr_net {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_down) (void)hipEventDestroy(ev_down);
+        if (ev_down_dg) (void)hipEventDestroy(ev_down_dg);
         if (side) (void)hipStreamDestroy(side);
     }
 };
@@ -561,6 +562,7 @@ static int side_stream(const tcr_net& net, hipStream_t* out) {
             hipEventCreateWithFlags(&net.ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_down, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&net.ev_down_dg, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_join2, hipEventDisableTiming) != hipSuccess ||
             hipStreamCreateWithFlags(&net.side2, hipStreamNonBlocking) != hipSuccess) {
             set_error("cannot create the internal side stream");
@@ -1046,8 +1048,20 @@ static int bwd_unit_pre(const TrainCtx& c, const BwdUnit& u, hipStream_t st, flo
 // BN part runs (the shortcut branch's may run early on the side stream with the second scratch set).
 enum { BWD_BN = 1, BWD_WGRAD = 2, BWD_DGRAD = 4, BWD_ALL = 7 };
 
+// down_first: a block's shortcut conv writes the block-input gradient FIRST (its data gradient on `dg_stream`, early), conv_a's
+// adds onto the phases the shortcut wrote -- instead of conv_a first and the shortcut's accumulated behind it on the main chain.
+static bool down_dgrad_first(const TrainCtx& c, const Block& b) {
+    // Measured (batch 4096, scripts/ab_down_dgrad.py): TCResNet8 -0.8 % at 49 frames, -3 % at 98; TCResNet14-1.5 +1 % (its side stream is
+    // the longer one already) -- so by width, like the front-end's submit point: nets of <= 48 channels.  Knob 2 forces it on.
+    const int knob = tune_get(TCR_TUNE_DOWN_DGRAD);
+    if (b.down < 0 || c.sync_bn || c.side == c.s || knob == 1 || (knob == 0 && c.net->feat_c > 48)) return false;
+    const ConvLayer& ld = c.net->layers[b.down];
+    const ConvLayer& la = c.net->layers[b.a];
+    return ld.in_act >= 0 && conv_dgrad_mfma_covers(ld.k, ld.stride, ld.cout) && conv_dgrad_mfma_covers(la.k, la.stride, la.cout);
+}
+
 static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, const float* dpool, int parts, hipStream_t bn_stream,
-                         float* partial, float* kc) {
+                         float* partial, float* kc, hipStream_t dg_stream = nullptr) {
     const tcr_net& net = *c.net;
     const ConvLayer& l = net.layers[u.li];
     const int tp = tcr_padded_len(l.tout), tpi = tcr_padded_len(l.tin);
@@ -1106,10 +1120,18 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     const float* add = nullptr;
     const float* add_mask = nullptr;
     int add_bcast = 0;
+    unsigned add_phases = ~0u;
+    hipStream_t ds = dg_stream ? dg_stream : c.s;
     for (size_t bi = 0; bi < net.blocks.size(); ++bi) {
         const Block& b = net.blocks[bi];
-        if (u.li == b.down) {               // conv_a's dgrad ran first and already wrote gact[in]
-            add = dx;
+        if (u.li == b.down) {               // conv_a's dgrad ran first and already wrote gact[in] -- or this one writes first
+            if (!down_dgrad_first(c, b)) add = dx;
+        } else if (u.li == b.a && b.down >= 0) {
+            if (down_dgrad_first(c, b)) {   // the shortcut's data gradient is in gact[in] (the phases it has taps for): wait for it, add
+                const ConvLayer& ld = net.layers[b.down];
+                add = dx; add_phases = conv_dgrad_phases(ld.k, ld.stride, ld.pad_lo, ld.tin);
+                if (hipStreamWaitEvent(ds, c.net->ev_down_dg, 0) != hipSuccess) { set_error("tcr_net_backward: stream wait failed"); return TCR_ERR_HIP; }
+            }
         } else if (u.li == b.a && b.down < 0) {     // identity shortcut: + dOut * [out > 0]
             if (b.b == net.blocks.back().b) { add = dpool; add_bcast = 1; }
             else add = c.base + c.w.gact[b.b];
@@ -1118,9 +1140,10 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     }
     {
         const int rc = launch_conv_dgrad_mfma(l.k, l.stride, l.pad_lo, c.params + l.w_off, wt, dy, dx, add, add_mask, add_bcast,
-                                              c.batch, l.cin, l.cout, l.tin, l.tout, c.s, true);
+                                              c.batch, l.cin, l.cout, l.tin, l.tout, ds, true, add_phases);
         if (rc != 1) return rc;
     }
+    TCR_REQUIRE(ds == c.s && add_phases == ~0u, "tcr_net_backward: layer %d has no matrix-core data gradient", u.li);
     wt = c.base + c.w.wt;
     TCR_TRY(launch_transpose_weights(c.params + l.w_off, wt, l.k, l.cin, l.cout, c.s));
     DgradArgs d;
@@ -1401,13 +1424,16 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
         const bool early = !c.sync_bn && c.side != c.s;
         auto down_of_block_starting_at = [&](int li) { for (const Block& b : net->blocks) if (b.b == li && b.down >= 0) return b.down; return -1; };
         auto is_down = [&](int li) { for (const Block& b : net->blocks) if (b.down == li) return true; return false; };
+        auto down_first_of = [&](int li) { for (const Block& b : net->blocks) if (b.down == li) return early && down_dgrad_first(c, b); return false; };
         float* partial = c.base + c.w.partial;
         float* kc = c.base + c.w.kcoef;
         if (st > 0) {
             const int li = order[st - 1];
             if (early && is_down(li)) {
-                if (hipStreamWaitEvent(c.s, net->ev_down, 0) != hipSuccess) { set_error("tcr_net_backward: stream wait failed"); return TCR_ERR_HIP; }
-                TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, li, dpool), grads, dpool, BWD_DGRAD, c.s, partial, kc));
+                if (!down_first_of(li)) {       // (else: ran on the side stream when the block began)
+                    if (hipStreamWaitEvent(c.s, net->ev_down, 0) != hipSuccess) { set_error("tcr_net_backward: stream wait failed"); return TCR_ERR_HIP; }
+                    TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, li, dpool), grads, dpool, BWD_DGRAD, c.s, partial, kc));
+                }
             } else {
                 TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, li, dpool), grads, dpool, BWD_ALL, c.s, partial, kc));
             }
@@ -1424,6 +1450,10 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
                 TCR_TRY(bwd_unit_pre(c, ud, c.side, c.base + c.w.partial2));
                 TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_BN, c.side, c.base + c.w.partial2, c.base + c.w.kcoef2));
                 if (hipEventRecord(net->ev_down, c.side) != hipSuccess) { set_error("tcr_net_backward: event record failed"); return TCR_ERR_HIP; }
+                if (down_first_of(dn)) {
+                    TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_DGRAD, c.side, c.base + c.w.partial2, c.base + c.w.kcoef2, c.side));
+                    if (hipEventRecord(net->ev_down_dg, c.side) != hipSuccess) { set_error("tcr_net_backward: event record failed"); return TCR_ERR_HIP; }
+                }
                 TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_WGRAD, c.side, c.base + c.w.partial2, c.base + c.w.kcoef2));
             }
             if (!(early && is_down(li))) TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, li, dpool), c.s, partial));

@@ -498,6 +498,32 @@ def check_bn_backward_fused_equals_pair(lib, name, width, batch, seed=3, combos=
         assert torch.equal(grads[0], g), float((grads[0] - g).abs().max())
 
 
+def check_down_dgrad_order(lib, name, width, batch, seed=4, t=25):
+    """A block's shortcut conv writing the block-input gradient first (early, on the side stream; conv_a's data gradient adds onto
+    it -- the default) is BITWISE conv_a first and the shortcut added behind it (TCR_TUNE_DOWN_DGRAD = 1): one addition, commuted."""
+    import tcresnet_amd as T
+    dev = device_of(lib)
+    rng = np.random.RandomState(seed)
+    f = 40
+    x = torch.from_numpy(rng.uniform(-2, 2, (batch, t, f)).astype(np.float32)).to(dev)
+    feat = T.features_to_planar(x, lib=lib)
+    labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
+    ch = R.tcresnet_channels(name, float(width))
+    grads = []
+    try:
+        for knob in (2, 1, 0):          # 2: early for every width (0: only nets of <= 48 channels)
+            lib.tcr_tune(17, knob)
+            net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)
+            net.init_xavier(1)
+            net.forward_train(feat, labels, keep_prob=0.5, seed=9)
+            grads.append(net.backward().clone())
+    finally:
+        lib.tcr_tune(17, 0)
+    for g in grads[1:]:
+        assert torch.equal(grads[0], g), float((grads[0] - g).abs().max())
+    assert float(grads[0].abs().max()) > 0
+
+
 def check_dscnn_mask_paths_agree(lib, size, batch, seed=5):
     """DS-CNN backward with the ReLU masks recomputed from the raw BN inputs (default) is BITWISE the run that reads the activations."""
     import tcresnet_amd as T

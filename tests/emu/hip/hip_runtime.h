@@ -65,7 +65,8 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hi
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 #define hipEventDisableTiming 0x2
 #define hipStreamNonBlocking 0x1
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+// (distinct handles, never dereferenced: the host code takes its multi-stream branches; launches still run in issue order)
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static char ids[64]; static int n = 0; *s = &ids[n++ & 63]; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

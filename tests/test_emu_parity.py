@@ -147,6 +147,11 @@ def test_bn_backward_fused_equals_pair(emu_lib):
     Cm.check_dscnn_mask_paths_agree(emu_lib, "S", 3)
 
 
+def test_down_dgrad_order_is_bitwise(emu_lib):
+    Cm.check_down_dgrad_order(emu_lib, "TCResNet8", 1.0, 3)
+    Cm.check_down_dgrad_order(emu_lib, "TCResNet14", 1.5, 2, t=24)     # even frame count: the other SAME-padding split
+
+
 def test_dscnn_staged_sync_bn_api(emu_lib):
     Cm.check_dscnn_staged_equals_unstaged(emu_lib, "S", 3)
     Cm.check_dscnn_staged_equals_unstaged(emu_lib, "M", 2)      # the lazy path: hand-offs from the epilogue sums

@@ -451,6 +451,13 @@ def test_bn_backward_fused_equals_pair(hip_lib):
     Cm.check_dscnn_mask_paths_agree(hip_lib, "L", 256)
 
 
+@pytest.mark.gpu
+def test_down_dgrad_order_is_bitwise(hip_lib):
+    Cm.check_down_dgrad_order(hip_lib, "TCResNet8", 1.0, 4096, t=49)
+    Cm.check_down_dgrad_order(hip_lib, "TCResNet14", 1.5, 300)
+    Cm.check_down_dgrad_order(hip_lib, "TCResNet8", 1.5, 512, t=98)
+
+
 @pytest.mark.parametrize("size,batch", [("S", 96), ("M", 100), ("L", 1024)])
 def test_dscnn_staged_sync_bn_api(hip_lib, size, batch):
     Cm.check_dscnn_staged_equals_unstaged(hip_lib, size, batch)
