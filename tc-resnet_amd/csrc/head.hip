@@ -174,7 +174,15 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < c * nc; i += 256) {
         const int ch = i / nc, o = i % nc;
         float s = 0.f;
-        for (int b = b0; b < b1; ++b) s = fmaf(dropped[(size_t)b * c + ch], dlogits[(size_t)b * nc + o], s);
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {       // eight utterances' operands in flight, added in utterance order (one dependent load pair per
+            float xv[8], dv[8];             // utterance was 64 L2 round trips per output: 72 us for 2.4 MFLOP)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xv[u] = dropped[(size_t)(b + u) * c + ch]; dv[u] = dlogits[(size_t)(b + u) * nc + o]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(xv[u], dv[u], s);
+        }
+        for (; b < b1; ++b) s = fmaf(dropped[(size_t)b * c + ch], dlogits[(size_t)b * nc + o], s);
         partial[(size_t)blockIdx.x * c * nc + i] = s;
     }
 }
@@ -183,7 +191,15 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nchunk, int n, float* __restrict__ out) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         double s = 0.0;
-        for (int k = 0; k < nchunk; ++k) s += (double)partial[(size_t)k * n + i];
+        int k = 0;
+        for (; k + 8 <= nchunk; k += 8) {       // eight rows in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(k + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; k < nchunk; ++k) s += (double)partial[(size_t)k * n + i];
         out[i] = (float)s;
     }
 }
