@@ -591,7 +591,6 @@ struct tcr_dscnn {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         for (hipEvent_t e : ev_done) if (e) (void)hipEventDestroy(e);
-        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -1072,11 +1071,11 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
     hipStream_t side = s;
     if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) {
         if (!net->side) {
-            bool ok = hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) == hipSuccess &&
+            bool ok = (net->side = shared_stream(0)) != nullptr &&         // (process-wide: see tcr::shared_stream)
                       hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&net->ev_done[i], hipEventDisableTiming) == hipSuccess;
-            if (!ok) { set_error("tcr_dscnn_backward: cannot create the filter-gradient stream"); return TCR_ERR_HIP; }
+            if (!ok) { net->side = nullptr; set_error("tcr_dscnn_backward: cannot create the filter-gradient stream"); return TCR_ERR_HIP; }
         }
         side = net->side;
     }

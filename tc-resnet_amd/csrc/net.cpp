@@ -47,12 +47,10 @@ struct tcr_net {
     mutable hipStream_t side2 = nullptr;        // the classifier's filter gradient (nothing below depends on it)
     ~tcr_net() {
         if (ev_join2) (void)hipEventDestroy(ev_join2);
-        if (side2) (void)hipStreamDestroy(side2);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_down) (void)hipEventDestroy(ev_down);
         if (ev_down_dg) (void)hipEventDestroy(ev_down_dg);
-        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -555,16 +553,17 @@ static int forward_infer_impl(const tcr_net* net, const float* params, const flo
 // ---- train-mode forward -----------------------------------------------------------------------
 namespace tcr {
 
-// the net's internal second stream + events, created on first use
+// the library's second stream (process-wide, tcr::shared_stream) + the net's own events, on first use
 static int side_stream(const tcr_net& net, hipStream_t* out) {
     if (!net.side) {
-        if (hipStreamCreateWithFlags(&net.side, hipStreamNonBlocking) != hipSuccess ||
+        net.side2 = shared_stream(1);
+        if (!(net.side = shared_stream(0)) || !net.side2 ||
             hipEventCreateWithFlags(&net.ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_down, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_down_dg, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&net.ev_join2, hipEventDisableTiming) != hipSuccess ||
-            hipStreamCreateWithFlags(&net.side2, hipStreamNonBlocking) != hipSuccess) {
+            hipEventCreateWithFlags(&net.ev_join2, hipEventDisableTiming) != hipSuccess) {
+            net.side = nullptr;
             set_error("cannot create the internal side stream");
             return TCR_ERR_HIP;
         }

@@ -2,6 +2,7 @@
 #include "tcr_common.h"
 
 #include <cstring>
+#include <mutex>
 
 namespace tcr {
 
@@ -21,6 +22,26 @@ int check_launch(const char* what) {
         return TCR_ERR_HIP;
     }
     return TCR_OK;
+}
+
+// The library's internal streams: ONE set per device for the whole process, created on first use and kept until exit.
+// HIP multiplexes streams onto a handful of hardware queues, and two streams that land on one queue serialise: with a
+// pair of streams per net object, the 4th and 6th TCResNet8 created in a process trained 33 % slower than the first
+// (1355 vs 1013 us per step, scripts/stream_alias_check.py) -- which streams shared a queue depended on how many nets
+// had come and gone.  A fixed set keeps the mapping the first net got; nets driven concurrently from different caller
+// streams share it (their event dependencies stay per net: correct, at worst serialised).
+hipStream_t shared_stream(int idx) {
+    constexpr int kDev = 64, kN = 2;
+    static std::mutex mu;
+    static hipStream_t pool[kDev][kN] = {};
+    int dev = 0;
+    if (idx < 0 || idx >= kN || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDev) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    // (Normal priority.  Streams of the lowest / highest priority were tried -- the idea: another priority level, another set of
+    // hardware queues, never the caller's -- and were WORSE whenever other streams existed: 2112 us per TCResNet8 step with two
+    // foreign streams created first, against 1035 at normal priority; scripts/stream_alias_check.py.)
+    if (!pool[dev][idx] && hipStreamCreateWithFlags(&pool[dev][idx], hipStreamNonBlocking) != hipSuccess) pool[dev][idx] = nullptr;
+    return pool[dev][idx];
 }
 
 static int g_tune[TCR_TUNE_COUNT] = {0};

@@ -23,6 +23,7 @@ constexpr int kWave = 64;
 // ---- error plumbing (thread-local message behind tcr_last_error) --------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);      // hipGetLastError -> TCR_OK / TCR_ERR_HIP
+hipStream_t shared_stream(int idx);      // the library's internal streams (0: filter gradients / shortcut branch, 1: classifier gradients); nullptr on failure
 int tune_get(int knob);                  // process-wide tuning knobs (tcr_tune)
 int device_cus();                        // compute units of the current device (cached per device; 256 on MI355X)
 

@@ -12,11 +12,25 @@ import torch
 from ._lib import padded_len
 
 
+_STREAMS = {}
+
+
+def shared_stream(dev, role: str) -> "torch.cuda.Stream":
+    """One stream per (device, role) for the whole process.  HIP multiplexes streams onto a few hardware queues and streams that
+    share a queue serialise; with a fresh stream per pipeline object, which streams collided depended on how many objects had come
+    and gone (the library's internal streams are process-wide for the same reason: tcr::shared_stream)."""
+    dev = torch.device(dev)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), role)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(dev)
+    return _STREAMS[key]
+
+
 class InferencePipeline:
     def __init__(self, frontend, net, batch: int, depth: int = 2):
         self.fe, self.net, self.batch, self.depth = frontend, net, int(batch), int(depth)
         dev = frontend.device
-        self.s_fe, self.s_net = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        self.s_fe, self.s_net = shared_stream(dev, "frontend"), shared_stream(dev, "network")
         self.feat = [torch.empty((batch, frontend.n_coef, padded_len(frontend.n_frames)), device=dev) for _ in range(depth)]
         self.out = [(torch.empty((batch, net.num_classes), device=dev), torch.empty((batch, net.num_classes), device=dev))
                     for _ in range(depth)]
@@ -84,7 +98,7 @@ class FeaturePrefetcher:
         """overlap=False degrades to the caller's stream (same results, no second stream)."""
         self.fe = frontend
         dev = frontend.device
-        self.stream = torch.cuda.Stream(dev) if overlap else None
+        self.stream = shared_stream(dev, "frontend") if overlap else None
         self.feat = [torch.empty((batch, frontend.n_coef, padded_len(frontend.n_frames)), device=dev) for _ in range(2)]
         self._ready = [torch.cuda.Event(), torch.cuda.Event()]
         self._free = [None, None]           # event after which buffer i may be overwritten
