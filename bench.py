@@ -119,8 +119,8 @@ def main():
     # ---------------- headline: eval forward, 49x40 front-end ----------------
     # One step = fused MFCC kernel + whole-network fused kernel, back to back on the current stream (so that the two HIP-event
     # intervals add up to the step).  A two-stream pipeline overlapping front-end(k+1) with network(k) -- tcresnet_amd.pipeline --
-    # is ~3 % faster three batches deep (295.7 vs 304.7 us, scripts/ab_coresident.py); capping both grids at one workgroup per CU
-    # so that the kernels co-reside on every CU LOSES (357 - 447 us): DESIGN.md section 7.
+    # is ~4 % faster three batches deep (272 vs 284 us, scripts/ab_coresident.py; the "forward_pipelined" leg below); capping both grids
+    # at one workgroup per CU so that the kernels co-reside on every CU LOSES (346 - 413 us): DESIGN.md section 7.
     fe, net = build("4020")
     feat = torch.empty((B, 40, fe.n_frames + 8), device=dev)
     outbuf = (torch.empty((B, 12), device=dev), torch.empty((B, 12), device=dev))
@@ -351,6 +351,26 @@ def main():
                           "hbm_gbs": round(aug_bytes / (dta / sa) / 1e9, 1), "hbm_frac": round(aug_bytes / (dta / sa) / 1e9 / HBM_PEAK_GBS, 4),
                           "algorithmic_bytes_per_launch": aug_bytes,
                           "workload": "tcr_augment_fwd: int16 PCM -> float, +-1600-sample shift, background mix (80 % of utterances), clip; batch 4096/GPU"}
+
+        # ---------------- the headline workload through the two-stream pipeline (tcresnet_amd.pipeline.InferencePipeline) ----------------
+        # front-end(k+1) overlaps network(k), three batches deep; every step computes its own batch (outputs bitwise the sequential step's,
+        # scripts/ab_coresident.py).  Reported next to the headline, which stays the sequential step so that its two event intervals add up.
+        from tcresnet_amd.pipeline import InferencePipeline
+        pipe = InferencePipeline(fe, net, B, depth=3)
+        sp = max(50, args.steps)
+        def seq_step():
+            fe(wav, out=feat)
+            net.forward_infer(feat, out=outbuf)
+        dts = timed(seq_step, sp, max(20, args.warmup), dist_on)          # the sequential step again, at this point of the run
+        dtp = timed(lambda: pipe.submit(wav), sp, max(20, args.warmup), dist_on)
+        pipe.sync()
+        torch.cuda.synchronize()
+        ref_logits = net.forward_infer(fe(wav))[0]
+        out["forward_pipelined"] = {"value": round(world * B * sp / dtp, 1), "unit": "utterances/s", "ms_per_step": round(dtp / sp * 1e3, 4), "steps": sp,
+                                    "sequential_ms_per_step_here": round(dts / sp * 1e3, 4),
+                                    "bitwise_equal_to_sequential": bool(all(torch.equal(o[0], ref_logits) for o in pipe.out)),
+                                    "whole_path_fp32_frac": round(B * sp / dtp * (w["mfcc_flops"] + w["net_flops"]) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                    "workload": "the headline workload, front-end(k+1) || network(k) on two streams, three batches deep"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -416,6 +416,14 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_COUNT = 18 };
 int tcr_tune(int knob, int value);
 
+/* The library's internal streams (hipStream_t), one set per device and process.  HIP multiplexes streams onto a few hardware queues
+ * and streams that share a queue serialise; the set is chosen on first use -- candidates are probed -- so that streams 0, 1, 2 and
+ * `caller_stream` (the stream the host launches on; it is synchronised a few times by that first call) run concurrently, and stream 3
+ * runs concurrently with `caller_stream` and stream 2.  0 / 1: the backward's filter gradients, used internally.  2: for the host's
+ * input stage (the next batch's front-end next to a training step: the reference's tf.data prefetch, datasets/data_wrapper_base.py:70-76).
+ * 3: for the network of a two-stream inference pipeline whose front-end runs on 2.  NULL on failure or idx outside 0..3. */
+void* tcr_internal_stream(int idx, void* caller_stream);
+
 #ifdef __cplusplus
 }
 #endif

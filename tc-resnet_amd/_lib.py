@@ -52,6 +52,7 @@ _PROTOTYPES = {
     "tcr_last_error": (C.c_char_p, []),
     "tcr_kernel_name": (C.c_char_p, [C.c_int]),
     "tcr_tune": (C.c_int, [C.c_int, C.c_int]),
+    "tcr_internal_stream": (_P, [C.c_int, _P]),
     "tcr_frontend_resolve": (C.c_int, [C.POINTER(FrontendCfg)]),
     "tcr_frontend_plan_bytes": (C.c_size_t, [C.POINTER(FrontendCfg)]),
     "tcr_frontend_plan_init": (C.c_int, [C.POINTER(FrontendCfg), _P]),

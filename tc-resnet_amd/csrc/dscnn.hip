@@ -1071,7 +1071,7 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
     hipStream_t side = s;
     if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) {
         if (!net->side) {
-            bool ok = (net->side = shared_stream(0)) != nullptr &&         // (process-wide: see tcr::shared_stream)
+            bool ok = (net->side = shared_stream(0, s)) != nullptr &&         // (process-wide: see tcr::shared_stream)
                       hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) == hipSuccess;
             for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&net->ev_done[i], hipEventDisableTiming) == hipSuccess;

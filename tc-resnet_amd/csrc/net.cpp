@@ -554,10 +554,10 @@ static int forward_infer_impl(const tcr_net* net, const float* params, const flo
 namespace tcr {
 
 // the library's second stream (process-wide, tcr::shared_stream) + the net's own events, on first use
-static int side_stream(const tcr_net& net, hipStream_t* out) {
+static int side_stream(const tcr_net& net, hipStream_t caller, hipStream_t* out) {
     if (!net.side) {
-        net.side2 = shared_stream(1);
-        if (!(net.side = shared_stream(0)) || !net.side2 ||
+        net.side2 = shared_stream(1, caller);
+        if (!(net.side = shared_stream(0, caller)) || !net.side2 ||
             hipEventCreateWithFlags(&net.ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&net.ev_down, hipEventDisableTiming) != hipSuccess ||
@@ -788,7 +788,7 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
     c.sync_bn = sync_bn != 0;
     c.s = static_cast<hipStream_t>(stream);
     c.side = c.s;
-    if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1 && !sync_bn) TCR_TRY(side_stream(*net, &c.side));
+    if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1 && !sync_bn) TCR_TRY(side_stream(*net, c.s, &c.side));
     const int nu = (int)net->units.size();
     TCR_REQUIRE(plan || (stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end), "tcr_net_forward_train: bad stage range [%d, %d)", stage_begin, stage_end);
     const bool phases = phases_usable(c);
@@ -1313,7 +1313,7 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     c.sync_bn = sync_bn != 0;
     c.s = static_cast<hipStream_t>(stream);
     c.side = c.s;
-    if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) TCR_TRY(side_stream(*net, &c.side));
+    if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) TCR_TRY(side_stream(*net, c.s, &c.side));
     const std::vector<int> order = backward_order(*net);
     const int nu = (int)order.size();
     TCR_REQUIRE(plan || (stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end), "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);

@@ -2,6 +2,7 @@
 #include "tcr_common.h"
 
 #include <cstring>
+#include <initializer_list>
 #include <mutex>
 
 namespace tcr {
@@ -24,23 +25,80 @@ int check_launch(const char* what) {
     return TCR_OK;
 }
 
-// The library's internal streams: ONE set per device for the whole process, created on first use and kept until exit.
-// HIP multiplexes streams onto a handful of hardware queues, and two streams that land on one queue serialise: with a
-// pair of streams per net object, the 4th and 6th TCResNet8 created in a process trained 33 % slower than the first
-// (1355 vs 1013 us per step, scripts/stream_alias_check.py) -- which streams shared a queue depended on how many nets
-// had come and gone.  A fixed set keeps the mapping the first net got; nets driven concurrently from different caller
-// streams share it (their event dependencies stay per net: correct, at worst serialised).
-hipStream_t shared_stream(int idx) {
-    constexpr int kDev = 64, kN = 2;
+// The library's internal streams: ONE set per device for the whole process, chosen on first use and kept until exit.
+// HIP multiplexes streams onto a handful of hardware queues (four by default), and two streams that land on one queue
+// serialise.  With a pair of streams per net object, the 4th and 6th TCResNet8 created in a process trained 33 % slower
+// than the first (1355 vs 1013 us per step, scripts/stream_alias_check.py); with one fixed pair, how many streams OTHER code
+// had created first decided it (five foreign streams: 1370 us); the two-stream inference pipeline runs at 272 us per batch on
+// streams with queues of their own, 313 on two streams that share one, 322 when the network's shares the caller's
+// (scripts/stream_concurrency_probe.py).  So the set is CHOSEN, not just created: candidates are created and probed --
+// a 2 ms spin on one stream, an empty kernel on the other: the empty kernel finishing first means different queues --
+// until streams 0, 1, 2 and the first caller's stream are pairwise concurrent (four queues), and stream 3 is concurrent with
+// the caller's and with stream 2; the other candidates are destroyed.  One-off, ~20-60 ms.  Streams of the lowest / highest
+// PRIORITY (hoping for a queue of another level, never the caller's) were worse: 2112 us per step with two foreign streams.
+// Roles: 0 filter gradients / shortcut branch, 1 classifier gradients, 2 front-end of the next batch, 3 network of the
+// two-stream inference pipeline (2 and 3 are handed to the host side by tcr_internal_stream).
+__global__ void stream_probe_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();            // 100 MHz constant clock
+    while (wall_clock64() - t0 < ticks) {}
+}
+__global__ void stream_probe_empty_kernel() {}
+
+// true: work on `b` overtakes work on `a` (different hardware queues)
+static bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb) {
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    hipLaunchKernelGGL(stream_probe_spin_kernel, dim3(1), dim3(1), 0, a, 200000LL);     // 2 ms
+    if (hipEventRecord(ea, a) != hipSuccess) return false;
+    hipLaunchKernelGGL(stream_probe_empty_kernel, dim3(1), dim3(1), 0, b);
+    if (hipEventRecord(eb, b) != hipSuccess || hipEventSynchronize(eb) != hipSuccess) { (void)hipEventSynchronize(ea); return false; }
+    const bool overtook = hipEventQuery(ea) == hipErrorNotReady;
+    (void)hipEventSynchronize(ea);
+    return overtook;
+}
+
+constexpr int kSharedStreams = 4;
+
+static void choose_streams(hipStream_t caller, hipStream_t (&out)[kSharedStreams]) {
+    constexpr int kCand = 12;
+    hipStream_t cand[kCand] = {};
+    bool used[kCand] = {};
+    int nc = 0;
+    for (; nc < kCand; ++nc)
+        if (hipStreamCreateWithFlags(&cand[nc], hipStreamNonBlocking) != hipSuccess) break;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    const bool probe = hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess;
+    auto pick = [&](std::initializer_list<hipStream_t> apart) -> hipStream_t {
+        for (int pass = 0; pass < 2; ++pass)                    // pass 1: nothing qualified (or no probing possible) -- the first unused candidate
+            for (int i = 0; i < nc; ++i) {
+                if (used[i]) continue;
+                bool ok = true;
+                if (pass == 0) {
+                    ok = probe;
+                    for (hipStream_t o : apart) ok = ok && streams_concurrent(o, cand[i], ea, eb);
+                }
+                if (ok) { used[i] = true; return cand[i]; }
+            }
+        return nullptr;
+    };
+    out[0] = pick({caller});
+    out[1] = pick({caller, out[0]});
+    out[2] = pick({caller, out[0], out[1]});
+    out[3] = pick({caller, out[2]});
+    for (int i = 0; i < nc; ++i) if (!used[i]) (void)hipStreamDestroy(cand[i]);
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    (void)hipGetLastError();
+}
+
+hipStream_t shared_stream(int idx, hipStream_t caller) {
+    constexpr int kDev = 64;
     static std::mutex mu;
-    static hipStream_t pool[kDev][kN] = {};
+    static hipStream_t pool[kDev][kSharedStreams] = {};
+    static bool chosen[kDev] = {};
     int dev = 0;
-    if (idx < 0 || idx >= kN || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDev) return nullptr;
+    if (idx < 0 || idx >= kSharedStreams || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDev) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    // (Normal priority.  Streams of the lowest / highest priority were tried -- the idea: another priority level, another set of
-    // hardware queues, never the caller's -- and were WORSE whenever other streams existed: 2112 us per TCResNet8 step with two
-    // foreign streams created first, against 1035 at normal priority; scripts/stream_alias_check.py.)
-    if (!pool[dev][idx] && hipStreamCreateWithFlags(&pool[dev][idx], hipStreamNonBlocking) != hipSuccess) pool[dev][idx] = nullptr;
+    if (!chosen[dev]) { choose_streams(caller, pool[dev]); chosen[dev] = true; }
     return pool[dev][idx];
 }
 
@@ -68,6 +126,12 @@ extern "C" int tcr_tune(int knob, int value) {
     }
     tcr::g_tune[knob] = value;
     return TCR_OK;
+}
+
+extern "C" void* tcr_internal_stream(int idx, void* caller_stream) {
+    hipStream_t st = tcr::shared_stream(idx, static_cast<hipStream_t>(caller_stream));
+    if (!st) tcr::set_error("tcr_internal_stream: no stream %d", idx);
+    return st;
 }
 
 extern "C" int tcr_abi_version(void) { return TCR_ABI_VERSION; }

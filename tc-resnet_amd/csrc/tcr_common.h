@@ -23,7 +23,9 @@ constexpr int kWave = 64;
 // ---- error plumbing (thread-local message behind tcr_last_error) --------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);      // hipGetLastError -> TCR_OK / TCR_ERR_HIP
-hipStream_t shared_stream(int idx);      // the library's internal streams (0: filter gradients / shortcut branch, 1: classifier gradients); nullptr on failure
+// the library's internal streams (0: filter gradients / shortcut branch, 1: classifier gradients, 2 / 3: tcr_internal_stream), chosen on first
+// use so that they do not share a hardware queue with `caller` (the stream of that first call) or each other; nullptr on failure
+hipStream_t shared_stream(int idx, hipStream_t caller);
 int tune_get(int knob);                  // process-wide tuning knobs (tcr_tune)
 int device_cus();                        // compute units of the current device (cached per device; 256 on MI355X)
 

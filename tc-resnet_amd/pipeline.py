@@ -13,16 +13,24 @@ from ._lib import padded_len
 
 
 _STREAMS = {}
+_ROLE_INDEX = {"frontend": 2, "network": 3}
 
 
 def shared_stream(dev, role: str) -> "torch.cuda.Stream":
-    """One stream per (device, role) for the whole process.  HIP multiplexes streams onto a few hardware queues and streams that
-    share a queue serialise; with a fresh stream per pipeline object, which streams collided depended on how many objects had come
-    and gone (the library's internal streams are process-wide for the same reason: tcr::shared_stream)."""
+    """One stream per (device, role) for the whole process: the library's internal stream of that role (`tcr_internal_stream`).
+    HIP multiplexes streams onto a few hardware queues and streams that share a queue serialise -- the two-stream pipeline runs at
+    272 us per batch on streams with queues of their own, 313 on two that share one (scripts/stream_concurrency_probe.py) -- so the
+    library probes candidates once and keeps a set that runs concurrently with the caller's current stream and with each other."""
+    from . import _lib
     dev = torch.device(dev)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), role)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (dev.type, index, role)
     if key not in _STREAMS:
-        _STREAMS[key] = torch.cuda.Stream(dev)
+        with torch.cuda.device(index):
+            ptr = _lib.get().tcr_internal_stream(_ROLE_INDEX[role], torch.cuda.current_stream(dev).cuda_stream)
+        if not ptr:
+            raise _lib.TcrError(f"tcr_internal_stream({role}): {_lib.get().tcr_last_error().decode()}")
+        _STREAMS[key] = torch.cuda.ExternalStream(ptr, device=dev)
     return _STREAMS[key]
 
 

@@ -12,6 +12,7 @@
 // (tc-resnet_amd/_lib.py) only ever opens the hipcc-built gfx950 library and fails loudly
 // without it; only tests/ load the emulator build.
 #pragma once
+#include <chrono>
 #include <ucontext.h>
 
 #include <algorithm>
@@ -72,6 +73,9 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+#define hipErrorNotReady 600
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }      // (launches are synchronous: nothing ever overtakes)
+static inline long long wall_clock64() { return (long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10); }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 
 namespace emu {
