@@ -224,7 +224,7 @@ def main():
             f = pf.get()
             if early: pf.submit(wav)
             dp.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
-            if not early: pf.submit(wav)       # wide nets: the forward's LDS-resident phases cannot share a CU with the front-end, the backward can
+            if not early: pf.submit(wav)
             dp.backward()
             net.sgd_momentum_step(0.1, 0.9, 0.001)
 
@@ -295,8 +295,8 @@ def main():
 
         def train_ds():
             ds_step[0] += 1
-            fe3(wav, out=feat3)
-            dpd.forward_train(feat3, labels)
+            fe3(wav, out=feat3)             # in line: prefetched next to the step (FeaturePrefetcher) it costs more than its own 0.17 ms --
+            dpd.forward_train(feat3, labels)    # 16.89 against 16.15 ms per step: its 2 x 77 KB of LDS per CU displace the step's LDS-tiled kernels
             dpd.backward()
             ds.adam_step(5e-4, ds_step[0])
 

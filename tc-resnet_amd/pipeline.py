@@ -86,21 +86,20 @@ class FeaturePrefetcher:
         pf.submit(first_wavs)
         for step in ...:
             feat = pf.get()                 # features of this step (ready on the caller's stream)
-            # pf.submit(next_wavs) here when FeaturePrefetcher.submit_point(net) == "before_forward" (narrow nets) ...
+            pf.submit(next_wavs)            # FeaturePrefetcher.submit_point(net) == "before_forward": the next step's features overlap this whole step
             net.forward_train(feat, ...)
-            pf.submit(next_wavs)            # ... or here: next step's features overlap the backward (wide nets: the forward's phases hold the LDS)
             net.backward(); net.sgd_momentum_step(...)
     """
 
     @staticmethod
     def submit_point(net) -> str:
-        """Where in the step the next batch's front-end is best issued, measured at batch 4096 (scripts/ab_prefetch_point.py, round 3, after
-        the backward's filter gradients had been re-packed onto its side streams): "before_forward" for the narrow nets (TCResNet8-1.0: 1161 us
-        against 1229 behind the forward, 1271 behind the backward, 1231 with no overlap; 98 frames: 1814 / 1849 / 1891 / 1847) -- their
-        single-stream forward leaves the chip the most room --, "after_forward" for the wide ones (TCResNet14-1.5: 3083 against 3126
-        before the forward: its forward phases' LDS and the front-end's 2 x 77 KB exclude each other on a CU)."""
-        widest = max((int(ti.shape[ti.rank - 1]) for n, ti in net.tensors.items() if n.endswith("/weights")), default=0)
-        return "before_forward" if widest <= 48 else "after_forward"
+        """Where in the step the next batch's front-end is best issued: in front of the forward, for every net family.  Measured at
+        batch 4096 (scripts/ab_prefetch_point.py, round 3, with the front-end on a stream that has a hardware queue of its own --
+        `shared_stream`): TCResNet8-1.0 1108 us against 1193 behind the forward, 1216 behind the backward, 1181 with no overlap, 995 for
+        the step alone; 98 frames 1705 / 1745 / 1758 / 1730; TCResNet14-1.5 3034 / 3079 / 3104 / 3061; 98 frames 4783 / 4841 / 4853 /
+        4815.  (An earlier measurement had the wide nets "after_forward": 3083 against 3126 -- taken on a stream that, as it turned out,
+        shared a hardware queue with one of the backward's; the argument `net` stays for callers that ask per net.)"""
+        return "before_forward"
 
     def __init__(self, frontend, batch: int, overlap: bool = True):
         """overlap=False degrades to the caller's stream (same results, no second stream)."""

@@ -191,8 +191,8 @@ def test_forward_waveform_single_call_is_the_three_call_path(emu_lib):
 
 
 def test_prefetch_submit_point_policy(emu_lib):
-    """FeaturePrefetcher.submit_point: the narrow nets take the next batch's front-end in front of their forward, the wide ones behind it."""
+    """FeaturePrefetcher.submit_point: every net family takes the next batch's front-end in front of its forward (measured, pipeline.py)."""
     from tcresnet_amd.pipeline import FeaturePrefetcher
     n8 = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, 49, 12, lib=emu_lib)
     n14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, 49, 12, lib=emu_lib)
-    assert FeaturePrefetcher.submit_point(n8) == "before_forward" and FeaturePrefetcher.submit_point(n14) == "after_forward"
+    assert FeaturePrefetcher.submit_point(n8) == "before_forward" and FeaturePrefetcher.submit_point(n14) == "before_forward"
