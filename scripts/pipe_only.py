@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Profiling target: the headline workload through the two-stream inference pipeline (front-end(k+1) || network(k), three batches deep)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import tcresnet_amd as T
+from tcresnet_amd.pipeline import InferencePipeline
+from bench import synth_batch
+
+dev = torch.device("cuda")
+B = 4096
+wav = synth_batch(B, dev, 1234)
+fe = T.Frontend(window_size_samples=640, window_stride_samples=320, device=dev)
+net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, fe.n_frames, 12, device=dev)
+net.init_xavier(0)
+pipe = InferencePipeline(fe, net, B, depth=3)
+for _ in range(int(os.environ.get("STEPS", "120"))):
+    pipe.submit(wav)
+pipe.sync()
+torch.cuda.synchronize()
