@@ -119,7 +119,7 @@ def main():
     # ---------------- headline: eval forward, 49x40 front-end ----------------
     # One step = fused MFCC kernel + whole-network fused kernel, back to back on the current stream (so that the two HIP-event
     # intervals add up to the step).  A two-stream pipeline overlapping front-end(k+1) with network(k) -- tcresnet_amd.pipeline --
-    # is ~4 % faster three batches deep (272 vs 284 us, scripts/ab_coresident.py; the "forward_pipelined" leg below); capping both grids
+    # is 4-7 % faster (272 us three batches deep, 264 with whole batches alternating between the streams, vs 284; the "forward_pipelined" leg below); capping both grids
     # at one workgroup per CU so that the kernels co-reside on every CU LOSES (346 - 413 us): DESIGN.md section 7.
     fe, net = build("4020")
     feat = torch.empty((B, 40, fe.n_frames + 8), device=dev)
@@ -353,10 +353,12 @@ def main():
                           "workload": "tcr_augment_fwd: int16 PCM -> float, +-1600-sample shift, background mix (80 % of utterances), clip; batch 4096/GPU"}
 
         # ---------------- the headline workload through the two-stream pipeline (tcresnet_amd.pipeline.InferencePipeline) ----------------
-        # front-end(k+1) overlaps network(k), three batches deep; every step computes its own batch (outputs bitwise the sequential step's,
-        # scripts/ab_coresident.py).  Reported next to the headline, which stays the sequential step so that its two event intervals add up.
+        # Whole batches alternate between two streams that have hardware queues of their own: batch k's front-end and network back to
+        # back on one stream while batch k+1 runs on the other; every step computes its own batch (outputs bitwise the sequential
+        # step's, scripts/ab_pipeline_modes.py).  Reported next to the headline, which stays the sequential step so that its two event
+        # intervals add up.
         from tcresnet_amd.pipeline import InferencePipeline
-        pipe = InferencePipeline(fe, net, B, depth=3)
+        pipe = InferencePipeline(fe, net, B, mode="alternate")
         sp = max(50, args.steps)
         def seq_step():
             fe(wav, out=feat)
@@ -370,7 +372,7 @@ def main():
                                     "sequential_ms_per_step_here": round(dts / sp * 1e3, 4),
                                     "bitwise_equal_to_sequential": bool(all(torch.equal(o[0], ref_logits) for o in pipe.out)),
                                     "whole_path_fp32_frac": round(B * sp / dtp * (w["mfcc_flops"] + w["net_flops"]) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                                    "workload": "the headline workload, front-end(k+1) || network(k) on two streams, three batches deep"}
+                                    "workload": "the headline workload, whole batches alternating between two streams (front-end + network of batch k on one, batch k+1 on the other)"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

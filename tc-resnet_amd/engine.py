@@ -256,6 +256,10 @@ class TCResNet(_Base):
             self._ws[key] = ws
         return ws
 
+    def new_workspace(self, batch: int, train: bool) -> torch.Tensor:
+        """A fresh scratch tensor of the size `workspace(batch, train)` has (not cached, not shared)."""
+        return torch.empty(self.lib.tcr_net_workspace_bytes(self._h, batch, int(train)) // 4, dtype=torch.float32, device=self.device)
+
     def _check_feat(self, feat: torch.Tensor):
         self._check_tensor(feat, "features")
         want = (self.in_channels, padded_len(self.t_in))
@@ -296,11 +300,13 @@ class TCResNet(_Base):
             cur.wait_event(self._fold_event)
         return self._fold_ss
 
-    def forward_infer(self, feat: torch.Tensor, want_ranges: bool = False, out=None):
-        """Eval-mode forward.  `out=(logits, probs)` reuses caller-owned output tensors (stream pipelines)."""
+    def forward_infer(self, feat: torch.Tensor, want_ranges: bool = False, out=None, workspace: Optional[torch.Tensor] = None):
+        """Eval-mode forward.  `out=(logits, probs)` reuses caller-owned output tensors (stream pipelines); `workspace`: a caller-owned
+        scratch tensor of `new_workspace(batch, False)`'s size instead of the net's own -- forwards in flight on two streams at once need
+        one each (layer activations live there whenever the shape has no fused kernel)."""
         self._check_feat(feat)
         b = feat.shape[0]
-        ws = self.workspace(b, False)
+        ws = self.workspace(b, False) if workspace is None else workspace
         if out is not None:
             logits, probs = out
         else:

@@ -523,3 +523,38 @@ def test_multi_stream_backward_repeats_bitwise(hip_lib, family):
             ref = (lg.clone(), g)
         else:
             assert torch.equal(lg, ref[0]) and torch.equal(g, ref[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,depth", [("handoff", 2), ("handoff", 3), ("alternate", 2)])
+@pytest.mark.parametrize("width,batch", [(1.0, 2048), (1.5, 96)])
+def test_inference_pipeline_equals_sequential(hip_lib, mode, depth, width, batch):
+    """The two-stream inference pipelines (tcresnet_amd.pipeline.InferencePipeline: front-end stream -> network stream, or whole batches
+    alternating between the streams) return, for a sequence of DIFFERENT batches, bitwise what front-end -> network gives on one stream;
+    width 1.5 at a small batch takes the per-layer eval path, whose activations live in the workspace (one per stream when alternating)."""
+    from tcresnet_amd.pipeline import InferencePipeline
+    fe = T.Frontend(window_size_samples=640, window_stride_samples=320, device="cuda")
+    net = T.TCResNet("TCResNet8", R.tcresnet_channels("TCResNet8", width), 40, fe.n_frames, 12, device="cuda")
+    net.init_xavier(7)
+    base = torch.from_numpy(R.synth_waveforms(64, seed=21)).cuda()
+    wavs = [(base.roll(k, 0) * (1.0 - 0.05 * k)).repeat((batch + 63) // 64, 1)[:batch].contiguous() for k in range(7)]
+    want = [net.forward_infer(fe(w))[0].clone() for w in wavs]
+    assert not torch.equal(want[0], want[1])
+    pipe = InferencePipeline(fe, net, batch, depth=depth, mode=mode)
+    got = []
+    for k, w in enumerate(wavs):
+        out = pipe.submit(w)
+        pipe.done_event(k % pipe.depth).synchronize()
+        got.append(out[0].clone())
+    pipe.sync()
+    for g, r in zip(got, want):
+        assert torch.equal(g, r)
+    # back to back, no host synchronisation between submits: the last `depth` results are still in their slots
+    for rep in range(3):
+        for w in wavs:
+            pipe.submit(w)
+    pipe.sync()
+    torch.cuda.synchronize()
+    n = len(wavs) * 3
+    for k in range(n - pipe.depth, n):
+        assert torch.equal(pipe.out[(7 + k) % pipe.depth][0], want[k % 7])
