@@ -10,6 +10,8 @@ from bench import synth_batch
 
 dev = torch.device("cuda")
 lib = T._lib.get()
+KNOB = int(os.environ.get("KNOB", "17"))                                  # 17: TCR_TUNE_DOWN_DGRAD (2 early for every net / 1 behind conv_a); 7: TCR_TUNE_WGRAD_STREAM (0 / 2: shortcut units on the second internal stream)
+KNOBS = [int(v) for v in os.environ.get("VALUES", "2,1").split(",")]
 B = 4096
 wav = synth_batch(B, dev, 1234)
 lab = torch.zeros((B, 12), device=dev); lab[torch.arange(B), torch.arange(B) % 12] = 1
@@ -36,7 +38,7 @@ for stride, tag in ((320, "49 frames"), (160, "98 frames")):
         def train():
             net.forward_train(feat, lab, keep_prob=0.5, seed=1); net.backward(); net.sgd_momentum_step(0.1, 0.9, 0.001)
         for rnd in range(3):
-            for knob in (2, 1):
-                lib.tcr_tune(17, knob)
+            for knob in KNOBS:
+                lib.tcr_tune(KNOB, knob)
                 print(f"  {name} {tag} knob {knob}: {timeit(train):9.1f} us", flush=True)
-        lib.tcr_tune(17, 0)
+        lib.tcr_tune(KNOB, 0)

@@ -1094,7 +1094,8 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
         // (not this call)
     } else if (conv_wgrad_deferrable(l.k, l.cin, l.cout)) {     // slabs summed for all layers at once at the end of backward
         hipStream_t ws = u.li == 0 ? c.s : c.side;      // (the first conv's: the step's last, on the main stream -- see reduce_slabs)
-        if (ws != c.s && bn_stream != c.side) {         // fork: the side stream waits for dy, the main stream carries on
+        if (bn_stream != c.s) ws = bn_stream;           // dy was written off the main stream (a shortcut unit): its filter gradient follows it there
+        else if (ws != c.s) {                           // fork: the side stream waits for dy, the main stream carries on
             if (hipEventRecord(c.net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(c.side, c.net->ev_fork, 0) != hipSuccess) {
                 set_error("tcr_net_backward: stream fork failed");
                 return TCR_ERR_HIP;
@@ -1318,6 +1319,10 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     const int nu = (int)order.size();
     TCR_REQUIRE(plan || (stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end), "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);
     const float* dpool = c.base + c.w.dpool;
+    // where a block's shortcut unit runs (BN backward, data gradient, filter gradient): behind the other units' filter gradients on the
+    // side stream, or on the second internal stream (TCR_TUNE_WGRAD_STREAM = 2), where it never queues behind a 50 us filter gradient
+    const bool down_on_second = c.side != c.s && tune_get(TCR_TUNE_WGRAD_STREAM) == 2;
+    const hipStream_t down_stream = down_on_second ? net->side2 : c.side;
     const bool bwd_phases = !plan && bwd_phases_usable(c, dpool);
     // Every layer's split-K slabs -> dW.  The side stream is the longer one at the end of a step (it still holds block 0's filter
     // gradients when the main chain has finished), so the FIRST conv's filter gradient runs on the main stream (bwd_unit_post) and the
@@ -1338,6 +1343,11 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
             return rm.n ? launch_wgrad_reduce_multi(rm, st) : TCR_OK;
         };
         if (!split) return run(2, c.s);
+        if (down_stream != c.side &&                    // the shortcut units' slabs were written on the second internal stream
+            (hipEventRecord(net->ev_join2, down_stream) != hipSuccess || hipStreamWaitEvent(c.side, net->ev_join2, 0) != hipSuccess)) {
+            set_error("tcr_net_backward: stream join failed");
+            return TCR_ERR_HIP;
+        }
         TCR_TRY(run(0, c.side));
         TCR_TRY(run(1, c.s));
         if (hipEventRecord(net->ev_join, c.side) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join, 0) != hipSuccess ||
@@ -1365,7 +1375,7 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
             hp.dpool = c.base + c.w.dpool; hp.batch = batch; hp.c = net->feat_c; hp.nc = nc; hp.zero = grads; hp.zero_n = net->param_floats;
             TCR_TRY(launch_bwd_prologue(hp, dm, c.s));
             // the classifier's own filter gradient feeds nothing below: on a stream of its own (behind the arena's zero fill)
-            hipStream_t fs = c.side != c.s ? net->side2 : c.s;
+            hipStream_t fs = c.side != c.s ? (down_on_second ? c.side : net->side2) : c.s;
             if (fs != c.s && (hipEventRecord(net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(fs, net->ev_fork, 0) != hipSuccess)) {
                 set_error("tcr_net_backward: stream fork failed");
                 return TCR_ERR_HIP;
@@ -1441,19 +1451,19 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
             const int li = order[st];
             const int dn = early ? down_of_block_starting_at(li) : -1;
             if (dn >= 0) {
-                if (hipEventRecord(net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(c.side, net->ev_fork, 0) != hipSuccess) {
+                if (hipEventRecord(net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(down_stream, net->ev_fork, 0) != hipSuccess) {
                     set_error("tcr_net_backward: stream fork failed");
                     return TCR_ERR_HIP;
                 }
                 const BwdUnit ud = bwd_unit_of(c, dn, dpool);
-                TCR_TRY(bwd_unit_pre(c, ud, c.side, c.base + c.w.partial2));
-                TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_BN, c.side, c.base + c.w.partial2, c.base + c.w.kcoef2));
-                if (hipEventRecord(net->ev_down, c.side) != hipSuccess) { set_error("tcr_net_backward: event record failed"); return TCR_ERR_HIP; }
+                TCR_TRY(bwd_unit_pre(c, ud, down_stream, c.base + c.w.partial2));
+                TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_BN, down_stream, c.base + c.w.partial2, c.base + c.w.kcoef2));
+                if (hipEventRecord(net->ev_down, down_stream) != hipSuccess) { set_error("tcr_net_backward: event record failed"); return TCR_ERR_HIP; }
                 if (down_first_of(dn)) {
-                    TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_DGRAD, c.side, c.base + c.w.partial2, c.base + c.w.kcoef2, c.side));
-                    if (hipEventRecord(net->ev_down_dg, c.side) != hipSuccess) { set_error("tcr_net_backward: event record failed"); return TCR_ERR_HIP; }
+                    TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_DGRAD, down_stream, c.base + c.w.partial2, c.base + c.w.kcoef2, down_stream));
+                    if (hipEventRecord(net->ev_down_dg, down_stream) != hipSuccess) { set_error("tcr_net_backward: event record failed"); return TCR_ERR_HIP; }
                 }
-                TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_WGRAD, c.side, c.base + c.w.partial2, c.base + c.w.kcoef2));
+                TCR_TRY(bwd_unit_post(c, ud, grads, dpool, BWD_WGRAD, down_stream, c.base + c.w.partial2, c.base + c.w.kcoef2));
             }
             if (!(early && is_down(li))) TCR_TRY(bwd_unit_pre(c, bwd_unit_of(c, li, dpool), c.s, partial));
         }

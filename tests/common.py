@@ -511,14 +511,16 @@ def check_down_dgrad_order(lib, name, width, batch, seed=4, t=25):
     ch = R.tcresnet_channels(name, float(width))
     grads = []
     try:
-        for knob in (2, 1, 0):          # 2: early for every width (0: only nets of <= 48 channels)
+        for knob, streams in ((2, 0), (1, 0), (0, 0), (2, 2)):     # 2: early for every width (0: only nets of <= 48 channels); streams 2: shortcut units on the second internal stream
             lib.tcr_tune(17, knob)
+            lib.tcr_tune(7, streams)
             net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)
             net.init_xavier(1)
             net.forward_train(feat, labels, keep_prob=0.5, seed=9)
             grads.append(net.backward().clone())
     finally:
         lib.tcr_tune(17, 0)
+        lib.tcr_tune(7, 0)
     for g in grads[1:]:
         assert torch.equal(grads[0], g), float((grads[0] - g).abs().max())
     assert float(grads[0].abs().max()) > 0
