@@ -95,7 +95,7 @@ def grads(arch, params_np: Dict[str, np.ndarray], stats_np, x_np, labels_np, wei
     tot, model = total_loss(out["logits"], torch.tensor(labels_np, dtype=dtype), params, weight_decay)
     tot.backward()
     g = {k: (v.grad.detach().numpy() if v.grad is not None else np.zeros_like(params_np[k])) for k, v in params.items()}
-    return g, float(tot), float(model), {k: v.detach().numpy() for k, v in out["new_stats"].items()}
+    return g, float(tot.detach()), float(model.detach()), {k: v.detach().numpy() for k, v in out["new_stats"].items()}
 
 
 class CpuBaseline:

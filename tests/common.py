@@ -498,7 +498,7 @@ def check_bn_backward_fused_equals_pair(lib, name, width, batch, seed=3, combos=
         assert torch.equal(grads[0], g), float((grads[0] - g).abs().max())
 
 
-def check_down_dgrad_order(lib, name, width, batch, seed=4, t=25):
+def check_down_dgrad_order(lib, name, width, batch, seed=4, t=25, variants=((2, 0), (1, 0), (0, 0), (2, 2))):
     """A block's shortcut conv writing the block-input gradient first (early, on the side stream; conv_a's data gradient adds onto
     it -- the default) is BITWISE conv_a first and the shortcut added behind it (TCR_TUNE_DOWN_DGRAD = 1): one addition, commuted."""
     import tcresnet_amd as T
@@ -511,7 +511,7 @@ def check_down_dgrad_order(lib, name, width, batch, seed=4, t=25):
     ch = R.tcresnet_channels(name, float(width))
     grads = []
     try:
-        for knob, streams in ((2, 0), (1, 0), (0, 0), (2, 2)):     # 2: early for every width (0: only nets of <= 48 channels); streams 2: shortcut units on the second internal stream
+        for knob, streams in variants:     # 2: early for every width (0: only nets of <= 48 channels); streams 2: shortcut units on the second internal stream
             lib.tcr_tune(17, knob)
             lib.tcr_tune(7, streams)
             net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)

@@ -9,6 +9,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`) spends its time in the wave-64 emulator, one test at a time: ~14 min serially, ~2.5 min over
+    the host's cores.  When pytest-xdist is importable and the caller chose no `-n` itself, run that suite on min(8, cores) workers
+    (`-n 0` or TCR_TEST_SERIAL=1 keeps it serial).  GPU runs (`-m gpu`) stay in one process: one device, one set of streams."""
+    if hasattr(config, "workerinput") or os.environ.get("TCR_TEST_SERIAL") == "1":
+        return None
+    opt = config.option
+    if getattr(opt, "markexpr", "") .replace(" ", "") != "notgpu" or not hasattr(opt, "numprocesses") or opt.numprocesses is not None:
+        return None
+    if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+        return None
+    workers = min(8, os.cpu_count() or 1)
+    if workers > 1:
+        opt.numprocesses = workers
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` through gpurun)")
 

@@ -1,10 +1,14 @@
 #!/bin/sh
 # TEST INFRASTRUCTURE: host (clang++) build of the kernel sources against tests/emu/hip/hip_runtime.h
+# (one object per source, compiled in parallel, then linked)
 set -e
 cd "$(dirname "$0")/../.."
-mkdir -p tests/emu/_build
+OUT=tests/emu/_build
+mkdir -p $OUT/obj
 SRC="tc-resnet_amd/csrc"
-/opt/rocm/lib/llvm/bin/clang++ -std=c++17 -O1 -g -fPIC -shared -x c++ -I tests/emu -Wall -Wno-unused-function -Wno-unused-variable \
-  -Wno-unknown-attributes -Wno-unknown-pragmas -Wno-pass-failed \
-  $SRC/tcr_common.cpp $SRC/frontend_plan.cpp $SRC/frontend.hip $SRC/frontend_pk.hip $SRC/conv.hip $SRC/mfma.hip $SRC/bn.hip $SRC/head.hip $SRC/optim.hip $SRC/net.cpp $SRC/dscnn.hip $SRC/dscnn_bwd.hip $SRC/fused.hip $SRC/train_fused.hip $SRC/train_fused_bwd.hip $SRC/augment.hip $SRC/net2d_kernels.hip $SRC/net2d.cpp \
-  -o tests/emu/_build/libtcr_emu.so
+FILES="tcr_common.cpp frontend_plan.cpp frontend.hip frontend_pk.hip conv.hip mfma.hip bn.hip head.hip optim.hip net.cpp dscnn.hip dscnn_bwd.hip fused.hip train_fused.hip train_fused_bwd.hip augment.hip net2d_kernels.hip net2d.cpp"
+FLAGS="-std=c++17 -O2 -fPIC -x c++ -I tests/emu -Wall -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-unknown-pragmas -Wno-pass-failed"
+printf '%s\n' $FILES | xargs -P "$(nproc 2>/dev/null || echo 4)" -I{} /opt/rocm/lib/llvm/bin/clang++ $FLAGS -c $SRC/{} -o $OUT/obj/{}.o
+OBJS=""
+for f in $FILES; do OBJS="$OBJS $OUT/obj/$f.o"; done
+/opt/rocm/lib/llvm/bin/clang++ -shared -fPIC $OBJS -o $OUT/libtcr_emu.so

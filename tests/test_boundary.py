@@ -15,7 +15,7 @@ from tests import common as Cm
 
 REF_TRAIN_CMD = ("--dataset_path synthetic --dataset_split_name train --output_name output/softmax --num_classes 12 "
                  "--train_dir {d} --num_silent 1854 --augmentation_method anchored_slice_or_pad_with_shift --preprocess_method mfcc "
-                 "--num_mfccs 40 --clip_duration_ms 1000 --window_size_ms 40 --window_stride_ms 20 --batch_size 6 --boundaries 2 4 "
+                 "--num_mfccs 40 --clip_duration_ms 1000 --window_size_ms 40 --window_stride_ms 20 --batch_size 3 --boundaries 2 4 "
                  "--max_step_from_restore 3 --lr_list 0.1 0.01 0.001 --absolute_schedule --no-boundaries_epoch --max_to_keep 20 "
                  "--step_save_checkpoint 500 --step_evaluation 500 --optimizer mom --momentum 0.9 --step_save_summaries 1 "
                  "TCResNet8Model --weight_decay 0.001 --width_multiplier 1.0")
@@ -67,7 +67,7 @@ def test_reference_command_lines_train_then_evaluate(rt, tmp_path):
     model = trainer.model
     assert (args.height, args.width, args.channels) == (49, 40, 1)          # args mutated like the reference (:83)
     # show_models counts every variable of the graph (65 264 trainable + 656 moving statistics)
-    assert model.total_params == 65920 and model.engine.total_params() == 65264 and tuple(model.audio.shape) == (6, 49, 40, 1)
+    assert model.total_params == 65920 and model.engine.total_params() == 65264 and tuple(model.audio.shape) == (3, 49, 40, 1)
     assert np.isfinite(float(model.total_loss)) and float(model.total_loss) > float(model.model_loss)
     # TF-format checkpoint: <train_dir>/<ModelName>-<global_step>.{index,data-00000-of-00001} + the `checkpoint` state file
     assert sorted(p.name for p in tmp_path.iterdir()) == ["TCResNet8Model-3.data-00000-of-00001", "TCResNet8Model-3.index", "checkpoint"]
@@ -178,10 +178,10 @@ def test_trainer_flags_are_honoured_or_refused(rt, tmp_path):
     # rmsprop with its constructor overrides, in-training evaluation on the training graph every step, epoch stop rule
     cmd = (REF_TRAIN_CMD.replace("--optimizer mom --momentum 0.9", "--optimizer rmsprop --optimizer_decay 0.8 --optimizer_epsilon 0.001 --momentum 0.5")
            .replace("--step_evaluation 500", "--step_evaluation 1 --evaluation_iterations 2").replace("--lr_list 0.1 0.01 0.001", "--lr_list 0.001 0.001 0.001")
-           .replace("--max_step_from_restore 3", "--max_step_from_restore 50 --max_epoch_from_restore 0.0005"))
+           .replace("--max_step_from_restore 3", "--max_step_from_restore 50 --max_epoch_from_restore 0.00025"))
     tr = train_audio.train(train_audio.parse_arguments(cmd.format(d=tmp_path / "r").split()))
-    assert tr.global_step == 2                       # 2 steps x 6 utterances / 22246 samples = 0.00054 epochs >= 0.0005
-    assert tr.last_eval["num_evaluated"] == 12 and "accuracy/train" in tr.last_eval and "metric_loss/train/total_loss" in tr.last_eval
+    assert tr.global_step == 2                       # 2 steps x 3 utterances / 22246 samples = 0.00027 epochs >= 0.00025
+    assert tr.last_eval["num_evaluated"] == 6 and "accuracy/train" in tr.last_eval and "metric_loss/train/total_loss" in tr.last_eval
     assert set(tr.model.engine.slots) >= {"RMSProp", "RMSProp_1"}
     tc_resnet.reset_engines()
     with pytest.raises(TypeError):                  # tf.train.AdamOptimizer(momentum=...) is a constructor error in the reference too
@@ -401,7 +401,7 @@ def test_wav_directory_dataset_train_and_evaluate(rt, tmp_path):
     peek = ds.get_input_and_output_op()             # building the graph does not consume the dataset
     wavs, labels = ds.next_batch()
     assert torch.equal(peek[0], wavs) and torch.equal(peek[1], labels)
-    assert tuple(wavs.shape) == (6, 16000, 1) and tuple(labels.shape) == (6, 12) and float(wavs.abs().max()) <= 1.0
+    assert tuple(wavs.shape) == (3, 16000, 1) and tuple(labels.shape) == (3, 12) and float(wavs.abs().max()) <= 1.0
     assert torch.all(labels.sum(1) == 1)
     # data-parallel shards: one global order, different augmentation draws per rank
     ds.setup_iterator()
