@@ -38,11 +38,18 @@ def emu_lib():
     so = os.path.join(ROOT, "tests", "emu", "_build", "libtcr_emu.so")
     srcs = [os.path.join(ROOT, "tc-resnet_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "tc-resnet_amd", "csrc"))]
     srcs += [os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "tcresnet_hip.h")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-        clang = "/opt/rocm/lib/llvm/bin/clang++"
-        if not os.path.exists(clang):
-            pytest.skip("clang++ for the emulator build is not available")
-        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    import fcntl
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    with open(os.path.join(os.path.dirname(so), ".lock"), "w") as lock:      # xdist workers: one of them builds, the others wait
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+                clang = "/opt/rocm/lib/llvm/bin/clang++"
+                if not os.path.exists(clang):
+                    pytest.skip("clang++ for the emulator build is not available")
+                subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return T._lib.load_from(so, "emu")
 
 
