@@ -66,7 +66,9 @@ static void choose_streams(hipStream_t caller, hipStream_t (&out)[kSharedStreams
     for (; nc < kCand; ++nc)
         if (hipStreamCreateWithFlags(&cand[nc], hipStreamNonBlocking) != hipSuccess) break;
     hipEvent_t ea = nullptr, eb = nullptr;
-    const bool probe = hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess;
+    bool probe = hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;       // a caller's stream under graph capture must not be synchronised: no probing then
+    if (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) probe = false;
     auto pick = [&](std::initializer_list<hipStream_t> apart) -> hipStream_t {
         for (int pass = 0; pass < 2; ++pass)                    // pass 1: nothing qualified (or no probing possible) -- the first unused candidate
             for (int i = 0; i < nc; ++i) {
