@@ -53,8 +53,11 @@ class InferencePipeline:
         self.feat = [torch.empty((batch, frontend.n_coef, padded_len(frontend.n_frames)), device=dev) for _ in range(depth)]
         self.out = [(torch.empty((batch, net.num_classes), device=dev), torch.empty((batch, net.num_classes), device=dev))
                     for _ in range(depth)]
-        self.net.workspace(batch, False)                 # allocate before the streams start
-        self._ws = [net.new_workspace(batch, False) for _ in range(2)] if mode == "alternate" else None
+        if mode == "alternate":
+            self._ws = [net.new_workspace(batch, False) for _ in range(2)]      # one per stream
+        else:
+            self._ws = None
+            self.net.workspace(batch, False)             # allocate before the streams start
         self._fe_done: List[torch.cuda.Event] = [torch.cuda.Event() for _ in range(depth)]
         self._net_done: List[torch.cuda.Event] = [torch.cuda.Event() for _ in range(depth)]
         self._k = 0
