@@ -44,24 +44,49 @@ def synth_batch(batch: int, device, seed: int, start: int = 0) -> torch.Tensor:
     return (noise + 0.25 * torch.sin(2.0 * torch.pi * f[:, None] * t[None, :])).contiguous()
 
 
+# TCR_BENCH_EMU=<tests/emu/_build/libtcr_emu.so>: a CPU REHEARSAL of this file's control flow (rank launch, process group, barriers,
+# collectives, the JSON line) on the host-emulator build of the kernel sources -- test infrastructure (tests/test_distributed.py), never
+# a measurement: the line it prints says so ("rehearsal").  Without it the gfx950 library and a GPU are required.
+EMU = os.environ.get("TCR_BENCH_EMU") or None
+LEGS = ("latency", "train", "train14", "forward_3010", "dscnn_forward", "dscnn_train", "train_3010", "augment", "pipelined")
+
+
+def sync():
+    if EMU is None:
+        torch.cuda.synchronize()
+
+
+class _HostEvent:
+    """stand-in for torch.cuda.Event in the CPU rehearsal (the emulator runs launches synchronously)"""
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def new_event():
+    return _HostEvent() if EMU else torch.cuda.Event(enable_timing=True)
+
+
 def timed(fn, steps: int, warmup: int, dist_on: bool):
     import torch.distributed as dist
     for _ in range(warmup):
         fn()
-    torch.cuda.synchronize()
+    sync()
     if dist_on:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
-    torch.cuda.synchronize()
+    sync()
     if dist_on:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if EMU else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     return dt
@@ -76,8 +101,20 @@ def main():
                     "launches on an idle GPU run ~15 %% slower while the clocks ramp, whatever --warmup says (reported as pre_warm_launches)")
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU per step (BASELINE config: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the train / 3010 legs (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the train / 3010 legs (profiling runs); same as --legs none")
+    ap.add_argument("--legs", default="all", help="secondary legs to run next to the headline: 'all', 'none' or a comma list of " + ", ".join(LEGS))
     args = ap.parse_args()
+    if args.no_extras or args.legs == "none":
+        legs = set()
+    elif args.legs == "all":
+        legs = set(LEGS)
+    else:
+        legs = set(x for x in args.legs.split(",") if x)
+        if legs - set(LEGS):
+            ap.error(f"--legs: unknown {sorted(legs - set(LEGS))}; known: {', '.join(LEGS)}")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))          # plain `python bench.py --gpus N`: become the launcher of N ranks
 
     import torch.distributed as dist
     import tcresnet_amd as T
@@ -87,19 +124,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
-    local_rank %= max(torch.cuda.device_count(), 1)       # (lets a 1-GPU box rehearse the N > 1 control flow over gloo)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or unset WORLD_SIZE and let bench.py launch its ranks)")
     dist_on = world > 1
-    if dist_on:
-        backend = os.environ.get("TCR_BENCH_BACKEND", "nccl")    # "nccl" == RCCL over xGMI; "gloo" only for rehearsals
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    if EMU:
+        lib = T._lib.load_from(EMU, "emu")
+        dev = torch.device("cpu")
+        if dist_on:
+            dist.init_process_group("gloo")
+    else:
+        lib = None                                            # the gfx950 library (T._lib.get() raises when it is missing)
+        assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+        if world > torch.cuda.device_count() and os.environ.get("TCR_BENCH_BACKEND", "nccl") == "nccl":
+            raise SystemExit(f"--gpus {world} needs {world} visible GPUs for RCCL (one rank per GPU); {torch.cuda.device_count()} visible. "
+                             "TCR_BENCH_BACKEND=gloo rehearses the control flow with the ranks time-sharing the visible devices.")
+        local_rank %= max(torch.cuda.device_count(), 1)       # (lets a 1-GPU box rehearse the N > 1 control flow over gloo)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if dist_on:
+            backend = os.environ.get("TCR_BENCH_BACKEND", "nccl")    # "nccl" == RCCL over xGMI; "gloo" only for rehearsals
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
 
     B = args.batch
     # what the collective of the training legs actually is: dist.get_backend() ("nccl" on ROCm is RCCL over xGMI)
@@ -107,8 +153,8 @@ def main():
 
     def build(tag):
         w = WORK[tag]
-        fe = T.Frontend(window_size_samples=w["win"], window_stride_samples=w["hop"], device=dev)
-        net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, fe.n_frames, 12, device=dev)
+        fe = T.Frontend(window_size_samples=w["win"], window_stride_samples=w["hop"], lib=lib, device=dev)
+        net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, fe.n_frames, 12, lib=lib, device=dev)
         net.init_xavier(0)
         return fe, net
 
@@ -129,7 +175,7 @@ def main():
     # scripts/ab_graph_fwd.py), so they are sampled: still live, inside the timed region, on the stream of the launches.
     nev = args.steps + args.warmup
     EV_EVERY = 8
-    ev = {i: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for i in range(args.warmup, nev) if (i - args.warmup) % EV_EVERY == 2 or (args.steps <= 2 and i == args.warmup)}       # timed steps 2, 10, 18, ...
+    ev = {i: [new_event() for _ in range(3)] for i in range(args.warmup, nev) if (i - args.warmup) % EV_EVERY == 2 or (args.steps <= 2 and i == args.warmup)}       # timed steps 2, 10, 18, ...
     counter = [0]
 
     def fwd_step():
@@ -150,7 +196,7 @@ def main():
     for _ in range(max(0, args.prewarm)):
         fe(wav, out=feat)
         net.forward_infer(feat, out=outbuf)
-    torch.cuda.synchronize()
+    sync()
     dt = timed(fwd_step, args.steps, args.warmup, dist_on)
     value = world * B * args.steps / dt
     timed_ev = [ev[i] for i in range(args.warmup, args.warmup + args.steps) if i in ev]
@@ -184,6 +230,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"TCResNet8-1.0 eval forward, waveform->softmax, batch {B}/GPU, 49x40 MFCC (40/20 ms, FFT 1024), 12 classes",
                    "global_batch": world * B, "parallelism": f"dp{world} (utterance shards, no collective)", "collective_backend": dist.get_backend() if dist_on else None},
+        "collective_backend": coll, "collectives_per_step": {"forward": 0},       # (eval forward: replicas only; the training legs add theirs below)
         "roofline": roof,
         "phases_ms": {"frontend": round(fe_ms, 4), "net": round(net_ms, 4)},
         "step_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "event_timed_steps": len(timed_ev),
@@ -192,103 +239,104 @@ def main():
         "whole_path_hbm_frac": round(value / world * 64048 / 1e9 / HBM_PEAK_GBS, 4),
     }
 
-    if not args.no_extras:
-        # ---------------- batch-1 latency (configs[0]'s regime; the CPU baseline's batch-1 number sits in cpu_baseline.forward_by_batch) ----
-        w1 = wav[:1].contiguous()
-        o1 = (torch.empty((1, 12), device=dev), torch.empty((1, 12), device=dev))
-        for _ in range(50):
-            net.forward_waveform(fe, w1, out=o1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(200):
-            net.forward_waveform(fe, w1, out=o1)
-            torch.cuda.synchronize()
-        out["latency_batch_1"] = {"value": round((time.perf_counter() - t0) / 200 * 1e6, 1), "unit": "us", "higher_is_better": False,
-                                  "workload": "one utterance, waveform -> softmax, host call (tcr_forward_waveform) + device synchronisation per "
-                                              "utterance; the two kernels' own serial latency dominates (persistent front-end set-up + one network group)"}
-        # ---------------- training step (configs[2]) ----------------
-        # Every step computes the MFCC of its own batch; like the reference's tf.data prefetch, the front-end of step k+1 is
-        # issued on a second stream while step k's forward/backward/update occupy the main stream (FeaturePrefetcher).
-        from tcresnet_amd.pipeline import FeaturePrefetcher
-        from tcresnet_amd.parallel import ranks_share_gpu
-        overlap = not ranks_share_gpu()
-        dp = DataParallel(net)
-        step_no = [0]
-        pf = FeaturePrefetcher(fe, B, overlap=overlap)
+    if EMU:
+        out["rehearsal"] = "CPU emulator build of the kernel sources (TCR_BENCH_EMU): control flow only, NOT a measurement"
+        out["data"] = "synthetic (CPU rehearsal)"
+
+    from tcresnet_amd.pipeline import FeaturePrefetcher
+    from tcresnet_amd.parallel import ranks_share_gpu
+    overlap = EMU is None and not ranks_share_gpu()
+    step_no = [0]
+    # every secondary leg: >= 20 timed steps after >= 10 warm-up steps whatever the command line says (the driver's
+    # --steps 20 --warmup 5 used to leave the DS-CNN leg 6 steps after 2: a bimodal 4.3 / 8.8 ms); the CPU rehearsal keeps the flags
+    floor = (lambda lo, v: v) if EMU else (lambda lo, v: max(lo, v))
+    tsteps, twarm = floor(20, args.steps // 2), floor(10, args.warmup // 2)
+
+    def train_leg(fe_, net_, steps, warm):
+        """One training leg: every step computes the MFCC of its own batch; like the reference's tf.data prefetch, the front-end of step
+        k+1 is issued on a second stream while step k's forward/backward/update occupy the main stream (FeaturePrefetcher)."""
+        dp = DataParallel(net_)
+        pf = FeaturePrefetcher(fe_, B, overlap=overlap)
         pf.submit(wav)
+        early = FeaturePrefetcher.submit_point(net_) == "before_forward"      # (measured per net family: pipeline.py)
 
-        early = FeaturePrefetcher.submit_point(net) == "before_forward"      # (measured per net family: pipeline.py)
-
-        def train_step():
+        def step():
             step_no[0] += 1
             f = pf.get()
             if early: pf.submit(wav)
             dp.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
             if not early: pf.submit(wav)
             dp.backward()
-            net.sgd_momentum_step(0.1, 0.9, 0.001)
+            net_.sgd_momentum_step(0.1, 0.9, 0.001)
 
-        # every secondary leg: >= 20 timed steps after >= 10 warm-up steps whatever the command line says (the driver's
-        # --steps 20 --warmup 5 used to leave the DS-CNN leg 6 steps after 2: a bimodal 4.3 / 8.8 ms)
-        tsteps, twarm = max(20, args.steps // 2), max(10, args.warmup // 2)
         c0 = dp.collectives
-        tdt = timed(train_step, tsteps, twarm, dist_on)
-        out["train"] = {"value": round(world * B * tsteps / tdt, 1), "unit": "utterances/s", "ms_per_step": round(tdt / tsteps * 1e3, 4),
-                        "steps": tsteps, "collectives_per_step": round((dp.collectives - c0) / (tsteps + twarm), 2), "workload": "TCResNet8-1.0 train step: MFCC (prefetched on a second stream) + train-mode BN fwd + bwd + momentum (wd 1e-3, keep_prob 0.5), "
-                                                     f"batch {B}/GPU" + (f", {coll} all-reduce of the flat gradient arena" if dist_on else "")}
+        dt_ = timed(step, steps, warm, dist_on)
+        return {"value": round(world * B * steps / dt_, 1), "unit": "utterances/s", "ms_per_step": round(dt_ / steps * 1e3, 4), "steps": steps,
+                "collectives_per_step": round((dp.collectives - c0) / (steps + warm), 2)}
+
+    if "latency" in legs:
+        # ---------------- batch-1 latency (configs[0]'s regime; the CPU baseline's batch-1 number sits in cpu_baseline.forward_by_batch) ----
+        w1 = wav[:1].contiguous()
+        o1 = (torch.empty((1, 12), device=dev), torch.empty((1, 12), device=dev))
+        for _ in range(50):
+            net.forward_waveform(fe, w1, out=o1)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            net.forward_waveform(fe, w1, out=o1)
+            sync()
+        out["latency_batch_1"] = {"value": round((time.perf_counter() - t0) / 200 * 1e6, 1), "unit": "us", "higher_is_better": False,
+                                  "workload": "one utterance, waveform -> softmax, host call (tcr_forward_waveform) + device synchronisation per "
+                                              "utterance; the two kernels' own serial latency dominates (persistent front-end set-up + one network group)"}
+    if "train" in legs:
+        # ---------------- training step (configs[2]) ----------------
+        out["train"] = train_leg(fe, net, tsteps, twarm)
+        out["train"]["workload"] = ("TCResNet8-1.0 train step: MFCC (prefetched on a second stream) + train-mode BN fwd + bwd + momentum (wd 1e-3, keep_prob 0.5), "
+                                    f"batch {B}/GPU" + (f", {coll} all-reduce of the flat gradient arena" if dist_on else ""))
+        out["collectives_per_step"]["train"] = out["train"]["collectives_per_step"]
+    if "train14" in legs:
         # ---------------- TCResNet14-1.5 training (configs[3]: global batch 32768 = 8 x 4096 over RCCL) ----------------
-        net14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, fe.n_frames, 12, device=dev)
+        net14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, fe.n_frames, 12, lib=lib, device=dev)
         net14.init_xavier(0)
-        dp14 = DataParallel(net14)
-
-        early14 = FeaturePrefetcher.submit_point(net14) == "before_forward"
-
-        def train14_step():
-            step_no[0] += 1
-            f = pf.get()
-            if early14: pf.submit(wav)
-            dp14.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
-            if not early14: pf.submit(wav)
-            dp14.backward()
-            net14.sgd_momentum_step(0.1, 0.9, 0.001)
-
-        t14 = max(20, args.steps // 4)
-        c0 = dp14.collectives
-        dt14 = timed(train14_step, t14, 10, dist_on)
-        out["train_tcresnet14_1.5"] = {"value": round(world * B * t14 / dt14, 1), "unit": "utterances/s", "ms_per_step": round(dt14 / t14 * 1e3, 4),
-                                       "steps": t14, "collectives_per_step": round((dp14.collectives - c0) / (t14 + 10), 2), "workload": f"TCResNet14-1.5 train step, batch 4096/GPU (global {world * B}), 303 144 params"
-                                                                 + (f", {coll} all-reduce of the 1.21 MB gradient arena" if dist_on else "")}
-        del net14, dp14
-        # ---------------- 30/10 ms front-end (98x40, the reference's training scripts) ----------------
+        out["train_tcresnet14_1.5"] = train_leg(fe, net14, floor(20, args.steps // 4), floor(10, args.warmup // 2))
+        out["train_tcresnet14_1.5"]["workload"] = (f"TCResNet14-1.5 train step, batch {B}/GPU (global {world * B}), 303 144 params"
+                                                   + (f", {coll} all-reduce of the 1.21 MB gradient arena" if dist_on else ""))
+        out["collectives_per_step"]["train_tcresnet14_1.5"] = out["train_tcresnet14_1.5"]["collectives_per_step"]
+        del net14
+    if legs & {"forward_3010", "train_3010"}:
         fe2, net2 = build("3010")
+    if "forward_3010" in legs:
+        # ---------------- 30/10 ms front-end (98x40, the reference's training scripts) ----------------
         feat2 = torch.empty((B, 40, fe2.n_frames + 8), device=dev)
 
         def fwd2():
             fe2(wav, out=feat2)
             net2.forward_infer(feat2)
 
-        s2 = max(50, args.steps)
-        dt2 = timed(fwd2, s2, max(20, args.warmup), dist_on)
+        s2 = floor(50, args.steps)
+        dt2 = timed(fwd2, s2, floor(20, args.warmup), dist_on)
         out["forward_3010"] = {"value": round(world * B * s2 / dt2, 1), "unit": "utterances/s", "ms_per_step": round(dt2 / s2 * 1e3, 4), "steps": s2,
                                "workload": "same, 98x40 MFCC (30/10 ms, FFT 512)"}
 
-        # ---------------- DS-CNN-L forward (configs[4]): 49x10 MFCC, batch 4096 ----------------
-        fe3 = T.Frontend(window_size_samples=640, window_stride_samples=320, num_mfccs=10, device=dev)
-        ds = T.DSCNN("L", fe3.n_frames, 10, 12, device=dev)
+    if legs & {"dscnn_forward", "dscnn_train"}:
+        fe3 = T.Frontend(window_size_samples=640, window_stride_samples=320, num_mfccs=10, lib=lib, device=dev)
+        ds = T.DSCNN("L", fe3.n_frames, 10, 12, lib=lib, device=dev)
         ds.init_xavier(0)
         feat3 = torch.empty((B, 10, fe3.n_frames + 8), device=dev)
-
+        ds_flops = 2.0 * 28327812.0          # SURVEY App. B: 28.33 M MAC / utterance
+    if "dscnn_forward" in legs:
+        # ---------------- DS-CNN-L forward (configs[4]): 49x10 MFCC, batch 4096 ----------------
         def fwd3():
             fe3(wav, out=feat3)
             ds.forward_infer(feat3)
 
-        dsteps = max(30, args.steps // 3)
-        dt3 = timed(fwd3, dsteps, max(10, args.warmup // 3), dist_on)
-        ds_flops = 2.0 * 28327812.0          # 28.33 M MAC / utterance
+        dsteps = floor(30, args.steps // 3)
+        dt3 = timed(fwd3, dsteps, floor(10, args.warmup // 3), dist_on)
         out["dscnn_l_forward"] = {"value": round(world * B * dsteps / dt3, 1), "unit": "utterances/s", "ms_per_step": round(dt3 / dsteps * 1e3, 4),
                                   "steps": dsteps, "net_tflops": round(world * B * dsteps / dt3 * ds_flops / 1e12 / world, 2),
-                                  "workload": "DSCNNLModel eval forward, waveform->softmax, 49x10 MFCC, batch 4096/GPU"}
+                                  "workload": f"DSCNNLModel eval forward, waveform->softmax, 49x10 MFCC, batch {B}/GPU"}
 
+    if "dscnn_train" in legs:
         # ---------------- DS-CNN-L training step (configs[4], training half): Adam lr 5e-4 ----------------
         dpd = DataParallel(ds)
         ds_step = [0]
@@ -300,34 +348,21 @@ def main():
             dpd.backward()
             ds.adam_step(5e-4, ds_step[0])
 
-        tds = max(20, args.steps // 6)
-        dtd = timed(train_ds, tds, 10, dist_on)
+        tds = floor(20, args.steps // 6)
+        c0 = dpd.collectives
+        dtd = timed(train_ds, tds, floor(10, args.warmup // 2), dist_on)
         out["dscnn_l_train"] = {"value": round(world * B * tds / dtd, 1), "unit": "utterances/s", "ms_per_step": round(dtd / tds * 1e3, 4),
                                 "steps": tds, "net_tflops": round(B * tds / dtd * 3.0 * ds_flops / 1e12, 2),
-                                "workload": "DSCNNLModel train step: MFCC + train-mode BN fwd + bwd + Adam, batch 4096/GPU"
+                                "workload": f"DSCNNLModel train step: MFCC + train-mode BN fwd + bwd + Adam, batch {B}/GPU"
                                             + (f", {coll} all-reduce of the gradient arena" if dist_on else "")}
+    if "train_3010" in legs:
         # ---------------- TCResNet8 training with the 30/10 ms front-end (the reference's training scripts) ----------------
-        dp2 = DataParallel(net2)
-        pf2 = FeaturePrefetcher(fe2, B, overlap=overlap)
-        pf2.submit(wav)
+        out["train_3010"] = train_leg(fe2, net2, tsteps, twarm)
+        out["train_3010"]["workload"] = f"TCResNet8-1.0 train step, 98x40 MFCC (30/10 ms), batch {B}/GPU"
 
-        early2 = FeaturePrefetcher.submit_point(net2) == "before_forward"
-
-        def train2_step():
-            step_no[0] += 1
-            f = pf2.get()
-            if early2: pf2.submit(wav)
-            dp2.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
-            if not early2: pf2.submit(wav)
-            dp2.backward()
-            net2.sgd_momentum_step(0.1, 0.9, 0.001)
-
-        tdt2 = timed(train2_step, tsteps, twarm, dist_on)
-        out["train_3010"] = {"value": round(world * B * tsteps / tdt2, 1), "unit": "utterances/s", "ms_per_step": round(tdt2 / tsteps * 1e3, 4),
-                             "steps": tsteps, "workload": "TCResNet8-1.0 train step, 98x40 MFCC (30/10 ms), batch 4096/GPU"}
-
+    if "augment" in legs:
         # ---------------- input stage: PCM16 -> shift -> background mix -> clip, batch 4096 ----------------
-        lib = T._lib.get()
+        alib = net.lib
         gen = torch.Generator(device=dev).manual_seed(7 + rank)
         pcm = torch.randint(-32768, 32768, (B * 16000,), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
         bgp = torch.randint(-32768, 32768, (6 * 60 * 16000,), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
@@ -338,20 +373,21 @@ def main():
         mixed = torch.rand((B,), generator=gen, device=dev) < 0.8
         bg_vol = (torch.rand((B,), generator=gen, device=dev) * 0.1 * mixed).contiguous()
         aug_out = torch.empty((B, 16000), device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = None if EMU else torch.cuda.current_stream(dev).cuda_stream
 
         def aug():
-            lib.check(lib.tcr_augment_fwd(pcm.data_ptr(), clip_off.data_ptr(), clip_len.data_ptr(), shift.data_ptr(), bgp.data_ptr(),
-                                          bg_off.data_ptr(), bg_vol.data_ptr(), B, 16000, aug_out.data_ptr(), stream), "tcr_augment_fwd")
+            alib.check(alib.tcr_augment_fwd(pcm.data_ptr(), clip_off.data_ptr(), clip_len.data_ptr(), shift.data_ptr(), bgp.data_ptr(),
+                                            bg_off.data_ptr(), bg_vol.data_ptr(), B, 16000, aug_out.data_ptr(), stream), "tcr_augment_fwd")
 
-        sa = max(50, args.steps)
-        dta = timed(aug, sa, max(20, args.warmup), dist_on)
+        sa = floor(50, args.steps)
+        dta = timed(aug, sa, floor(20, args.warmup), dist_on)
         aug_bytes = B * 16000 * (2 + 4) + int(mixed.sum().item()) * 16000 * 2
         out["augment"] = {"value": round(world * B * sa / dta, 1), "unit": "utterances/s", "ms_per_step": round(dta / sa * 1e3, 4), "steps": sa,
                           "hbm_gbs": round(aug_bytes / (dta / sa) / 1e9, 1), "hbm_frac": round(aug_bytes / (dta / sa) / 1e9 / HBM_PEAK_GBS, 4),
                           "algorithmic_bytes_per_launch": aug_bytes,
-                          "workload": "tcr_augment_fwd: int16 PCM -> float, +-1600-sample shift, background mix (80 % of utterances), clip; batch 4096/GPU"}
+                          "workload": f"tcr_augment_fwd: int16 PCM -> float, +-1600-sample shift, background mix (80 % of utterances), clip; batch {B}/GPU"}
 
+    if "pipelined" in legs and not EMU:
         # ---------------- the headline workload through the two-stream pipeline (tcresnet_amd.pipeline.InferencePipeline) ----------------
         # Whole batches alternate between two streams that have hardware queues of their own: batch k's front-end and network back to
         # back on one stream while batch k+1 runs on the other; every step computes its own batch (outputs bitwise the sequential
@@ -366,7 +402,7 @@ def main():
         dts = timed(seq_step, sp, max(20, args.warmup), dist_on)          # the sequential step again, at this point of the run
         dtp = timed(lambda: pipe.submit(wav), sp, max(20, args.warmup), dist_on)
         pipe.sync()
-        torch.cuda.synchronize()
+        sync()
         ref_logits = net.forward_infer(fe(wav))[0]
         out["forward_pipelined"] = {"value": round(world * B * sp / dtp, 1), "unit": "utterances/s", "ms_per_step": round(dtp / sp * 1e3, 4), "steps": sp,
                                     "sequential_ms_per_step_here": round(dts / sp * 1e3, 4),
@@ -374,12 +410,31 @@ def main():
                                     "whole_path_fp32_frac": round(B * sp / dtp * (w["mfcc_flops"] + w["net_flops"]) / 1e12 / FP32_PEAK_TFLOPS, 4),
                                     "workload": "the headline workload, whole batches alternating between two streams (front-end + network of batch k on one, batch k+1 on the other)"}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher's environment: re-run this command under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` -- one rank per GPU,
+    RCCL over xGMI (backend "nccl") --, pass the ranks' output through (rank 0 prints the ONE JSON line) and return their exit code.
+    The rendezvous is on 127.0.0.1 (the container's hostname may not resolve); HSA_ENABLE_IPC_MODE_LEGACY=0 is kept/added because
+    the host driver only supports dmabuf IPC, which RCCL's intra-node transport needs."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")             # (torch.distributed.run would set 1 and print a warning block on stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def pmc_traffic(kernel: str):

@@ -222,3 +222,39 @@ def test_train_audio_cli_two_ranks(emu_lib, tmp_path, sync_bn):
 @pytest.mark.gpu
 def test_train_audio_cli_two_ranks_hip(hip_lib, tmp_path):
     _cli_two_ranks("hip", tmp_path, True)
+
+
+def _bench_plain_command(env_extra, batch):
+    """`python bench.py --gpus 2 ...` as a PLAIN command (no launcher, WORLD_SIZE unset): bench.py launches its own two ranks under
+    torch.distributed.run, rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--batch", str(batch),
+           "--no-cpu-baseline", "--legs", "train"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]              # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2 * batch and out["value"] > 0
+    assert out["collectives_per_step"] == {"forward": 0, "train": 1.0}        # replicas only / ONE all-reduce of the gradient arena
+    assert out["train"]["value"] > 0 and out["train"]["collectives_per_step"] == 1.0
+    return out
+
+
+def test_bench_self_launches_two_ranks(emu_lib):
+    """CPU rehearsal (emulator build, gloo): the launcher, rendezvous, barriers, max-over-ranks timing and the JSON contract."""
+    out = _bench_plain_command({"TCR_BENCH_EMU": EMU}, 4)
+    assert "rehearsal" in out and out["collective_backend"].startswith("gloo")
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_two_ranks_hip(hip_lib):
+    """The same plain command on the gfx950 library: two ranks time-sharing the test box's one GPU over gloo (on an N-GPU node the
+    identical command without TCR_BENCH_BACKEND runs one rank per GPU over RCCL)."""
+    out = _bench_plain_command({"TCR_BENCH_BACKEND": "gloo"}, 256)
+    assert "rehearsal" not in out and out["collective_backend"].startswith("gloo")
