@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TCR_ABI_VERSION 1
+#define TCR_ABI_VERSION 2
 #define TCR_HALO 4
 #define TCR_MAX_BLOCKS 16
 
@@ -404,7 +404,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_CONV_KSPLIT = 6, /* train-mode conv / data-gradient: waves sharing one 32-position group's reduction (0 auto, 1, 2, 4) */
        TCR_TUNE_WGRAD_STREAM = 7,/* backward: 0 weight-gradient kernels on the library's internal streams (one set per device and process; default), 1 everything on the caller's stream, 2: as 0 with the TC-ResNet shortcut units (BN backward, data and filter gradient) on the second internal stream instead of behind the other units' filter gradients (measured: -1 % at 49 frames, +7 % for TCResNet8 at 98) */
        TCR_TUNE_TRAIN_FWD = 8,   /* train-mode forward: 0 group-resident phases (train_fused.hip; BN affine / ReLU / residual applied while the next conv stages its input, statistics from the conv epilogue), 1 per-layer kernels (conv -> statistics -> finalize -> normalise) */
-       TCR_TUNE_TRAIN_BWD = 9,   /* backward: 0 per-layer kernels (reduce -> finalize -> bn_bwd_apply -> data gradient; weight gradients and the shortcut branch on a second stream) -- the measured-faster default; 1 group-resident phases (train_fused_bwd.hip: BN backward applied while the data gradient stages dy, the next unit's sums from its epilogue) */
+       TCR_TUNE_TRAIN_BWD = 9,   /* TC-ResNet backward: 0 "lazy" BN backward (bwd_lazy.hip: dy never written -- the data-gradient kernel applies BN backward while it stages a group of utterances into LDS, runs every stride phase and the block's shortcut conv from that image and leaves the next unit's sums from its epilogue; the filter-gradient kernels compute dy where they load it; default for nets of <= 48 channels, where it measured faster; 3: for every net it covers), 1 the group-resident phases of round 2 (train_fused_bwd.hip), 2 the per-layer chain (reduce -> finalize + bn_bwd_apply -> data gradient per phase; the default until round 3) */
        TCR_TUNE_PHASE_CFG = 10,  /* training phases: waves per workgroup * 100 + utterances per group (0: default) */
        TCR_TUNE_BWD_BN_FUSED = 11, /* BN backward: 0 finalize folded into the apply pass for layers of <= 48 channels (one launch; default), 1 finalize + apply kernels, >= 2: folded everywhere, that many workgroups aimed at */
        TCR_TUNE_BWD_MASK = 12,   /* BN backward: 0 a unit's own ReLU mask recomputed from its raw conv output ([fmaf(y, scale, shift) > 0], bitwise the activation's; default), 1 read back from the stored activation, 2: as 0 with the scalar (one element per thread) elementwise BN kernels instead of the 16-byte ones (bitwise the same), 3: also the scalar per-channel reduction kernel (another summation order), 4: the 16-byte reduction kernel also where its grid would be small (tests) */
@@ -413,7 +413,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_DS_TRAIN = 15,   /* DS-CNN training: 0 normalised activations never materialised where every consumer has the form (172 / 276-channel nets): consumers apply BN + ReLU to the raw conv outputs, batch statistics and backward sums come from conv / data-gradient epilogues (default); 1 the materialising path (statistics reduce -> finalize -> normalise, backward reduce); 2: as 0, but every unit's BN backward by a bn_bwd_apply pass (default 0: conv_1's filter gradient computes dy where it reads it); 3: as 0, the depthwise units' kernels too; 4: as 0, and the pointwise units' data-gradient kernel applies the BN backward while staging and writes dy for the filter gradient instead of a bn_bwd_apply pass (measured slower) */
        TCR_TUNE_WGRAD_TILES = 16, /* 9-tap filter gradients (16-byte-load kernel): output-channel tiles per launch (0: default 3; a layer of more tiles is split into launches that share one slab) */
        TCR_TUNE_DOWN_DGRAD = 17,  /* TC-ResNet backward, a block's 1x1 shortcut conv: 0 its data gradient runs early on the side stream and writes the block-input gradient first, conv_a's adds onto it (default for nets of <= 48 channels, where it measured faster; 2: for every net); 1 conv_a's first, the shortcut's added behind it on the main stream (bitwise the same sums: one addition, commuted) */
-       TCR_TUNE_COUNT = 18 };
+       TCR_TUNE_BWD_LAZY_CFG = 18, /* lazy backward geometry: utterances per group + 100 * waves per job (0: cost model) + 10000 * (out channels * 10 + layers) to address one kernel of the net */
+       TCR_TUNE_COUNT = 19 };
 int tcr_tune(int knob, int value);
 
 /* The library's internal streams (hipStream_t), one set per device and process.  HIP multiplexes streams onto a few hardware queues

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, tcresnet_amd as T
 from bench import synth_batch
 dev = torch.device("cuda")
+for kv in filter(None, os.environ.get("TUNE", "").split(",")):     # e.g. TUNE=7=1,9=2
+    T._lib.get().tcr_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
 B = 4096
 wav = synth_batch(B, dev, 1234)
 lab = torch.zeros((B, 12), device=dev); lab[torch.arange(B), torch.arange(B) % 12] = 1

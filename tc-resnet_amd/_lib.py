@@ -13,6 +13,7 @@ from typing import Optional
 
 HALO = 4
 MAX_BLOCKS = 16
+ABI_VERSION = 2            # == TCR_ABI_VERSION of include/tcresnet_hip.h these prototypes were written against
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "lib", "libtcresnet_hip.so")
 
@@ -158,6 +159,16 @@ class Library:
         self.path = path
         self.kind = kind            # "hip" (gfx950 product build) or "emu" (tests only)
         self._dll = C.CDLL(path)
+        if not allow_missing:
+            # a stale library would otherwise fail with a bare AttributeError on the first new symbol, or silently ignore new knobs
+            ver = getattr(self._dll, "tcr_abi_version", None)
+            got = None
+            if ver is not None:
+                ver.restype, ver.argtypes = C.c_int, []
+                got = int(ver())
+            if got != ABI_VERSION:
+                raise TcrError(f"{path} reports TCR_ABI_VERSION {got}, these bindings need {ABI_VERSION}: rebuild the HIP library "
+                               "(`python tc-resnet_amd/build.py --force`, or tests/emu/build_emu.sh for the emulator build)")
         for name, (res, args) in _PROTOTYPES.items():
             if allow_missing and not hasattr(self._dll, name):      # (side libraries of OLDER revisions: scripts/build_ref_lib.py)
                 continue

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
                 if (a.m1 && !(a.m1[o] > 0.f)) dz = 0.f;
                 if (a.m2 && !(a.m2[o] > 0.f)) dz = 0.f;
                 if (self && !(fmaf(yv, ssc[c], ssh[c]) > 0.f)) dz = 0.f;
+                if (a.g_out) a.g_out[o] = dz;
                 q1[c] += dz;
                 q2[c] = fmaf(dz, (yv - mu[c]) * is[c], q2[c]);
             }
@@ -220,7 +221,7 @@ int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t 
     const int nt4 = ceil_div(ceil_div(8 * a.tp, 4), 64) * 64;
     // (its workgroups are short -- (8 Tp / 4) threads walking a few utterances -- so it needs many of them: DS-CNN-L, 276 channels:
     //  -3 % on the step; TC-ResNet's 16-48 channels leave it ~1500 waves for 256 CUs: +8 % on the TCResNet8 step -> scalar kernel there)
-    const bool vec = a.pos_per_block % a.t == 0 && nt4 <= 512 && ((int64_t)grid.x * grid.y * (nt4 / 64) >= 16 * 256 || tune_get(TCR_TUNE_BWD_MASK) == 4) && (8 * a.tp) % 4 == 0 && (a.c * a.tp) % 4 == 0 &&
+    const bool vec = !a.g_out && a.pos_per_block % a.t == 0 && nt4 <= 512 && ((int64_t)grid.x * grid.y * (nt4 / 64) >= 16 * 256 || tune_get(TCR_TUNE_BWD_MASK) == 4) && (8 * a.tp) % 4 == 0 && (a.c * a.tp) % 4 == 0 &&
                      ((a.c % 8) * a.tp) % 4 == 0 && bn_vec4_ok(a.y, (mode == 1 && !a.bcast) ? a.da : nullptr, a.m1, a.m2, a.c * a.tp, true);
     if (vec) {
         if (mode == 0) hipLaunchKernelGGL((chan_reduce4_kernel<0>), grid, dim3(nt4), 0, s, a);
@@ -463,7 +464,45 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const BnBwdFinaliz
         a.k1[c] = a.gamma ? a.gamma[c] * a.invstd[c] : a.invstd[c];
         a.k2[c] = (float)((double)db / a.count);
         a.k3[c] = (float)((double)a.invstd[c] * (double)dg / a.count);
+        if (a.tab) {
+            float* t = a.tab + (size_t)c * 8;
+            t[0] = a.k1[c]; t[1] = a.k2[c]; t[2] = a.k3[c]; t[3] = a.mean[c];
+            t[4] = a.self_scale ? a.self_scale[c] : 0.f; t[5] = a.self_scale ? a.self_shift[c] : 1.f; t[6] = 0.f; t[7] = 0.f;
+        }
     }
+}
+
+// two units in one launch (blockIdx.y): a block's conv_b and its shortcut conv get their backward sums from the same kernel
+// (the lazy backward's data-gradient epilogue, bwd_lazy.hip), and both must be final before the block's kernels start
+__global__ __launch_bounds__(512) void bn_bwd_finalize2_kernel(const BnBwdFinalizeArgs a, const BnBwdFinalizeArgs b) {
+    __shared__ double s_slices[512];
+    __shared__ double s_tot[2 * kBnCB];
+    const BnBwdFinalizeArgs& u = blockIdx.y == 0 ? a : b;
+    const int c0 = blockIdx.x * u.cbw, cb = min(u.cbw, u.c - c0);
+    if (cb <= 0) return;
+    reduce_partials(u.partial, u.nchunk, u.sums, u.c, c0, cb, s_slices, s_tot);
+    for (int i = threadIdx.x; i < cb; i += blockDim.x) {
+        const int c = c0 + i;
+        const float db = (float)s_tot[i], dg = (float)s_tot[cb + i];
+        u.dbeta[c] = db * u.grad_scale;
+        if (u.dgamma) u.dgamma[c] = dg * u.grad_scale;
+        u.k1[c] = u.gamma ? u.gamma[c] * u.invstd[c] : u.invstd[c];
+        u.k2[c] = (float)((double)db / u.count);
+        u.k3[c] = (float)((double)u.invstd[c] * (double)dg / u.count);
+        if (u.tab) {
+            float* t = u.tab + (size_t)c * 8;
+            t[0] = u.k1[c]; t[1] = u.k2[c]; t[2] = u.k3[c]; t[3] = u.mean[c];
+            t[4] = u.self_scale ? u.self_scale[c] : 0.f; t[5] = u.self_scale ? u.self_shift[c] : 1.f; t[6] = 0.f; t[7] = 0.f;
+        }
+    }
+}
+
+int launch_bn_bwd_finalize2(const BnBwdFinalizeArgs& a0, const BnBwdFinalizeArgs& b0, hipStream_t s) {
+    BnBwdFinalizeArgs a = a0, b = b0;
+    a.cbw = bn_finalize_cb(a.nchunk); b.cbw = bn_finalize_cb(b.nchunk);
+    const int gx = max(ceil_div(a.c, a.cbw), ceil_div(b.c, b.cbw));
+    hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(gx, 2), dim3(bn_finalize_threads(a.nchunk)), 0, s, a, b);
+    return check_launch("bn_bwd_finalize2_kernel");
 }
 
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a0, hipStream_t s) {

@@ -140,8 +140,11 @@ struct WgradReduceMulti {
     WgradReduceEntry e[kMultiMax];
 };
 bool conv_wgrad_deferrable(int k, int cin, int cout);         // single slab (Cout <= 80), slab kernel
+bool conv_wgrad_fly_covers(int k, int stride, bool x_slack);  // launch_conv_wgrad_partial honours a WgradFly for this shape
+struct WgradFly;
 int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, const float* dy, float* scratch, int batch, int cin, int cout,
-                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine = false, bool x_slack = false);
+                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine = false, bool x_slack = false,
+                              const WgradFly* fly = nullptr);
 // x_slack: x and dy are followed by >= 64 readable floats (tensors inside a workspace): allows the 16-byte-load kernel
 WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const float* scratch, float* dw, bool fine = false);
 int launch_wgrad_reduce_multi(const WgradReduceMulti& m, hipStream_t s);
@@ -277,6 +280,76 @@ struct TrainBwdPhaseArgs {
 int launch_train_bwd_phase(TrainBwdPhaseArgs a, int* rows_out, hipStream_t s);       // 1: does not fit (nothing launched)
 int train_bwd_phase_rows(const TrainBwdPhaseArgs& a);                                // -1: does not fit
 
+// ---- bwd_lazy.hip : TC-ResNet backward without BN passes ("lazy" BN backward) -------------------
+// The per-layer chain was, for every BN unit: reduce (sum dz, sum dz xhat) -> finalize + bn_bwd_apply (writes dy) -> data gradient
+// (one launch per stride phase) + filter gradient, i.e. two elementwise passes over HBM that exist only because BN backward is a
+// separate kernel.  Here dy is NEVER materialised:
+//   * a unit's gradient tensor gz holds the gradient wrt its activation with every ReLU mask that does not depend on the unit
+//     already applied by the kernel that wrote it (the block-output mask [out > 0]; for single-consumer units also their own mask);
+//   * the data-gradient kernel stages  dy = k1 (dz - k2 - (raw - mean) k3)  into LDS for a group of whole utterances while it reads
+//     gz / raw (bn_bwd_apply's expression), runs every stride phase -- and the block's 1x1 shortcut conv, whose gradient meets
+//     conv_a's in the accumulators -- from that image on the matrix cores, and its EPILOGUE applies the next mask, stores the
+//     next unit's gz and leaves that unit's (those units') backward sums as one partial row per workgroup;
+//   * the filter-gradient kernel computes dy in registers where it loads it (WgradFly).
+// Between two such kernels only the tiny finalize (partial rows -> dgamma, dbeta, k1..k3) runs.
+struct LazySrc {            // dy of one BN unit, built while it is staged
+    const float* gz;        // [B][c][t + 2 halo] gradient wrt the unit's activation (see above)
+    const float* raw;       // [B][c][t + 2 halo] the unit's raw conv output
+    const float* k1;        // per-channel coefficients left by bn_bwd_finalize
+    const float* k2;
+    const float* k3;
+    const float* mean;
+    const float* self_scale;    // the unit's own ReLU mask still to be applied: dz = gz [fmaf(raw, scale, shift) > 0]; or nullptr
+    const float* self_shift;
+    const float* tab;       // the same coefficients packed per channel by bn_bwd_finalize: [c][8] = k1, k2, k3, mean, scale, shift (0, 1 without own mask)
+    int c, t;
+};
+struct LazyLayer {          // data gradient of one conv (k x 1, stride 1 or 2) whose dy is src
+    int src;
+    int k, stride, pad_lo;
+    const float* wt;        // phase-major re-arranged weights (bwd_prologue / dgrad_weights_body)
+};
+struct LazyStat {           // backward sums of a unit whose activation gradient this kernel writes
+    int on;
+    const float* raw;
+    const float* mean;
+    const float* invstd;
+    const float* self_scale;    // the unit's own ReLU mask (nullptr: none -- a block's conv_b)
+    const float* self_shift;
+    float* partial;             // [rows][2][out_c]
+};
+struct BwdLazyArgs {
+    LazySrc src[2];
+    int n_layers;           // 1: conv_b, or conv_a of an identity block; 2: conv_a + the block's shortcut conv (same stride)
+    LazyLayer layer[2];
+    int out_c, out_t;       // channels / frames of the gradient written (the convs' input)
+    float* out_g;           // [B][out_c][out_t + 2 halo]
+    const float* add;       // identity shortcut: + the block-output gradient (same shape), or nullptr
+    const float* mask_act;  // block-output activation the written gradient is masked with ([mask_act > 0]), or nullptr
+    int store_self;         // the stored gradient also carries stat[0]'s own mask (its only consumer is that unit)
+    LazyStat stat[2];
+    int batch;
+    // (set by the launcher)
+    int group, n_groups, ks, mt, nw, qmax, taps;
+    int img_off[2], red_off, stat_off, coef_off, ecoef_off, cstat;
+    int nu[2];              // output positions per utterance of stride phase 0 / 1
+    int cnt[2][2], dmin[2][2], wbase[2][2];     // [layer][phase]: taps, first dy offset, float offset of the phase's weights in wt
+    long long* dbg;         // (TCR_DEBUG_LAZY_TS: per-workgroup cycle stamps of the kernel's sections; nullptr otherwise)
+};
+int launch_bwd_lazy(BwdLazyArgs a, int* rows_out, hipStream_t s);      // 1: shape not covered (nothing launched)
+int bwd_lazy_rows(const BwdLazyArgs& a);                               // partial rows it writes (-1: not covered)
+
+// dy computed where the filter-gradient kernel loads it (raw == nullptr: off, `dy` is read as is)
+struct WgradFly {
+    const float* raw = nullptr;
+    const float* k1 = nullptr;
+    const float* k2 = nullptr;
+    const float* k3 = nullptr;
+    const float* mean = nullptr;
+    const float* self_scale = nullptr;
+    const float* self_shift = nullptr;
+};
+
 // ---- bn.hip ---------------------------------------------------------------------------------
 constexpr int kBnMaxLayers = 40;
 
@@ -307,6 +380,8 @@ struct ChanReduceArgs {
     // expression the forward's bn_apply / staging uses, so the mask is bitwise the activation's (one tensor read less per pass)
     const float* self_scale;
     const float* self_shift;
+    float* g_out;           // MODE 1 (scalar kernel): also store dz at the element's place ([B][C][Tp] interior) -- the lazy backward's last block,
+                            // whose pooled, broadcast gradient becomes a masked tensor on the way; or nullptr
 };
 
 struct BnFinalizeArgs {
@@ -354,6 +429,11 @@ struct BnBwdFinalizeArgs {
     float grad_scale;       // sync BN: sums are global on every replica, and the arena all-reduce will add the
                             // replicas' copies up again -> store dgamma/dbeta divided by the replica count
     int cbw = 0;            // (set by the launcher)
+    // lazy backward: also one packed row per channel, tab[c][8] = k1, k2, k3, mean, own-mask scale, shift (0, 1 when self_scale is null), 0, 0
+    float* tab = nullptr;
+    const float* mean = nullptr;
+    const float* self_scale = nullptr;
+    const float* self_shift = nullptr;
 };
 
 struct BnBwdApplyArgs {
@@ -384,6 +464,7 @@ int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 int launch_bn_finalize2(const BnFinalizeArgs& a, const BnFinalizeArgs& b, hipStream_t s);       // two units, one launch (bitwise two launch_bn_finalize calls)
 int launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
+int launch_bn_bwd_finalize2(const BnBwdFinalizeArgs& a, const BnBwdFinalizeArgs& b, hipStream_t s);    // two units, one launch (bitwise two launch_bn_bwd_finalize calls)
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s);
 int launch_bn_bwd_apply_fused(const BnBwdFinalizeArgs& f, const BnBwdApplyArgs& a, hipStream_t s);     // 1: not applicable, launch the pair
 

@@ -968,6 +968,7 @@ struct WgradArgs {
     int xoff;               // HALO - pad_lo
     int utt_per_block;
     int pcol = 0;           // first column of this launch inside the [.][Cout_pad] slab rows (a layer split into channel slices that share one slab)
+    WgradFly fly;           // (16-byte-load kernel) dy computed where it is loaded: `dy` is the unit's gz, fly.raw its raw conv output
 };
 
 template <int K, int NCO>
@@ -1065,13 +1066,27 @@ struct __attribute__((packed, aligned(4))) wg_f4u { float v[4]; };
 // One trip over BS = 16 (8) positions starting at t0: lane (r, q) holds NPL = BS / 4 consecutive positions t0 + NPL q + c of its row.
 // Rows whose length leaves 1..8 positions behind the 16-position trips finish with an 8-position trip (two k-steps): a 7-frame layer
 // costs 2 k-steps, as with the 4-position steps of the kernel above, not 4.
-template <int K, int S, int NCO, int BS, bool SAFE>
+template <int K, int S, int NCO, int BS, bool SAFE, bool FLY>
 __device__ __forceinline__ void wgrad4_trip(f32x4 (&acc)[K][NCO], const float* xr, const float* dr, const int (&doff)[NCO], const bool (&cov)[NCO],
-                                            bool civ, int q, int t0, int tout, bool safe, int xmax) {
+                                            bool civ, int q, int t0, int tout, bool safe, int xmax, const float* rr, const float (&kk)[NCO][6]) {
     constexpr int NPL = BS / 4, W = (NPL - 1) * S + K, NW4 = (W + 3) / 4;
     wg_f4u d4[NCO], w4[NW4];
 #pragma unroll
     for (int m = 0; m < NCO; ++m) d4[m] = *reinterpret_cast<const wg_f4u*>(dr + doff[m] + t0 + NPL * q);      // (NPL = 2: the upper half is not used)
+    if (FLY) {          // dy = k1 (dz - k2 - (raw - mean) k3), dz = gz [fmaf(raw, scale, shift) > 0]: bn_bwd_apply's expression, the lane's channels fixed
+        wg_f4u r4[NCO];
+#pragma unroll
+        for (int m = 0; m < NCO; ++m) r4[m] = *reinterpret_cast<const wg_f4u*>(rr + doff[m] + t0 + NPL * q);
+#pragma unroll
+        for (int m = 0; m < NCO; ++m)
+#pragma unroll
+            for (int c = 0; c < NPL; ++c) {
+                float g = d4[m].v[c];
+                const float y = r4[m].v[c];
+                if (!(fmaf(y, kk[m][4], kk[m][5]) > 0.f)) g = 0.f;
+                d4[m].v[c] = kk[m][0] * (g - kk[m][1] - (y - kk[m][3]) * kk[m][2]);
+            }
+    }
     if (!SAFE || !safe) {
 #pragma unroll
         for (int i = 0; i < NW4; ++i) w4[i] = *reinterpret_cast<const wg_f4u*>(xr + (t0 + NPL * q) * S + 4 * i);
@@ -1097,7 +1112,7 @@ __device__ __forceinline__ void wgrad4_trip(f32x4 (&acc)[K][NCO], const float* x
     }
 }
 
-template <int K, int S, int NCO, bool SAFE>
+template <int K, int S, int NCO, bool SAFE, bool FLY>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a) {
     __shared__ float s_acc[K * 16 * NCO * 16];
     const int lane = threadIdx.x & 63;
@@ -1119,6 +1134,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a
         cov[m] = m * 16 + r < a.cout;
         doff[m] = (a.co_base + (cov[m] ? m * 16 + r : 0)) * a.tpo + kHalo;
     }
+    float kk[NCO][6];                               // FLY: k1, k2, k3, mean, own-mask scale / shift of the lane's dy channels
+#pragma unroll
+    for (int m = 0; m < NCO; ++m) {
+        const int ch = a.co_base + (cov[m] ? m * 16 + r : 0);
+        kk[m][0] = FLY ? a.fly.k1[ch] : 0.f; kk[m][1] = FLY ? a.fly.k2[ch] : 0.f; kk[m][2] = FLY ? a.fly.k3[ch] : 0.f;
+        kk[m][3] = FLY ? a.fly.mean[ch] : 0.f;
+        kk[m][4] = (FLY && a.fly.self_scale) ? a.fly.self_scale[ch] : 0.f;      // (no own mask: fmaf(raw, 0, 1) > 0 always)
+        kk[m][5] = (FLY && a.fly.self_scale) ? a.fly.self_shift[ch] : 1.f;
+    }
     const int n_begin = blockIdx.x * a.utt_per_block;
     const int n_end = min(n_begin + a.utt_per_block, a.batch);
     const int xlane = cic * a.tpi + a.xoff;
@@ -1126,10 +1150,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a
     for (int n = n_begin + wave; n < n_end; n += 4) {
         const float* xr = a.x + (size_t)n * a.cin * a.tpi + xlane;
         const float* dr = a.dy + (size_t)n * a.cout_all * a.tpo;
+        const float* rr = FLY ? a.fly.raw + (size_t)n * a.cout_all * a.tpo : nullptr;
         const bool safe = SAFE && n == a.batch - 1;
         int t0 = 0;
-        for (; a.tout - t0 > 12; t0 += 16) wgrad4_trip<K, S, NCO, 16, SAFE>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax);
-        for (; t0 < a.tout; t0 += 8) wgrad4_trip<K, S, NCO, 8, SAFE>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax);
+        for (; a.tout - t0 > 12; t0 += 16) wgrad4_trip<K, S, NCO, 16, SAFE, FLY>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax, rr, kk);
+        for (; t0 < a.tout; t0 += 8) wgrad4_trip<K, S, NCO, 8, SAFE, FLY>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax, rr, kk);
     }
     // combine the 4 waves in LDS (fixed order), then write the slab
     for (int wv = 0; wv < 4; ++wv) {
@@ -1396,13 +1421,17 @@ size_t wgrad_partial_floats(int k, int cin, int cout, int batch, bool fine) {
 
 template <int K, int S, bool SAFE>
 static int launch_wgrad4_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s) {
+#define TCR_W4(NCO_)                                                                                                            \
+    if (a.fly.raw) hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, NCO_, SAFE, true>), grid, dim3(256), 0, s, a);            \
+    else hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, NCO_, SAFE, false>), grid, dim3(256), 0, s, a)
     switch (nco) {
-        case 1: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 1, SAFE>), grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 2, SAFE>), grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 3, SAFE>), grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 4, SAFE>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, 5, SAFE>), grid, dim3(256), 0, s, a); break;
+        case 1: TCR_W4(1); break;
+        case 2: TCR_W4(2); break;
+        case 3: TCR_W4(3); break;
+        case 4: TCR_W4(4); break;
+        default: TCR_W4(5); break;
     }
+#undef TCR_W4
     return check_launch("conv_wgrad_mfma4_kernel");
 }
 
@@ -1420,6 +1449,7 @@ static int launch_wgrad_k(const WgradArgs& a0, int nco, dim3 grid, hipStream_t s
         return a0.stride == 1 ? launch_wgrad4_k<KK, 1, false>(a0, nco, grid, s) : launch_wgrad4_k<KK, 2, false>(a0, nco, grid, s);
     }
     const WgradArgs& a = a0;
+    if (a.fly.raw) { set_error("conv wgrad: on-the-fly BN backward needs the 16-byte-load kernel (%dx1, stride %d)", K, a.stride); return TCR_ERR_ARG; }
     switch (nco) {
         case 1: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<K, 1>), grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<K, 2>), grid, dim3(256), 0, s, a); break;
@@ -1440,10 +1470,13 @@ WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const flo
     return e;
 }
 
+bool conv_wgrad_fly_covers(int k, int stride, bool x_slack) { return wgrad4_covers(k, stride, x_slack); }
+
 int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, const float* dy, float* scratch, int batch, int cin, int cout,
-                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine, bool x_slack) {
+                              int tpi, int tout, int tpo, WgradReduceEntry* entry, hipStream_t s, bool fine, bool x_slack, const WgradFly* fly) {
     if (!conv_wgrad_deferrable(k, cin, cout)) { set_error("conv wgrad: shape %dx1 %d->%d cannot defer its reduction", k, cin, cout); return TCR_ERR_ARG; }
     WgradArgs a;
+    if (fly) a.fly = *fly;
     a.x = x; a.dy = dy; a.partial = scratch;
     a.batch = batch; a.cin = cin; a.cout = cout; a.cout_all = cout; a.co_base = 0;
     a.cin_pad = ceil_div(cin, 16) * 16;

@@ -74,6 +74,7 @@ struct Workspace {
     std::vector<int64_t> gact;              // grad wrt activation per conv layer (train)
     std::vector<int64_t> mean, invstd;      // saved batch statistics (train)
     std::vector<int64_t> wg, wtl;           // per-layer wgrad partial slabs / re-arranged dgrad weights (train)
+    std::vector<int64_t> kc;                // per-unit k1 / k2 / k3 rows of the lazy backward (its filter gradients read them on other streams, later)
     int64_t partial = -1, sums = -1, sums_slot = 0, kcoef = -1;    // sums: two slots of sums_slot floats (2 x Cmax doubles): main units / shortcut units
     int64_t partial2 = -1, kcoef2 = -1;     // second set: the shortcut branch's BN backward runs concurrently on the side stream
     int64_t dropped = -1, dscale = -1, dlogits = -1, loss_utt = -1, dpool = -1;
@@ -87,7 +88,7 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
     auto take = [&](int64_t n) { int64_t at = o; o += align_up(n, 64); return at; };
     const size_t nl = net.layers.size();
     w.act.assign(nl, -1); w.raw.assign(nl, -1); w.dyb.assign(nl, -1); w.gact.assign(nl, -1);
-    w.mean.assign(nl, -1); w.invstd.assign(nl, -1); w.wg.assign(nl, -1); w.wtl.assign(nl, -1);
+    w.mean.assign(nl, -1); w.invstd.assign(nl, -1); w.wg.assign(nl, -1); w.wtl.assign(nl, -1); w.kc.assign(nl, -1);
     int64_t ss = 0;
     for (const ConvLayer& l : net.layers) if (l.bn) ss += 2 * l.c_pad;
     w.ss = take(ss);
@@ -106,6 +107,7 @@ static Workspace carve(const tcr_net& net, int batch, bool train) {
             w.invstd[i] = take(l.c_pad);
             w.wg[i] = take((int64_t)wgrad_partial_floats(l.k, l.cin, l.cout, batch, true));        // (sized for the finer grid; which layers use it: wgrad_fine)
             w.wtl[i] = take((int64_t)l.k * l.cin * l.cout);
+            w.kc[i] = take(3 * align_up(l.cout, 64) + 8 * (int64_t)l.cout);    // k1, k2, k3 rows + the packed [c][8] table
         }
         cmax = l.cout > cmax ? l.cout : cmax;
         const int64_t wsz = (int64_t)l.k * l.cin * l.cout;
@@ -1298,6 +1300,289 @@ static int bwd_finalize(const TrainCtx& c, int li, float* grads, float* partial,
 
 }  // namespace tcr
 
+// ---- lazy BN backward (bwd_lazy.hip): no reduce / bn_bwd_apply passes, dy never written ----------------------------------------
+namespace tcr {
+
+static int block_index_of(const tcr_net& net, int li) {
+    for (size_t bi = 0; bi < net.blocks.size(); ++bi) {
+        const Block& b = net.blocks[bi];
+        if (li == b.b || li == b.a || li == b.down) return (int)bi;
+    }
+    return -1;
+}
+
+// The gradient tensor unit `li` consumes (gz: every mask but, for a shortcut unit, its own already applied by the kernel that wrote
+// it) and the coefficients its finalize leaves.
+static LazySrc lazy_src_of(const TrainCtx& c, int li) {
+    const tcr_net& net = *c.net;
+    const ConvLayer& l = net.layers[li];
+    const int64_t ks = align_up(l.cout, 64);
+    float* kc = c.base + c.w.kc[li];
+    LazySrc s;
+    std::memset(&s, 0, sizeof(s));
+    s.c = l.cout; s.t = l.tout;
+    s.raw = c.base + c.w.raw[li]; s.mean = c.base + c.w.mean[li];
+    s.k1 = kc; s.k2 = kc + ks; s.k3 = kc + 2 * ks; s.tab = kc + 3 * ks;
+    s.gz = c.base + c.w.gact[li];                           // conv0, conv_a, conv_b: the gradient wrt their own activation
+    const int bi = block_index_of(net, li);
+    if (bi >= 0 && net.blocks[bi].down == li) {             // the shortcut shares the block-output gradient and still applies its own ReLU
+        s.gz = c.base + c.w.gact[net.blocks[bi].b];
+        s.self_scale = ss_of(c, li); s.self_shift = ss_of(c, li) + l.c_pad;
+    }
+    return s;
+}
+
+static LazyStat lazy_stat_of(const TrainCtx& c, int li, bool self) {
+    const ConvLayer& l = c.net->layers[li];
+    LazyStat t;
+    std::memset(&t, 0, sizeof(t));
+    t.on = 1; t.raw = c.base + c.w.raw[li]; t.mean = c.base + c.w.mean[li]; t.invstd = c.base + c.w.invstd[li];
+    if (self) { t.self_scale = ss_of(c, li); t.self_shift = ss_of(c, li) + l.c_pad; }
+    t.partial = c.base + (is_down_unit(*c.net, li) ? c.w.partial2 : c.w.partial);
+    return t;
+}
+
+static LazyLayer lazy_layer_of(const TrainCtx& c, int li, int src) {
+    const ConvLayer& l = c.net->layers[li];
+    LazyLayer L;
+    L.src = src; L.k = l.k; L.stride = l.stride; L.pad_lo = l.pad_lo; L.wt = c.base + c.w.wtl[li];
+    return L;
+}
+
+// conv_b of block bi: writes the gradient wrt conv_a's activation with conv_a's ReLU applied, leaves conv_a's sums
+static BwdLazyArgs lazy_args_b(const TrainCtx& c, int bi) {
+    const tcr_net& net = *c.net;
+    const Block& b = net.blocks[bi];
+    const ConvLayer& lb = net.layers[b.b];
+    BwdLazyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = c.batch; a.n_layers = 1;
+    a.src[0] = lazy_src_of(c, b.b); a.layer[0] = lazy_layer_of(c, b.b, 0);
+    a.out_c = lb.cin; a.out_t = lb.tin; a.out_g = c.base + c.w.gact[b.a];
+    a.store_self = 1; a.stat[0] = lazy_stat_of(c, b.a, true);
+    return a;
+}
+
+// conv_a (+ the shortcut conv) of block bi: writes the gradient wrt the block input -- the previous block's output, masked with
+// its ReLU, with the sums of that block's conv_b and shortcut unit; or, for the first block, wrt conv0's activation
+static BwdLazyArgs lazy_args_a(const TrainCtx& c, int bi) {
+    const tcr_net& net = *c.net;
+    const Block& b = net.blocks[bi];
+    const ConvLayer& la = net.layers[b.a];
+    BwdLazyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = c.batch; a.n_layers = 1;
+    a.src[0] = lazy_src_of(c, b.a); a.layer[0] = lazy_layer_of(c, b.a, 0);
+    if (b.down >= 0) { a.n_layers = 2; a.src[1] = lazy_src_of(c, b.down); a.layer[1] = lazy_layer_of(c, b.down, 1); }
+    else a.add = c.base + c.w.gact[b.b];                    // identity shortcut: + the (masked) block-output gradient
+    a.out_c = la.cin; a.out_t = la.tin; a.out_g = c.base + c.w.gact[la.in_act];
+    if (bi == 0) {
+        a.store_self = 1; a.stat[0] = lazy_stat_of(c, 0, true);
+    } else {
+        const Block& pb = net.blocks[bi - 1];
+        a.mask_act = c.base + c.w.act[pb.b];
+        a.stat[0] = lazy_stat_of(c, pb.b, false);
+        if (pb.down >= 0) a.stat[1] = lazy_stat_of(c, pb.down, true);
+    }
+    return a;
+}
+
+static bool lazy_usable(const TrainCtx& c) {
+    const tcr_net& net = *c.net;
+    const int knob = tune_get(TCR_TUNE_TRAIN_BWD);
+    if ((knob != 0 && knob != 3) || tune_get(TCR_TUNE_CONV_PATH) == 1) return false;
+    // Measured (batch 4096, scripts/ab_knob_train.py KNOB=9): TCResNet8-1.0 -7 % per step at 49 frames, -4 % at 98; TCResNet14-1.5
+    // (36 / 48 / 72 channels: three to five row tiles per data-gradient job, 150-215 VGPRs) +14 % -- so by width, like the other
+    // backward policies: nets of <= 48 channels.  Knob 3 forces it for every net that fits.
+    if (knob == 0 && net.feat_c > 48) return false;
+    for (int li : net.units) {
+        const ConvLayer& l = net.layers[li];
+        if (!conv_wgrad_deferrable(l.k, l.cin, l.cout) || !conv_wgrad_fly_covers(l.k, l.stride, l.in_act >= 0)) return false;
+        if (l.in_act >= 0 && !conv_dgrad_mfma_covers(l.k, l.stride, l.cout)) return false;
+    }
+    if ((int)net.units.size() > kMultiMax) return false;
+    for (size_t bi = 0; bi < net.blocks.size(); ++bi) {
+        const Block& b = net.blocks[bi];
+        if (b.down >= 0 && (net.layers[b.down].stride != net.layers[b.a].stride || net.layers[b.down].k != 1)) return false;
+        if (bwd_lazy_rows(lazy_args_b(c, (int)bi)) < 0 || bwd_lazy_rows(lazy_args_a(c, (int)bi)) < 0) return false;
+    }
+    return true;
+}
+
+// partial rows holding the backward sums of unit li (who wrote them: the last block's units a reduction pass, all others the
+// epilogue of the data-gradient kernel that produced their gradient)
+static int lazy_rows_of(const TrainCtx& c, int li) {
+    const tcr_net& net = *c.net;
+    const int nb = (int)net.blocks.size();
+    if (li == 0) return bwd_lazy_rows(lazy_args_a(c, 0));
+    const int bi = block_index_of(net, li);
+    const Block& b = net.blocks[bi];
+    if (li == b.a) return bwd_lazy_rows(lazy_args_b(c, bi));
+    if (bi == nb - 1) return chan_reduce_launch_chunks(c.batch * net.layers[li].tout, net.layers[li].tout);
+    return bwd_lazy_rows(lazy_args_a(c, bi + 1));
+}
+
+static BnBwdFinalizeArgs lazy_finalize_args(const TrainCtx& c, int li, float* grads) {
+    const ConvLayer& l = c.net->layers[li];
+    const int64_t ks = align_up(l.cout, 64);
+    float* kc = c.base + c.w.kc[li];
+    BnBwdFinalizeArgs f;
+    f.partial = c.base + (is_down_unit(*c.net, li) ? c.w.partial2 : c.w.partial);
+    f.nchunk = c.sync_bn ? 0 : lazy_rows_of(c, li);
+    f.sums = sums_of(c, li); f.gamma = c.params + l.gamma_off; f.invstd = c.base + c.w.invstd[li];
+    f.dgamma = grads + l.gamma_off; f.dbeta = grads + l.beta_off;
+    f.k1 = kc; f.k2 = kc + ks; f.k3 = kc + 2 * ks;
+    f.c = l.cout; f.count = c.bn_batch * (double)l.tout;
+    f.grad_scale = (float)((double)c.batch / c.bn_batch);
+    const LazySrc src = lazy_src_of(c, li);
+    f.tab = kc + 3 * ks; f.mean = src.mean; f.self_scale = src.self_scale; f.self_shift = src.self_shift;
+    return f;
+}
+
+// filter gradient of unit li on stream `ws`, dy computed where it is loaded
+static int lazy_wgrad(const TrainCtx& c, int li, hipStream_t ws) {
+    const tcr_net& net = *c.net;
+    const ConvLayer& l = net.layers[li];
+    const LazySrc src = lazy_src_of(c, li);
+    WgradFly fly;
+    fly.raw = src.raw; fly.k1 = src.k1; fly.k2 = src.k2; fly.k3 = src.k3; fly.mean = src.mean;
+    fly.self_scale = src.self_scale; fly.self_shift = src.self_shift;
+    const float* x = layer_input(net, c.w, c.base, c.feat, l);
+    return launch_conv_wgrad_partial(l.k, l.stride, l.pad_lo, x, src.gz, c.base + c.w.wg[li], c.batch, l.cin, l.cout, tcr_padded_len(l.tin), l.tout,
+                                     tcr_padded_len(l.tout), nullptr, ws, wgrad_fine(l), l.in_act >= 0, &fly);
+}
+
+// Sums of the last block's units.  conv_b's reduction reads the head's pooled gradient (broadcast over time) under the block's ReLU
+// mask and WRITES that masked tensor on the way (the gz every later reader takes); the shortcut's reads it back with its own mask.
+static int lazy_last_block_sums(const TrainCtx& c, int li, hipStream_t st) {
+    const tcr_net& net = *c.net;
+    const ConvLayer& l = net.layers[li];
+    const Block& lastb = net.blocks.back();
+    const LazySrc src = lazy_src_of(c, li);
+    ChanReduceArgs r;
+    std::memset(&r, 0, sizeof(r));
+    r.y = src.raw; r.mean = src.mean; r.invstd = c.base + c.w.invstd[li];
+    if (li == lastb.b) {
+        r.da = c.base + c.w.dpool; r.bcast = 1; r.m1 = c.base + c.w.act[lastb.b]; r.g_out = c.base + c.w.gact[lastb.b];
+    } else {
+        r.da = src.gz; r.self_scale = src.self_scale; r.self_shift = src.self_shift;
+    }
+    r.partial = c.base + (is_down_unit(net, li) ? c.w.partial2 : c.w.partial);
+    r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout);
+    int nchunk = 0;
+    return launch_chan_reduce(1, r, &nchunk, st);
+}
+
+static int backward_lazy(const TrainCtx& c, float* grads, const LevelPlan* plan) {
+    const tcr_net* net = c.net;
+    const int nb = (int)net->blocks.size();
+    const Block& lastb = net->blocks[nb - 1];
+    const bool multi = !plan && c.side != c.s;              // (a dependency level of the cross-replica hand-off stays on the caller's stream)
+    const hipStream_t s_b = multi ? c.side : c.s;           // filter gradients of conv_b + shortcut units
+    const hipStream_t s_a = multi ? net->side2 : c.s;       // filter gradients of conv_a units; first the classifier's
+    auto fork = [&](hipStream_t to) -> int {
+        if (to == c.s) return TCR_OK;
+        if (hipEventRecord(net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(to, net->ev_fork, 0) != hipSuccess) {
+            set_error("tcr_net_backward: stream fork failed");
+            return TCR_ERR_HIP;
+        }
+        return TCR_OK;
+    };
+    auto launch_d = [&](const BwdLazyArgs& a) -> int {
+        const int rc = launch_bwd_lazy(a, nullptr, c.s);
+        if (rc == 1) { set_error("tcr_net_backward: lazy data gradient does not cover a layer it was planned for"); return TCR_ERR_ARG; }
+        return rc;
+    };
+    if (!plan || plan->first) {
+        // ONE launch: head backward (pooled gradient + the last block's masked output gradient), arena zero fill, re-arranged weights
+        const int nc = net->cfg.num_classes;
+        DgradWeightsMulti dm;
+        dm.n = 0;
+        for (int li : net->units) {
+            const ConvLayer& l = net->layers[li];
+            if (l.in_act < 0) continue;
+            dm.e[dm.n++] = {c.params + l.w_off, c.base + c.w.wtl[li], l.k, l.cin, l.cout, l.stride, l.pad_lo};
+        }
+        BwdPrologueArgs hp;
+        hp.dlogits = c.base + c.w.dlogits; hp.wfc = c.params + net->layers[net->fc].w_off; hp.dscale = c.base + c.w.dscale;
+        hp.dpool = c.base + c.w.dpool; hp.batch = c.batch; hp.c = net->feat_c; hp.nc = nc; hp.zero = grads; hp.zero_n = net->param_floats;
+        TCR_TRY(launch_bwd_prologue(hp, dm, c.s));
+        TCR_TRY(fork(s_a));
+        TCR_TRY(launch_fc_wgrad(c.base + c.w.dropped, c.base + c.w.dlogits, c.base + c.w.fc_partial,
+                                grads + net->layers[net->fc].w_off, c.batch, net->feat_c, nc, s_a));
+    }
+    // everything downstream of unit li's sums
+    auto finish_unit = [&](int li, bool finalize) -> int {
+        if (finalize) TCR_TRY(launch_bn_bwd_finalize(lazy_finalize_args(c, li, grads), c.s));
+        if (li == 0) return lazy_wgrad(c, 0, c.s);          // the step's last filter gradient: the main stream is idle by then
+        const int bi = block_index_of(*net, li);
+        const Block& b = net->blocks[bi];
+        const hipStream_t ws = li == b.a ? s_a : s_b;
+        TCR_TRY(fork(ws));
+        TCR_TRY(lazy_wgrad(c, li, ws));
+        if (li == b.b) return launch_d(lazy_args_b(c, bi));
+        if (li == b.a) return launch_d(lazy_args_a(c, bi));
+        return TCR_OK;
+    };
+    if (plan) {
+        TCR_REQUIRE(c.sync_bn, "tcr_net_backward_level: levels exist for the cross-replica hand-off");
+        std::vector<int> post;
+        for (int li : plan->post) if (is_down_unit(*net, li)) post.push_back(li);       // shortcut units first: conv_a's kernel needs both
+        for (int li : plan->post) if (!is_down_unit(*net, li)) post.push_back(li);
+        for (int li : post) TCR_TRY(finish_unit(li, true));
+        for (int li : plan->pre) {
+            if (li == lastb.b || li == lastb.down) TCR_TRY(lazy_last_block_sums(c, li, c.s));
+            TCR_TRY(launch_chan_sums(c.base + (is_down_unit(*net, li) ? c.w.partial2 : c.w.partial), lazy_rows_of(c, li), net->layers[li].cout,
+                                     sums_of(c, li), c.s));
+        }
+    } else {
+        TCR_TRY(lazy_last_block_sums(c, lastb.b, c.s));
+        if (lastb.down >= 0) TCR_TRY(lazy_last_block_sums(c, lastb.down, c.s));
+        for (int bi = nb - 1; bi >= 0; --bi) {
+            const Block& b = net->blocks[bi];
+            if (b.down >= 0) {
+                TCR_TRY(launch_bn_bwd_finalize2(lazy_finalize_args(c, b.b, grads), lazy_finalize_args(c, b.down, grads), c.s));
+                // the shortcut's filter gradient first: conv_b's is the longer one and nothing waits for either
+                TCR_TRY(fork(s_b));
+                TCR_TRY(lazy_wgrad(c, b.down, s_b));
+                TCR_TRY(lazy_wgrad(c, b.b, s_b));
+                TCR_TRY(launch_d(lazy_args_b(c, bi)));
+            } else {
+                TCR_TRY(finish_unit(b.b, true));
+            }
+            TCR_TRY(finish_unit(b.a, true));
+        }
+        TCR_TRY(finish_unit(0, true));
+    }
+    if (plan && !plan->last) return TCR_OK;
+    // every layer's split-K slabs -> dW, summed where their producers ran; then the joins
+    auto run = [&](int which, hipStream_t st) -> int {      // 0: every layer but the first conv, 1: the first conv, 2: all
+        WgradReduceMulti rm;
+        rm.n = 0;
+        for (int li : net->units) {
+            const ConvLayer& l = net->layers[li];
+            if ((which == 0 && li == 0) || (which == 1 && li != 0)) continue;
+            if (rm.n == kMultiMax) { TCR_TRY(launch_wgrad_reduce_multi(rm, st)); rm.n = 0; }
+            rm.e[rm.n++] = conv_wgrad_entry(l.k, l.cin, l.cout, c.batch, c.base + c.w.wg[li], grads + l.w_off, wgrad_fine(l));
+        }
+        return rm.n ? launch_wgrad_reduce_multi(rm, st) : TCR_OK;
+    };
+    if (!multi) return run(2, c.s);
+    if (hipEventRecord(net->ev_join2, s_a) != hipSuccess || hipStreamWaitEvent(s_b, net->ev_join2, 0) != hipSuccess) {
+        set_error("tcr_net_backward: stream join failed");
+        return TCR_ERR_HIP;
+    }
+    TCR_TRY(run(0, s_b));
+    TCR_TRY(run(1, c.s));
+    if (hipEventRecord(net->ev_join, s_b) != hipSuccess || hipStreamWaitEvent(c.s, net->ev_join, 0) != hipSuccess) {
+        set_error("tcr_net_backward: stream join failed");
+        return TCR_ERR_HIP;
+    }
+    return TCR_OK;
+}
+
+}  // namespace tcr
+
 static int backward_stages(const tcr_net* net, const float* params, const float* feat, int batch, int global_batch, int sync_bn,
                            void* workspace, size_t workspace_bytes, float* grads, int stage_begin, int stage_end, void* stream,
                            const LevelPlan* plan = nullptr) {
@@ -1318,6 +1603,8 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     const std::vector<int> order = backward_order(*net);
     const int nu = (int)order.size();
     TCR_REQUIRE(plan || (stage_begin >= 0 && stage_end <= nu + 1 && stage_begin < stage_end), "tcr_net_backward: bad stage range [%d, %d)", stage_begin, stage_end);
+    // lazy BN backward: whole backward passes and the dependency levels of the cross-replica hand-off (the per-unit stage API keeps the per-layer chain)
+    if ((plan || (stage_begin == 0 && stage_end == nu + 1)) && lazy_usable(c)) return backward_lazy(c, grads, plan);
     const float* dpool = c.base + c.w.dpool;
     // where a block's shortcut unit runs (BN backward, data gradient, filter gradient): behind the other units' filter gradients on the
     // side stream, or on the second internal stream (TCR_TUNE_WGRAD_STREAM = 2), where it never queues behind a 50 us filter gradient

@@ -384,7 +384,7 @@ def check_small_batch(lib, batch, name="TCResNet8", width=1.0, tag="4020", seeds
     return worst
 
 
-def check_staged_equals_unstaged(lib, name, width, batch, tag="4020", keep_prob=0.5, handoff="level"):
+def check_staged_equals_unstaged(lib, name, width, batch, tag="4020", keep_prob=0.5, handoff="level", bwd_knob=None):
     """One replica: forward_train / backward run stage by stage through the sync-BN hand-off API with an identity hook must be
     BITWISE the unstaged path (logits, loss, every gradient, moving statistics)."""
     cfg = R.FRONTEND_4020 if tag == "4020" else R.FRONTEND_3010
@@ -399,12 +399,19 @@ def check_staged_equals_unstaged(lib, name, width, batch, tag="4020", keep_prob=
     feat = fe(wav)
     outs = []
     seen = []
-    for hook in (None, lambda sums: seen.append((sums.dtype, sums.numel()))):
-        net = make_net(lib, name, width, fe.n_frames, p, s)
-        net.handoff = handoff
-        logits, probs, loss = net.forward_train(feat, labels, keep_prob=keep_prob, seed=11, sync_hook=hook)
-        g = net.backward().clone()
-        outs.append((logits.clone(), probs.clone(), loss.clone(), g, net.stats.clone()))
+    # The per-unit stage API keeps the per-layer backward chain (reduce -> bn_bwd_apply -> data gradient); whole passes and dependency
+    # levels run the lazy BN backward (bwd_lazy.hip).  Bitwise equality is a property of ONE chain, so the per-unit comparison pins the
+    # unstaged run to the per-layer chain as well (TCR_TUNE_TRAIN_BWD = 2).
+    lib.tcr_tune(9, bwd_knob if bwd_knob is not None else (2 if handoff == "unit" else 0))
+    try:
+        for hook in (None, lambda sums: seen.append((sums.dtype, sums.numel()))):
+            net = make_net(lib, name, width, fe.n_frames, p, s)
+            net.handoff = handoff
+            logits, probs, loss = net.forward_train(feat, labels, keep_prob=keep_prob, seed=11, sync_hook=hook)
+            g = net.backward().clone()
+            outs.append((logits.clone(), probs.clone(), loss.clone(), g, net.stats.clone()))
+    finally:
+        lib.tcr_tune(9, 0)
     # one hand-off per dependency level each way: conv0, and per block (shortcut + first conv) | second conv
     nblocks = len(R.tcresnet_channels(name, float(width))) - 1
     assert lib.tcr_net_num_levels(net._h, 0) - 1 == 1 + 2 * nblocks == lib.tcr_net_num_levels(net._h, 1) - 1

@@ -135,7 +135,22 @@ def test_backward_phases_opt_in(emu_lib):
     try:
         emu_lib.tcr_tune(9, 1)
         Cm.check_train(emu_lib, "tcresnet8_1.0_4020.npz", "TCResNet8", 1.0, steps=1)
-        Cm.check_staged_equals_unstaged(emu_lib, "TCResNet8", 1.0, batch=3, handoff="unit")     # (the level hand-off runs the per-layer backward)
+        Cm.check_staged_equals_unstaged(emu_lib, "TCResNet8", 1.0, batch=3, handoff="unit", bwd_knob=1)     # (the level hand-off runs the per-layer backward)
+    finally:
+        emu_lib.tcr_tune(9, 0)
+
+
+def test_backward_chains_against_the_fixtures(emu_lib):
+    """TCR_TUNE_TRAIN_BWD: 3 = the lazy BN backward (bwd_lazy.hip) for every net -- TCResNet14-1.5 takes the per-layer chain by default:
+    identity shortcuts, 36 / 48 / 72-channel gradients = three to five row tiles per job --, 2 = the per-layer chain for the narrow nets
+    that default to the lazy one; each against the oracle fixtures, and the lazy one through the level hand-off bitwise the unstaged run."""
+    try:
+        emu_lib.tcr_tune(9, 3)
+        Cm.check_train(emu_lib, "tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, steps=1)
+        Cm.check_staged_equals_unstaged(emu_lib, "TCResNet14", 1.5, batch=2, bwd_knob=3)
+        emu_lib.tcr_tune(9, 2)
+        Cm.check_train(emu_lib, "tcresnet8_1.0_4020.npz", "TCResNet8", 1.0, steps=1)
+        Cm.check_train(emu_lib, "tcresnet8_1.0_3010.npz", "TCResNet8", 1.0, steps=1)
     finally:
         emu_lib.tcr_tune(9, 0)
 

@@ -415,9 +415,10 @@ def test_wide_net_training(hip_lib):
 
 
 def test_train_paths_agree(hip_lib):
-    """Train-mode forward as group-resident phases (default) vs per-layer kernels (TCR_TUNE_TRAIN_FWD = 1), backward per-layer (default)
-    vs group-resident phases (TCR_TUNE_TRAIN_BWD = 1): same logits / gradients up to f32 re-association, each path against the oracle
-    fixture, each bitwise reproducible."""
+    """Train-mode forward as group-resident phases (default) vs per-layer kernels (TCR_TUNE_TRAIN_FWD = 1); backward with the lazy BN
+    backward (bwd_lazy.hip: default for nets of <= 48 channels, knob 3 for every net -- TCResNet14-1.5's identity shortcuts and 3-5 row
+    tiles), the group-resident phases (1) and the per-layer chain (2): same logits / gradients up to f32 re-association, each path
+    against the oracle fixture, each bitwise reproducible."""
     fx = Cm.load("tcresnet8_1.0_4020.npz")
     arch, p, s = Cm.fixture_params(fx, "TCResNet8", 1.0)
     fe = Cm.make_frontend(hip_lib, fx["win"], fx["hop"])
@@ -425,7 +426,7 @@ def test_train_paths_agree(hip_lib):
     labels = Cm.to_dev(hip_lib, np.tile(fx["labels"], (256, 1)))
     outs = {}
     try:
-        for fwd, bwd in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        for fwd, bwd in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (0, 3), (1, 3)):     # backward: 0 lazy (narrow nets) / 1 phases / 2 per-layer chain / 3 lazy for every net
             hip_lib.tcr_tune(8, fwd); hip_lib.tcr_tune(9, bwd)
             Cm.check_train(hip_lib, "tcresnet8_1.0_4020.npz", "TCResNet8", 1.0, steps=1)
             Cm.check_train(hip_lib, "tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, steps=1)
