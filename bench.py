@@ -48,7 +48,7 @@ def synth_batch(batch: int, device, seed: int, start: int = 0) -> torch.Tensor:
 # collectives, the JSON line) on the host-emulator build of the kernel sources -- test infrastructure (tests/test_distributed.py), never
 # a measurement: the line it prints says so ("rehearsal").  Without it the gfx950 library and a GPU are required.
 EMU = os.environ.get("TCR_BENCH_EMU") or None
-LEGS = ("latency", "train", "train14", "forward_3010", "dscnn_forward", "dscnn_train", "train_3010", "augment", "pipelined")
+LEGS = ("latency", "train", "train14", "forward_3010", "dscnn_forward", "dscnn_train", "train_3010", "augment")
 
 
 def sync():
@@ -148,6 +148,7 @@ def main():
                 dist.init_process_group(backend)
 
     B = args.batch
+    from tcresnet_amd.parallel import ranks_share_gpu as ranks_share_gpu_
     # what the collective of the training legs actually is: dist.get_backend() ("nccl" on ROCm is RCCL over xGMI)
     coll = {"nccl": "RCCL (backend nccl)", "gloo": "gloo (CPU rehearsal, not RCCL)"}.get(dist.get_backend(), dist.get_backend()) if dist_on else None
 
@@ -163,25 +164,19 @@ def main():
     labels[torch.arange(B), (torch.arange(B) + rank * B) % 12] = 1.0
 
     # ---------------- headline: eval forward, 49x40 front-end ----------------
-    # One step = fused MFCC kernel + whole-network fused kernel, back to back on the current stream (so that the two HIP-event
-    # intervals add up to the step).  A two-stream pipeline overlapping front-end(k+1) with network(k) -- tcresnet_amd.pipeline --
-    # is 4-7 % faster (272 us three batches deep, 264 with whole batches alternating between the streams, vs 284; the "forward_pipelined" leg below); capping both grids
-    # at one workgroup per CU so that the kernels co-reside on every CU LOSES (346 - 413 us): DESIGN.md section 7.
+    # One step = one batch through the fused MFCC kernel + the whole-network fused kernel.  Whole batches ALTERNATE between two streams
+    # that have hardware queues of their own (tcresnet_amd.pipeline.InferencePipeline, mode "alternate": batch k's two kernels back to
+    # back on one stream, batch k+1's on the other; every step computes its own batch, outputs bitwise the one-stream sequence's:
+    # tests/test_gpu_parity.py::test_inference_pipeline_equals_sequential) -- 6-7 % more batches per second than the one-stream
+    # sequence, which is timed first (its two HIP-event intervals add up to its step, and its front-end interval is the dominant
+    # kernel's SOLO duration: co-running, each kernel stretches to ~260 us and no longer describes itself).
     fe, net = build("4020")
     feat = torch.empty((B, 40, fe.n_frames + 8), device=dev)
     outbuf = (torch.empty((B, 12), device=dev), torch.empty((B, 12), device=dev))
-    # HIP events on the launch stream bracket the two kernels of every 8th step (e0 | front-end | e1 | network | e2).  An event record
-    # between two kernels costs ~4 us of dispatch gap on this part (281 us/step without events, 292 with three per step --
-    # scripts/ab_graph_fwd.py), so they are sampled: still live, inside the timed region, on the stream of the launches.
-    nev = args.steps + args.warmup
-    EV_EVERY = 8
-    ev = {i: [new_event() for _ in range(3)] for i in range(args.warmup, nev) if (i - args.warmup) % EV_EVERY == 2 or (args.steps <= 2 and i == args.warmup)}       # timed steps 2, 10, 18, ...
-    counter = [0]
+    w = WORK["4020"]
+    EV_EVERY = 8        # an event record between two kernels costs ~4 us of dispatch gap (281 us/step without, 292 with three per step): sampled
 
-    def fwd_step():
-        i = counter[0]
-        counter[0] += 1
-        e = ev.get(i)
+    def seq_step(e=None):
         if e is None:
             fe(wav, out=feat)
             net.forward_infer(feat, out=outbuf)
@@ -192,20 +187,56 @@ def main():
         net.forward_infer(feat, out=outbuf)
         e[2].record()
 
-    # clock pre-warm: labelled, untimed, outside the K timed steps and the W warm-up steps of the contract
+    # (1) clock pre-warm + the one-stream sequence: labelled, untimed by the contract (outside the K timed steps and the W warm-up steps).
+    #     The first ~50 launches on an idle GPU run ~15 % slower whatever --warmup says; the sequence's sampled events give the solo kernels.
     for _ in range(max(0, args.prewarm)):
-        fe(wav, out=feat)
-        net.forward_infer(feat, out=outbuf)
+        seq_step()
     sync()
+    nseq = 0 if EMU else max(64, args.steps)
+    sev = {i: [new_event() for _ in range(3)] for i in range(nseq) if i % EV_EVERY == 2}
+    c_seq = [0]
+
+    def seq_counted():
+        seq_step(sev.get(c_seq[0]))
+        c_seq[0] += 1
+
+    dt_seq = timed(seq_counted, nseq, 0, dist_on) if nseq else 0.0
+    # (2) the headline: K timed steps after W warm-up steps
+    pipelined = not EMU and not ranks_share_gpu_()
+    if pipelined:
+        from tcresnet_amd.pipeline import InferencePipeline
+        pipe = InferencePipeline(fe, net, B, mode="alternate")
+        step_out = pipe.out
+    nev = args.steps + args.warmup
+    ev = {i: [new_event() for _ in range(3)] for i in range(args.warmup, nev) if (i - args.warmup) % EV_EVERY == 2 or (args.steps <= 2 and i == args.warmup)}       # timed steps 2, 10, 18, ...
+    counter = [0]
+
+    def fwd_step():
+        i = counter[0]
+        counter[0] += 1
+        if pipelined:
+            pipe.submit(wav, events=ev.get(i))
+        else:
+            seq_step(ev.get(i))
+
     dt = timed(fwd_step, args.steps, args.warmup, dist_on)
     value = world * B * args.steps / dt
     timed_ev = [ev[i] for i in range(args.warmup, args.warmup + args.steps) if i in ev]
-    fe_ms = sum(e[0].elapsed_time(e[1]) for e in timed_ev) / len(timed_ev)
-    net_ms = sum(e[1].elapsed_time(e[2]) for e in timed_ev) / len(timed_ev)
+    fe_in = sum(e[0].elapsed_time(e[1]) for e in timed_ev) / len(timed_ev)          # inside the timed region (co-running when pipelined)
+    net_in = sum(e[1].elapsed_time(e[2]) for e in timed_ev) / len(timed_ev)
     per_step = sorted(e[0].elapsed_time(e[2]) for e in timed_ev)
     pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4)
+    if sev:
+        fe_ms = sum(e[0].elapsed_time(e[1]) for e in sev.values()) / len(sev)       # solo: the one-stream sequence
+        net_ms = sum(e[1].elapsed_time(e[2]) for e in sev.values()) / len(sev)
+    else:
+        fe_ms, net_ms = fe_in, net_in
+    bitwise = None
+    if pipelined:
+        sync()
+        ref_logits = net.forward_infer(fe(wav))[0]
+        bitwise = bool(all(torch.equal(o[0], ref_logits) for o in step_out))
 
-    w = WORK["4020"]
     # dominant kernel = the fused front-end (one launch per step): waveform read once, [40][49] tile written once
     fe_bytes = B * (16000 * 4 + 40 * w["frames"] * 4)
     fe_flops = B * w["mfcc_flops"]
@@ -219,8 +250,11 @@ def main():
     traffic, traffic_src = pmc_traffic("frontend_pk_kernel<512,")
     prof_avg_us, prof_src = profile_avg_us("frontend_pk_kernel<512,")
     roof.update({"traffic": traffic, "traffic_source": traffic_src, "profile_avg_us": prof_avg_us, "profile_source": prof_src, "kernel": "frontend_pk_kernel<512, 10, false>", "kernel_ms": round(fe_ms, 4),
-                 "note": "f32 VALU pipe; its 157.3 TFLOP/s peak equals the exact-f32 MFMA peak. HIP-event-bracketed launch on the "
-                         "launch stream, inside the timed region (every 8th step: an event record costs ~4 us of dispatch gap)",
+                 "kernel_ms_in_timed_region": round(fe_in, 4),
+                 "note": "f32 VALU pipe; its 157.3 TFLOP/s peak equals the exact-f32 MFMA peak. kernel_ms: HIP-event-bracketed launches on the launch "
+                         "stream in the one-stream sequence of this run (the kernel alone on the chip; every 8th step: an event record costs ~4 us of "
+                         "dispatch gap); kernel_ms_in_timed_region: the same brackets inside the timed region, where the kernel shares the chip with the "
+                         "other stream's network kernel -- see pair_roofline for the co-running pair",
                  "hbm_gbs": round(fe_gbs, 1), "hbm_frac": round(hbm_frac, 4), "fp32_tflops": round(fe_tf, 3), "fp32_frac": round(fp_frac, 4),
                  "algorithmic_bytes_per_launch": fe_bytes, "algorithmic_flops_per_launch": fe_flops})
     whole_tf = value / world * (w["mfcc_flops"] + w["net_flops"]) / 1e12
@@ -229,11 +263,20 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"TCResNet8-1.0 eval forward, waveform->softmax, batch {B}/GPU, 49x40 MFCC (40/20 ms, FFT 1024), 12 classes",
-                   "global_batch": world * B, "parallelism": f"dp{world} (utterance shards, no collective)", "collective_backend": dist.get_backend() if dist_on else None},
+                   "global_batch": world * B, "parallelism": f"dp{world} (utterance shards, no collective)", "collective_backend": dist.get_backend() if dist_on else None,
+                   "schedule": "whole batches alternating between two streams (InferencePipeline 'alternate')" if pipelined else "one stream"},
         "collective_backend": coll, "collectives_per_step": {"forward": 0},       # (eval forward: replicas only; the training legs add theirs below)
         "roofline": roof,
-        "phases_ms": {"frontend": round(fe_ms, 4), "net": round(net_ms, 4)},
-        "step_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "event_timed_steps": len(timed_ev),
+        # the co-running pair: algorithmic flops of BOTH kernels of a step / the step time of the timed region
+        "pair_roofline": {"bound": "mfma", "achieved": round(whole_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(whole_tf / FP32_PEAK_TFLOPS, 4),
+                          "kernels": ["frontend_pk_kernel<512, 10, false>", "net_fused_tc8_kernel<8, 49, 0>"],
+                          "algorithmic_flops_per_step": B * (w["mfcc_flops"] + w["net_flops"])},
+        "phases_ms": {"frontend": round(fe_ms, 4), "net": round(net_ms, 4), "frontend_in_timed_region": round(fe_in, 4), "net_in_timed_region": round(net_in, 4)},
+        "sequential": {"ms_per_step": round(dt_seq / nseq * 1e3, 4) if nseq else None, "steps": nseq,
+                       "what": "the same batches on ONE stream (front-end, network back to back), timed in this run ahead of the warm-up steps"},
+        "bitwise_equal_to_sequential": bitwise,
+        ("batch_latency_ms_p10_p50_p90" if pipelined else "step_ms_p10_p50_p90"): [pct(0.1), pct(0.5), pct(0.9)],     # (pipelined: e0 -> e2 of a batch on its own stream, two batches in flight)
+        "event_timed_steps": len(timed_ev),
         "pre_warm_launches": max(0, args.prewarm),
         "whole_path_fp32_frac": round(whole_tf / FP32_PEAK_TFLOPS, 4),
         "whole_path_hbm_frac": round(value / world * 64048 / 1e9 / HBM_PEAK_GBS, 4),
@@ -386,29 +429,6 @@ def main():
                           "hbm_gbs": round(aug_bytes / (dta / sa) / 1e9, 1), "hbm_frac": round(aug_bytes / (dta / sa) / 1e9 / HBM_PEAK_GBS, 4),
                           "algorithmic_bytes_per_launch": aug_bytes,
                           "workload": f"tcr_augment_fwd: int16 PCM -> float, +-1600-sample shift, background mix (80 % of utterances), clip; batch {B}/GPU"}
-
-    if "pipelined" in legs and not EMU:
-        # ---------------- the headline workload through the two-stream pipeline (tcresnet_amd.pipeline.InferencePipeline) ----------------
-        # Whole batches alternate between two streams that have hardware queues of their own: batch k's front-end and network back to
-        # back on one stream while batch k+1 runs on the other; every step computes its own batch (outputs bitwise the sequential
-        # step's, scripts/ab_pipeline_modes.py).  Reported next to the headline, which stays the sequential step so that its two event
-        # intervals add up.
-        from tcresnet_amd.pipeline import InferencePipeline
-        pipe = InferencePipeline(fe, net, B, mode="alternate")
-        sp = max(50, args.steps)
-        def seq_step():
-            fe(wav, out=feat)
-            net.forward_infer(feat, out=outbuf)
-        dts = timed(seq_step, sp, max(20, args.warmup), dist_on)          # the sequential step again, at this point of the run
-        dtp = timed(lambda: pipe.submit(wav), sp, max(20, args.warmup), dist_on)
-        pipe.sync()
-        sync()
-        ref_logits = net.forward_infer(fe(wav))[0]
-        out["forward_pipelined"] = {"value": round(world * B * sp / dtp, 1), "unit": "utterances/s", "ms_per_step": round(dtp / sp * 1e3, 4), "steps": sp,
-                                    "sequential_ms_per_step_here": round(dts / sp * 1e3, 4),
-                                    "bitwise_equal_to_sequential": bool(all(torch.equal(o[0], ref_logits) for o in pipe.out)),
-                                    "whole_path_fp32_frac": round(B * sp / dtp * (w["mfcc_flops"] + w["net_flops"]) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                                    "workload": "the headline workload, whole batches alternating between two streams (front-end + network of batch k on one, batch k+1 on the other)"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not EMU:
         out["cpu_baseline"] = cpu_baseline()

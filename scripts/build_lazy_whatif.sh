@@ -6,7 +6,7 @@ python tc-resnet_amd/build.py > /dev/null
 mkdir -p scripts/whatif_libs
 OBJS=$(ls tc-resnet_amd/build/*.o | grep -v bwd_lazy.o)
 for m in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Wall -Wno-unused-function -Wno-unused-variable -Wno-pass-failed \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Itc-resnet_amd/csrc -Wall -Wno-unused-function -Wno-unused-variable -Wno-pass-failed \
       -DTCR_LAZY_WHATIF=$m -c tc-resnet_amd/csrc/bwd_lazy.hip -o /tmp/bwd_lazy_whatif_$m.o &&
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/whatif_libs/lib_whatif_$m.so $OBJS /tmp/bwd_lazy_whatif_$m.o && echo "built $m"
 done

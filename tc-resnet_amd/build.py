@@ -21,9 +21,9 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libtcresnet_hip.so")
 SOURCES = ["tcr_common.cpp", "frontend_plan.cpp", "frontend.hip", "frontend_pk.hip", "conv.hip", "mfma.hip", "bn.hip", "head.hip",
            "optim.hip", "net.cpp", "dscnn.hip", "dscnn_bwd.hip", "fused.hip", "train_fused.hip", "train_fused_bwd.hip", "bwd_lazy.hip", "augment.hip", "net2d_kernels.hip", "net2d.cpp"]
-HEADERS = ["tcr_common.h", "frontend_plan.h", "frontend_args.h", "kernels.h", "net2d.h", os.path.join("..", "..", "include", "tcresnet_hip.h")]
+HEADERS = ["tcr_common.h", "gfx950_isa.h", "frontend_plan.h", "frontend_args.h", "kernels.h", "net2d.h", os.path.join("..", "..", "include", "tcresnet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", CSRC, "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-pass-failed"] + os.environ.get("TCR_BUILD_EXTRA", "").split()      # (diagnostic builds: extra -D flags)
 
 

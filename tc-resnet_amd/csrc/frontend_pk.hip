@@ -21,125 +21,7 @@
 
 namespace tcr {
 
-typedef float v2 __attribute__((ext_vector_type(2)));
-typedef float v4 __attribute__((ext_vector_type(4)));
-
-#if defined(TCR_HOST_EMULATION)
-#define TCR_PK_ASM 0
-#else
-#define TCR_PK_ASM 1
-#endif
-
-// a - i b = (a.x + b.y, a.y - b.x)
-__device__ __forceinline__ v2 c_submi(v2 a, v2 b) {
-#if TCR_PK_ASM
-    v2 d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-#else
-    return (v2){a.x + b.y, a.y - b.x};
-#endif
-}
-// a + i b = (a.x - b.y, a.y + b.x)
-__device__ __forceinline__ v2 c_addmi(v2 a, v2 b) {
-#if TCR_PK_ASM
-    v2 d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-#else
-    return (v2){a.x - b.y, a.y + b.x};
-#endif
-}
-// a + conj(b), a - conj(b)
-__device__ __forceinline__ v2 c_addc(v2 a, v2 b) {
-#if TCR_PK_ASM
-    v2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-#else
-    return (v2){a.x + b.x, a.y - b.y};
-#endif
-}
-__device__ __forceinline__ v2 c_subc(v2 a, v2 b) {
-#if TCR_PK_ASM
-    v2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-#else
-    return (v2){a.x - b.x, a.y + b.y};
-#endif
-}
-// a * b:  t = a.y * (b.y, b.x);  r = (fma(a.x, b.x, -t.x), fma(a.x, b.y, t.y))
-__device__ __forceinline__ v2 c_mul(v2 a, v2 b) {
-#if TCR_PK_ASM
-    v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-    return r;
-#else
-    const float tx = a.y * b.y, ty = a.y * b.x;
-    return (v2){fmaf(a.x, b.x, -tx), fmaf(a.x, b.y, ty)};
-#endif
-}
-// a * b with a wave-uniform constant b (scalar register pair)
-__device__ __forceinline__ v2 c_mulk(v2 a, v2 b) {
-#if TCR_PK_ASM
-    v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
-    return r;
-#else
-    return c_mul(a, b);
-#endif
-}
-// a * conj(b):  r = (fma(a.x, b.x, t.x), fma(-a.x, b.y, t.y))
-__device__ __forceinline__ v2 c_mulc(v2 a, v2 b) {
-#if TCR_PK_ASM
-    v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-    return r;
-#else
-    const float tx = a.y * b.y, ty = a.y * b.x;
-    return (v2){fmaf(a.x, b.x, tx), fmaf(-a.x, b.y, ty)};
-#endif
-}
-
-// Cross-lane moves of the real-FFT split (no LDS round trip):
-//   row_swap: the odd 16-lane rows of `a` trade places with the even rows of `b` (v_permlane16_swap_b32) -- a frame's two
-//             256-point units sit in adjacent rows, so one swap per register pair hands every lane E[k] and O[k] of ITS bins;
-//   lane_gather: value of an arbitrary lane (ds_bpermute_b32: the LDS crossbar, no memory, no bank conflicts).
-__device__ __forceinline__ void row_swap(float& a, float& b, int lane) {
-#if TCR_PK_ASM
-    (void)lane;
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-#else
-    const float ax = __shfl_xor(a, 16), bx = __shfl_xor(b, 16);
-    const bool odd = (lane >> 4) & 1;
-    const float na = odd ? bx : a, nb = odd ? b : ax;
-    a = na;
-    b = nb;
-#endif
-}
-__device__ __forceinline__ float lane_gather(float v, int src_lane) {
-#if TCR_PK_ASM
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-#else
-    return __shfl(v, src_lane);
-#endif
-}
-
-// ln(x) for normal positive x (the mel energies are >= 1e-12): v_log_f32 (1 ulp) * ln 2 -- two instructions against the ~15 of the
-// library call's denormal / special-value handling; 2e-7 relative, far inside the 1e-4 budget of the MFCCs.
-__device__ __forceinline__ float fast_log(float x) {
-#if TCR_PK_ASM
-    return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
-#else
-    return logf(x);
-#endif
-}
+// (v2 / v4, the packed-FP32 complex idioms c_*, row_swap, lane_gather, fast_log, pk_sq_pair: gfx950_isa.h)
 
 // 4-point forward DFT (W4 = -i), in place: 8 packed instructions.
 __device__ __forceinline__ void pk_dft4(v2& a, v2& b, v2& c, v2& d) {
@@ -183,19 +65,7 @@ __device__ __forceinline__ void pk_dft16(v2 (&v)[16]) {
 __device__ __forceinline__ void pk_real_pair_power(v2 zk, v2 zn, v2 wmi, float& p_lo, float& p_hi) {
     const v2 A = c_addc(zk, zn), D = c_subc(zk, zn);
     const v2 C = c_mul(D, wmi);
-#if TCR_PK_ASM
-    // (X.x, Y.x) and (X.y, Y.y) packed side by side: both squared magnitudes in one pk_mul + one pk_fma
-    v2 xs, ys;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(xs) : "v"(A), "v"(C));
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(ys) : "v"(A), "v"(C));
-    const v2 p = __builtin_elementwise_fma(xs, xs, ys * ys);
-    p_lo = p.x;
-    p_hi = p.y;
-#else
-    const v2 X = A + C, Y = A - C;
-    p_lo = fmaf(X.x, X.x, X.y * X.y);
-    p_hi = fmaf(Y.x, Y.x, Y.y * Y.y);
-#endif
+    pk_sq_pair(A, C, p_lo, p_hi);
 }
 
 // QV: number of leading radix-16 inputs per lane that fall inside the analysis window -- identical for every lane when

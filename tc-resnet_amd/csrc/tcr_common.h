@@ -8,6 +8,7 @@
 #include <cstdio>
 
 #include "../../include/tcresnet_hip.h"
+#include <gfx950_isa.h>      // raw-ISA idioms (inline asm, LDS base, cross-lane moves); tests/emu supplies a host stand-in under the same name
 
 namespace tcr {
 
@@ -65,30 +66,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Base of the dynamic LDS region (launch-time size, third hipLaunchKernelGGL argument).
-#if defined(TCR_HOST_EMULATION)
-inline char* dyn_lds() {
-    alignas(16) static char buf[160 * 1024];
-    return buf;
-}
-#else
-__device__ __forceinline__ char* dyn_lds() {
-    extern __shared__ __attribute__((aligned(16))) char tcr_dyn_lds[];
-    return tcr_dyn_lds;
-}
-#endif
-
-// A zero the optimiser cannot see through.  Adding it to a table pointer keeps loop-invariant table
-// loads INSIDE the loop (they hit L1/K$) instead of being hoisted into dozens of long-lived VGPRs.
-__device__ __forceinline__ int opaque_zero() {
-#if defined(TCR_HOST_EMULATION)
-    return 0;
-#else
-    int z;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-    return z;
-#endif
-}
+// (dyn_lds(), opaque_zero(): gfx950_isa.h)
 
 // n / d for 0 <= n < 2^22, 1 <= d: float multiply + one-step fix-up (a 32-bit integer division by a run-time value is
 // ~25 dependent VALU instructions on this ISA).  inv_d = 1.0f / d.

@@ -63,17 +63,24 @@ class InferencePipeline:
         self._k = 0
         self.fe_events = None                            # optional (start, end) timing events per step
 
-    def submit(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def submit(self, wav: torch.Tensor, events=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Enqueue one batch; returns the (logits, probs) buffers it will land in (valid after `sync()`, after `done_event(...)`, or
-        after `depth` further submits have been synchronised by the caller)."""
+        after `depth` further submits have been synchronised by the caller).  events (mode "alternate"): three timing events recorded
+        on the batch's stream around its two kernels (e0 | front-end | e1 | network | e2)."""
         i = self._k % self.depth
         cur = torch.cuda.current_stream(self.fe.device)
         if self.mode == "alternate":
             st = (self.s_fe, self.s_net)[i]
             with torch.cuda.stream(st):
                 st.wait_stream(cur)                             # the caller produced `wav` on its current stream
+                if events is not None:
+                    events[0].record(st)
                 self.fe(wav, out=self.feat[i])
+                if events is not None:
+                    events[1].record(st)
                 self.net.forward_infer(self.feat[i], out=self.out[i], workspace=self._ws[i])
+                if events is not None:
+                    events[2].record(st)
                 self._net_done[i].record(st)
             self._k += 1
             return self.out[i]
