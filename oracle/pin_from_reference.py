@@ -19,8 +19,14 @@ What it does, with the SAME seeds and inputs as oracle/make_golden.py (so every 
     stat1:*, stat3:*.  Dropout: the fixtures use keep_prob 0.5 with the kernel's counter-based mask; TF cannot reproduce that stream,
     so the pinned train-mode vectors are generated with keep_prob 1.0
     (`pin_nets`: keys `tf:*_keep1`; the keep_prob 0.5 fixtures keep exercising the kernel's own mask against the restatement);
-  * DS-CNN (audio_nets/ds_cnn.py:36-118) is not pinned by this script yet: its fixtures follow the same pattern (`pin_nets` with
-    ds_cnn.DSCNN + DSCNN_arg_scope).
+  * DS-CNN (`pin_dscnn`): builds audio_nets.ds_cnn.DSCNN with S / M / L_NET_DEF under DSCNN_arg_scope (audio_nets/ds_cnn.py:36-118,
+    factory/audio_nets.py:299-360) on the 49 x 10 MFCC of dscnn_4020.npz, assigns the seed-generated variables by TF name and fetches the
+    eval logits / softmax (`tf:logits_{S,M,L}`, `tf:probs_*`); for size S also the training graph of dscnn_train_4020.npz: train-mode
+    logits, tf.gradients of the loss wrt every variable and the variables / moving statistics after one and three AdamOptimizer steps
+    (lr 5e-4, TF defaults beta1 .9, beta2 .999, epsilon 1e-8: the reference's DS-CNN scripts) -- `tf:S:train_logits`, `tf:S:grad:*`,
+    `tf:S:param{1,3}:*`, `tf:S:stat{1,3}:*`;
+  * deploy-path MFCC (`for_deploy=True`: contrib_audio.audio_spectrogram + mfcc, datasets/preprocessors.py:98-124,196-203): pinned by
+    `pin_frontend` as `mfcc_deploy` for every front-end fixture that carries the key (the edge-row fixtures included).
 After it ran, `python -m pytest tests/test_oracle.py` checks the NumPy restatement against the now-pinned vectors: every
 difference > 1e-10 (float64 graph) / > 1e-5 (float32 graph) is a place where SURVEY App. A's recollection of TF 1.13 semantics is wrong
 (the four flagged ones: Hann / mel-matrix precision, SAME padding side, moving-variance estimator, dropout arithmetic;
@@ -70,6 +76,7 @@ def pin_frontend(tf, golden: str, out: str):
             with tf.Session(config=tf.ConfigProto(device_count={"GPU": 0})) as sess:
                 res[key] = sess.run(node, {wav: fx["wav"][..., None]})[..., 0].astype(np.float64)
         fx.update(res)
+        fx["tf:pinned"] = np.asarray(sorted(res), dtype="U")          # which keys now hold the reference's own outputs
         np.savez_compressed(os.path.join(out, name), **fx)
         print("pinned", name, {k: v.shape for k, v in res.items()})
 
@@ -141,6 +148,75 @@ def pin_nets(tf, golden: str, out: str):
         print("pinned", fname, len(res), "tf:* keys")
 
 
+def pin_dscnn(tf, golden: str, out: str):
+    """Adds `tf:*` keys to dscnn_4020.npz (eval, S / M / L) and dscnn_train_4020.npz (size S: train-mode forward, gradients, Adam steps);
+    tests/test_oracle.py::test_dscnn_oracle_against_pinned_reference compares oracle/dscnn_ref.py with them."""
+    slim = tf.contrib.slim
+    import dataclasses
+    from audio_nets import ds_cnn
+    from oracle import dscnn_ref as D
+    from oracle import numpy_ref as R
+    defs = {"S": ds_cnn.S_NET_DEF, "M": ds_cnn.M_NET_DEF, "L": ds_cnn.L_NET_DEF}
+
+    def build(size, x_shape, n_classes, is_training):
+        tf.reset_default_graph()
+        inp = tf.placeholder(tf.float32, [None] + list(x_shape))
+        lab = tf.placeholder(tf.float32, [None, n_classes])
+        with slim.arg_scope(ds_cnn.DSCNN_arg_scope(is_training=is_training)):
+            logits, _ = ds_cnn.DSCNN(inp, n_classes, defs[size])
+        return inp, lab, logits
+
+    def assign_ops(values):
+        variables = {v.op.name: v for v in tf.global_variables()}
+        missing = [k for k in values if k not in variables]
+        assert not missing, f"the oracle's variable names are not the graph's: {missing[:4]}"
+        return variables, [tf.assign(variables[k], np.asarray(v, np.float32).reshape(variables[k].shape.as_list())) for k, v in values.items()]
+
+    fx = dict(np.load(os.path.join(golden, "dscnn_4020.npz")))
+    x = fx["mfcc"].astype(np.float32)[..., None]                              # [B, 49, 10, 1]
+    res = {}
+    for size in ("S", "M", "L"):
+        p, st = D.init_params(D.net_def(size), seed=int(fx["init_seed"]))
+        inp, lab, logits = build(size, x.shape[1:], 12, False)
+        _, assign = assign_ops({**p, **st})
+        with tf.Session(config=tf.ConfigProto(device_count={"GPU": 0})) as sess:
+            sess.run(tf.global_variables_initializer())
+            sess.run(assign)
+            lg, pr = sess.run([logits, slim.softmax(logits)], {inp: x})
+        res.update({f"tf:logits_{size}": lg, f"tf:probs_{size}": pr})
+    fx.update({k: np.asarray(v, np.float64) for k, v in res.items()})
+    np.savez_compressed(os.path.join(out, "dscnn_4020.npz"), **fx)
+    print("pinned dscnn_4020.npz", sorted(res))
+
+    tr = dict(np.load(os.path.join(golden, "dscnn_train_4020.npz")))
+    p, st = D.init_params(D.net_def("S"), seed=int(tr["init_seed"]))
+    wav = R.synth_waveforms(tr["labels"].shape[0], seed=int(tr["S:wav_seed"]))
+    xt = R.mfcc(wav, dataclasses.replace(R.FRONTEND_4020, num_mfccs=10)).astype(np.float32)[..., None]     # (pin_frontend pins the MFCC itself)
+    labels = tr["labels"].astype(np.float32)
+    inp, lab, logits = build("S", xt.shape[1:], labels.shape[1], True)
+    loss = tf.losses.softmax_cross_entropy(logits=logits, onehot_labels=lab, label_smoothing=0.0, weights=1.0)    # weight_decay 0.0 (factory/audio_nets.py:305)
+    variables, assign = assign_ops({**p, **st})
+    grads = tf.gradients(loss, [variables[k] for k in p])
+    opt = tf.train.AdamOptimizer(learning_rate=5e-4)
+    train_op = slim.learning.create_train_op(loss, opt, global_step=tf.train.get_or_create_global_step())     # runs the BN update ops (slim)
+    res = {}
+    with tf.Session(config=tf.ConfigProto(device_count={"GPU": 0})) as sess:
+        sess.run(tf.global_variables_initializer())
+        sess.run(assign)
+        lg, gv = sess.run([logits, grads], {inp: xt, lab: labels})
+        res["tf:S:train_logits"] = lg
+        res.update({"tf:S:grad:" + k: g for k, g in zip(p, gv)})
+        for step in (1, 2, 3):
+            sess.run(train_op, {inp: xt, lab: labels})
+            if step in (1, 3):
+                vals = sess.run({k: variables[k] for k in list(p) + list(st)})
+                res.update({f"tf:S:param{step}:" + k: vals[k] for k in p})
+                res.update({f"tf:S:stat{step}:" + k: vals[k] for k in st})
+    tr.update({k: np.asarray(v, np.float64) for k, v in res.items()})
+    np.savez_compressed(os.path.join(out, "dscnn_train_4020.npz"), **tr)
+    print("pinned dscnn_train_4020.npz", len(res), "tf:* keys")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True, help="tests/golden of this repository (fixtures are rewritten in place)")
@@ -150,6 +226,7 @@ def main():
     pin_frontend(tf, args.out, args.out)
     if args.only == "all":
         pin_nets(tf, args.out, args.out)
+        pin_dscnn(tf, args.out, args.out)
 
 
 if __name__ == "__main__":

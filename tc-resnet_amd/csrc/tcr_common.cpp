@@ -58,6 +58,11 @@ static bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t ea, hipE
 
 constexpr int kSharedStreams = 4;
 
+// The set is chosen ONCE per device and process, against the stream of the FIRST call that needs an internal stream (training step,
+// pipeline, or an explicit tcr_internal_stream(i, stream) at start-up, which is the way to pay the one-off probe cost -- tens of ms of
+// 2 ms spin kernels and stream synchronisations on that stream -- outside a latency-sensitive call).  The handles are handed to callers,
+// so the set is never re-chosen: when the first call arrives on a stream under graph capture the probe is skipped (synchronising would
+// invalidate the capture) and the first unused candidates are taken as they come -- warm the library up before capturing.
 static void choose_streams(hipStream_t caller, hipStream_t (&out)[kSharedStreams]) {
     constexpr int kCand = 12;
     hipStream_t cand[kCand] = {};
@@ -76,7 +81,7 @@ static void choose_streams(hipStream_t caller, hipStream_t (&out)[kSharedStreams
                 bool ok = true;
                 if (pass == 0) {
                     ok = probe;
-                    for (hipStream_t o : apart) ok = ok && streams_concurrent(o, cand[i], ea, eb);
+                    for (hipStream_t o : apart) ok = ok && (o == nullptr || streams_concurrent(o, cand[i], ea, eb));    // (a slot that could not be filled constrains nothing)
                 }
                 if (ok) { used[i] = true; return cand[i]; }
             }

@@ -252,7 +252,8 @@ class TCResNet(_Base):
         ws = self._ws.get(key)
         if ws is None:
             nbytes = self.lib.tcr_net_workspace_bytes(self._h, batch, int(train))
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            # (training: zeroed once -- the cross-replica hand-off all-reduces one contiguous range over both float64 sum slots, gap included)
+            ws = (torch.zeros if train else torch.empty)(nbytes // 4, dtype=torch.float32, device=self.device)
             self._ws[key] = ws
         return ws
 
@@ -286,8 +287,9 @@ class TCResNet(_Base):
             if self._fold_ss is None:
                 self._fold_ss = torch.zeros(self.lib.tcr_net_frozen_floats(self._h), dtype=torch.float32, device=self.device)
             elif cur is not None and self._fold_readers:
-                for ev in self._fold_readers.values():      # forwards still reading the old table on other streams
-                    cur.wait_event(ev)
+                for st, ev in self._fold_readers.items():   # forwards still reading the old table on other streams (the previous fold stream included)
+                    if st != cur.cuda_stream:
+                        cur.wait_event(ev)
             self.lib.check(self.lib.tcr_net_fold_bn(self._h, self.params.data_ptr(), self.stats.data_ptr(), self._fold_ss.data_ptr(),
                                                     self._stream()), "tcr_net_fold_bn")
             self._fold_key = key
@@ -317,14 +319,18 @@ class TCResNet(_Base):
         self.lib.check(self.lib.tcr_net_forward_frozen(self._h, self.params.data_ptr(), ss.data_ptr(), feat.data_ptr(), b,
                                                        ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(),
                                                        _ptr(ranges), self._stream()), "tcr_net_forward_frozen")
+        self._note_fold_reader()
+        return (logits, probs, ranges) if want_ranges else (logits, probs)
+
+    def _note_fold_reader(self):
+        """A forward on the current stream has read the folded table: a refold issued from ANOTHER stream must wait for it (readers on
+        the fold stream itself are recorded too -- the next fold may come from a different stream)."""
         if self.device.type == "cuda":
             cur = torch.cuda.current_stream(self.device)
-            if cur.cuda_stream != self._fold_stream:            # a refold must wait for this reader
-                ev = self._fold_readers.get(cur.cuda_stream)
-                if ev is None:
-                    ev = self._fold_readers[cur.cuda_stream] = torch.cuda.Event()
-                ev.record(cur)
-        return (logits, probs, ranges) if want_ranges else (logits, probs)
+            ev = self._fold_readers.get(cur.cuda_stream)
+            if ev is None:
+                ev = self._fold_readers[cur.cuda_stream] = torch.cuda.Event()
+            ev.record(cur)
 
     def forward_waveform(self, frontend: "Frontend", wav: torch.Tensor, want_ranges: bool = False, out=None, feat: Optional[torch.Tensor] = None):
         """Waveforms [B, n_samples] -> (logits, probs): front-end, BN fold when the weights changed since the last fold, and the network
@@ -352,7 +358,7 @@ class TCResNet(_Base):
         ver = self._weights_version()
         cur = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
         refold = self._fold_key != ver or self._fold_ss is None or (cur is not None and cur != self._fold_stream)
-        if refold and (self._fold_ss is None or self._fold_readers or (cur is not None and cur != self._fold_stream)):
+        if refold and (self._fold_ss is None or any(st != cur for st in self._fold_readers) or (cur is not None and cur != self._fold_stream)):
             ss = self._folded_table()           # allocation / cross-stream ordering: the general path
             refold = False
         else:
@@ -361,8 +367,15 @@ class TCResNet(_Base):
                                                      self.stats.data_ptr(), ss.data_ptr(), int(refold), wav.data_ptr(), b, feat.data_ptr(),
                                                      ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), _ptr(ranges),
                                                      self._stream()), "tcr_forward_waveform")
-        if refold:
+        if refold:          # the call refolded in line (on the fold stream, no other readers): other streams order themselves behind THIS fold
             self._fold_key = ver
+            self._fold_readers = {}
+            if self.device.type == "cuda":
+                st = torch.cuda.current_stream(self.device)
+                self._fold_event = torch.cuda.Event()
+                self._fold_event.record(st)
+                self._fold_stream = st.cuda_stream
+        self._note_fold_reader()
         return (logits, probs, ranges) if want_ranges else (logits, probs)
 
     def fold_bn(self) -> torch.Tensor:

@@ -161,6 +161,8 @@ class AudioNetModel(TFModel):
         names = [n for n, ti in self.engine.tensors.items() if ti.arena == 0]
         train = [n for n in names if any(re.match(sc, n) for sc in scopes)] if scopes else names
         self._frozen = [(int(ti.offset), int(ti.size)) for n, ti in self.engine.tensors.items() if ti.arena == 0 and n not in set(train)]
+        self._trained_names = set(train)                # (optimiser slots / EMA shadows exist for these only: tf.train.Optimizer.minimize(var_list=...))
+        self._train_nothing = bool(scopes) and not train
         for n in (train if scopes else []):
             if logger is not None:
                 logger.info("vars to train > %s", n)
@@ -179,6 +181,19 @@ class AudioNetModel(TFModel):
         Momentum needs `momentum`; Adam beta1 .9, beta2 .999, epsilon 1e-8; RMSProp decay .9, momentum 0, epsilon 1e-10)."""
         self._audio_original, self.labels, self.is_training = wavs, labels, True
         self.preprocess_input()
+        if getattr(self, "_train_nothing", False):
+            # Empty variables_to_train: the reference's train op is tf.no_op() (helper/trainer.py:220-222) -- no optimiser, no UPDATE_OPS
+            # (BN moving averages untouched), no slot, only the losses are fetched: the training-graph forward with everything it
+            # would have written put back.
+            saved = self.engine.stats.clone()
+            dp0 = self.data_parallel(sync_bn)
+            self.logits, self._outputs, loss_sum = dp0.forward_train(
+                self._preprocessor.planar, labels, keep_prob=self._keep_prob(), seed=self._step,
+                label_smoothing=float(getattr(self.args, "label_smoothing", 0.0)))
+            self.engine.stats.copy_(saved)
+            self._model_loss = dp0.mean_loss(loss_sum, wavs.shape[0])
+            self._total_loss = self._model_loss + self.engine.l2_loss(self.args.weight_decay)
+            return self._total_loss, self._model_loss
         self._step += 1
         dp = self.data_parallel(sync_bn)
         b = wavs.shape[0]

@@ -24,11 +24,15 @@ class Base:
     def run_inference(self, global_step: int, iters: Optional[int] = None, is_training: bool = False, do_eval: bool = True):
         """One forward pass per batch (`session.run(fetch_ops)` in the reference, :52-125); returns the per-batch values
         stacked with np.vstack: labels_onehot, predictions_onehot, total_loss, model_loss, batch / unit inference time (ms)."""
+        rank, world = getattr(self, "rank", 0), getattr(self, "world", 1)
         if iters is None:
-            iters = self.build_iters_from_batch_size(self.dataset.num_samples, self.args.batch_size)
+            # one iteration consumes batch_size utterances PER RANK: the default covers the split once, not `world` times
+            iters = self.build_iters_from_batch_size(self.dataset.num_samples, self.args.batch_size * world)
+            if world > 1 and self.dataset.num_samples % (self.args.batch_size * world):
+                self.log.warning("evaluation over %d ranks drops the last %d of %d samples (batches of %d per rank)", world,
+                                 self.dataset.num_samples % (self.args.batch_size * world), self.dataset.num_samples, self.args.batch_size)
         agg: Dict[str, list] = {k: [] for k in ("labels_onehot", "predictions_onehot", "total_loss", "model_loss",
                                                 "batch_infer_time", "unit_infer_time")}
-        rank, world = getattr(self, "rank", 0), getattr(self, "world", 1)
         for _ in range(int(iters)):
             wavs, labels = self.dataset.next_batch(rank, world)
             st = time.time()
@@ -46,10 +50,16 @@ class Base:
         if world > 1:
             # data parallel: every rank evaluated its shard of each batch; the metrics are over all of them (rank order = sample order
             # within a batch does not matter to any metric)
+            import torch
             import torch.distributed as dist
-            parts = [None] * world
-            dist.all_gather_object(parts, out)
-            out = {k: np.vstack([p[k] for p in parts]) for k in out}
+            dev = self.model.outputs.device if dist.get_backend() == "nccl" else torch.device("cpu")
+            gathered = {}
+            for k in sorted(out):           # fixed-shape tensors (every rank ran the same iterations), no pickling
+                t = torch.from_numpy(np.ascontiguousarray(out[k], dtype=np.float32)).to(dev)
+                parts = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(parts, t)
+                gathered[k] = np.vstack([p.cpu().numpy() for p in parts])
+            out = gathered
         return out
 
     def run_evaluation(self, global_step: int, iters: Optional[int] = None, is_training: bool = False) -> Dict[str, object]:

@@ -101,7 +101,10 @@ class TrainerBase(AudioBase):
         if getattr(a, "trainable_scopes", ""):
             trained = self.model.set_trainable_scopes(a.trainable_scopes, self.log)
             if not trained:
-                self.log.info("Empty variables_to_train")           # (the reference's train op is then tf.no_op(), :220-222)
+                # the reference's train op is then tf.no_op() (:220-222): nothing is ever updated -- and its global_step never advances, so
+                # its loop never ends.  Here the steps are forward-only as well (no variable, slot or moving statistic changes) but the
+                # step counter still advances, so that --max_step_from_restore ends the run: the one deliberate deviation.
+                self.log.info("Empty variables_to_train")
         if a.use_ema:
             self.model.engine.ema_init()
         self.routine_restore_and_initialize()
@@ -114,8 +117,9 @@ class TrainerBase(AudioBase):
         names = list(_SLOTS[self.args.optimizer]) + (["ExponentialMovingAverage"] if self.args.use_ema else [])
         for slot in names:
             arena = eng.slot_arena(slot)
+            trained = getattr(self.model, "_trained_names", None)       # --trainable_scopes: slots / EMA shadows exist for the trained variables only
             for name, ti in eng.tensors.items():
-                if ti.arena == 0:
+                if ti.arena == 0 and (trained is None or name in trained):
                     out[f"{name}/{slot}"] = arena[ti.offset:ti.offset + ti.size].view(*eng.tf_shape(name))    # slots have their variable's TF shape
         return out
 

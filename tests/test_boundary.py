@@ -202,6 +202,21 @@ def test_trainer_flags_are_honoured_or_refused(rt, tmp_path):
         if ti.arena == 0 and n not in moved:
             assert float(mom[ti.offset:ti.offset + ti.size].abs().max()) == 0.0, n      # no slot update either
     assert any(not np.array_equal(init[n], now[n]) for n in now if n.endswith("moving_mean"))
+    # ... and the checkpoint holds slots for the trained variables only (tf.train.Optimizer creates slots for its var_list)
+    from tcresnet_amd.common import tf_bundle
+    ck = tf_bundle.read_checkpoint(str(tmp_path / "y" / "TCResNet8Model-2"))
+    assert {k[:-len("/Momentum")] for k in ck if k.endswith("/Momentum")} == \
+        {"TCResNet8/fc/weights", "TCResNet8/fc2/weights", "TCResNet8/block2/conv2_1/BatchNorm/gamma", "TCResNet8/block2/conv2_1/BatchNorm/beta"}
+    # a scope that matches nothing: the reference's train op is tf.no_op() (helper/trainer.py:220-222) -- no variable, slot or moving
+    # statistic changes; the losses are still fetched (here the step counter advances so that the run ends: documented deviation)
+    tc_resnet.reset_engines()
+    tr = train_audio.train(train_audio.parse_arguments(REF_TRAIN_CMD.replace("--optimizer mom", "--trainable_scopes NoSuchScope --optimizer mom")
+                                                       .replace("--max_step_from_restore 3", "--max_step_from_restore 2").format(d=tmp_path / "z").split()))
+    eng = tr.model.engine
+    fresh = type(eng)(eng.scope, eng.channels, eng.in_channels, eng.t_in, eng.num_classes, lib=eng.lib, device=eng.device)
+    fresh.init_xavier(0)
+    init, now = fresh.state_dict(), eng.state_dict()
+    assert tr.global_step == 2 and all(np.array_equal(init[n], now[n]) for n in now), [n for n in now if not np.array_equal(init[n], now[n])]
     with pytest.raises(SystemExit):
         train_audio.parse_arguments(REF_TRAIN_CMD.replace("--step_evaluation 500", "--step_evaluation 0").format(d=tmp_path).split())
 

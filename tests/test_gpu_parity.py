@@ -289,10 +289,19 @@ def test_dscnn_train_full_batch(hip_lib):
             kpos = np.transpose(act.reshape(64, pre.shape[3], pre.shape[1], pre.shape[2]), (0, 2, 3, 1)) > 0
             masks[ck] = np.where(close, kpos, pre > 0)
     gref = D.backward(blocks, p, ref, labels64, masks=masks)
-    for k in ("DSCNN/fc1/weights", "DSCNN/fc1/biases", "DSCNN/conv_ds_5/pointwise_conv/weights", "DSCNN/conv_ds_3/depthwise_conv/depthwise_weights",
-              "DSCNN/conv_ds_1/dw_batch_norm/beta", "DSCNN/conv_ds_2/pw_batch_norm/beta", "DSCNN/conv_ds_1/pointwise_conv/weights", "DSCNN/conv_1/weights"):
+    # EVERY gradient tensor of the net (weights, depthwise weights, biases, BN betas: 35), not a hand-picked few.  Conv biases ahead of a
+    # train-mode BN have an exactly-zero gradient (TF computes round-off noise there): an absolute bound relative to the net's largest entry.
+    gmax = max(float(np.abs(v).max()) for v in gref.values())
+    checked = 0
+    for k in [n for n, ti in net.tensors.items() if ti.arena == 0]:
+        if k not in gref:
+            continue
         got = net.grad_view(k).cpu().numpy().reshape(gref[k].shape)
-        assert np.abs(got - gref[k]).max() < 1e-3 * np.abs(gref[k]).max(), (k, near)
+        scale = float(np.abs(gref[k]).max())
+        tol = 1e-3 * scale if scale > 1e-6 * gmax else 1e-6 * gmax
+        assert np.abs(got - gref[k]).max() <= tol, (k, float(np.abs(got - gref[k]).max()), scale, near)
+        checked += 1
+    assert checked == len(gref) >= 30, (checked, len(gref))          # DS-CNN-L: 35 gradient tensors
     net.stats.copy_(stats0)
     logits2, _, loss2 = net.forward_train(feat, labels)
     g2 = net.backward()

@@ -108,6 +108,57 @@ def test_oracle_against_pinned_reference(fname, name, width):
         assert np.abs(g[k[len("tf:grad_keep1:"):]].reshape(ref.shape) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), k
 
 
+def test_dscnn_oracle_against_pinned_reference():
+    """DS-CNN twin of the test above: runs only when oracle/pin_from_reference.py::pin_dscnn has added `tf:*` keys (the reference's
+    ds_cnn.DSCNN graphs under TF 1.13) to the DS-CNN fixtures; skips -- parity unpinned -- in this image."""
+    from oracle import dscnn_ref as D
+    fx = Cm.load("dscnn_4020.npz")
+    if "tf:logits_S" not in fx:
+        pytest.skip("parity unpinned: no tf:* keys in dscnn_4020.npz (oracle/pin_from_reference.py needs TensorFlow 1.13)")
+    for size in ("S", "M", "L"):
+        p, s = D.init_params(D.net_def(size), seed=int(fx["init_seed"]))
+        r = D.forward(D.net_def(size), p, s, fx["mfcc"], False)
+        assert np.abs(r["logits"] - fx[f"tf:logits_{size}"]).max() < 2e-5, size
+        assert np.abs(r["probs"] - fx[f"tf:probs_{size}"]).max() < 2e-6, size
+    tr = Cm.load("dscnn_train_4020.npz")
+    if "tf:S:train_logits" in tr:
+        import dataclasses
+        blocks = D.net_def("S")
+        p, s = D.init_params(blocks, seed=int(tr["init_seed"]))
+        x = R.mfcc(R.synth_waveforms(tr["labels"].shape[0], seed=int(tr["S:wav_seed"])), dataclasses.replace(R.FRONTEND_4020, num_mfccs=10))
+        f = D.forward(blocks, p, s, x, True)
+        assert np.abs(f["logits"] - tr["tf:S:train_logits"]).max() < 2e-5
+        g = D.backward(blocks, p, f, tr["labels"])
+        for k in [k for k in tr if k.startswith("tf:S:grad:")]:
+            ref = tr[k]
+            assert np.abs(g[k[len("tf:S:grad:"):]].reshape(ref.shape) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), k
+        m = {k: np.zeros_like(v) for k, v in p.items()}
+        v2 = {k: np.zeros_like(v) for k, v in p.items()}
+        for t in (1, 2, 3):
+            D.train_step(blocks, p, s, m, v2, x, tr["labels"], 5e-4, t)
+            if t in (1, 3):
+                for k in p:     # Adam's first steps move every entry by ~lr: entries whose gradient sign is undetermined in f32 may differ by 2 lr
+                    assert np.abs(p[k] - tr[f"tf:S:param{t}:" + k].reshape(p[k].shape)).max() < 2.5 * 5e-4 * t, (t, k)
+                for k in s:
+                    assert np.abs(s[k] - tr[f"tf:S:stat{t}:" + k].reshape(s[k].shape)).max() < 1e-4, (t, k)
+
+
+def test_frontend_deploy_against_pinned_reference():
+    """Deploy-path MFCC (audio_spectrogram + mfcc ops): `mfcc_deploy` of the front-end fixtures IS the restatement's output until
+    pin_from_reference.py::pin_frontend overwrites it with the reference's (it then marks the fixture with `tf:pinned`).  Either way the
+    restatement must reproduce the stored rows; pinned, this is the parity check of SURVEY 8(f) #3."""
+    pinned = 0
+    for tag in ("3010", "4020"):
+        fx = Cm.load(f"frontend_{tag}.npz")
+        if "mfcc_deploy" not in fx:
+            continue
+        pinned += int("tf:pinned" in fx)
+        got = R.mfcc_deploy(fx["wav"], Cm.frontend_cfg(fx["win"], fx["hop"]))
+        assert np.abs(got - fx["mfcc_deploy"]).max() < (1e-3 if "tf:pinned" in fx else 1e-9), tag
+    if not pinned:
+        pytest.skip("parity unpinned: the deploy-path rows are the restatement's own (no tf:pinned marker in the front-end fixtures)")
+
+
 def test_float32_oracle_error_budget():
     """The f32 restatement stays within the 1e-4 logit budget of the f64 one (sets the tolerance's meaning)."""
     arch = R.make_tcresnet("TCResNet8", 1.0)
