@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     constexpr int NMEL = 64, NSEG = NMEL + 1;
     constexpr int XLD = 17;                 // padded row of the 16x16 transpose tile
     constexpr int UNIT = 16 * XLD;
-    constexpr int PLD = NBINS + 31;         // row stride = 32 (mod 64) banks: the two frames of a wave never collide
+    constexpr int PLD = NBINS + (LPF >= 32 ? 31 : 15);      // row stride: 16 lanes per frame put TWO frames into a 32-lane ds_read_b32 / ds_write_b32 group
+                                            // (banks are mod 32 for these): their rows sit 16 banks apart (stride = 16 mod 32) and a trip's items
+                                            // start in distinct bins mod 16; at 32 lanes per frame a group is one frame (distinct mod 32)
     constexpr int kMelItemBins = mel_item_bins(NC);
     constexpr bool kItemsLds = QV >= 15;    // mel item descriptors read from LDS per trip instead of held in registers (see kDctPre)
     constexpr int LMS = 80;                 // log-mel row stride, = 16 (mod 32): the DCT's MFMA B fragment reads 32 distinct banks
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
                 v2 ud = (v2){0.f, 0.f};
 #pragma unroll
                 for (int b = 0; b < kMelItemBins; ++b) ud = __builtin_elementwise_fma(wv[b], (v2){p[b], p[b]}, ud);
-                UD[it] = ud;
+                UD[(d >> 21) & 255] = ud;                    // (the slot's LOGICAL item: the log phase adds a band's items in logical order)
             }
             if (nitems > NIT) {                             // (filterbanks with more items than the trips cover: slow path)
                 const float fold = MAG ? 0.5f : 0.25f;

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "frontend_plan.h"
@@ -201,14 +202,86 @@ extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_pl
             }
         }
         ifirst[L.nseg] = n; ifirst[L.nseg + 1] = n;
-        const int nfast = mel_items_fast(L.nc);
-        for (int i = 0; i < n && i < nfast; ++i) {
-            const int k0 = items[i] & 1023, nb = (items[i] >> 10) & 15;
-            for (int b = 0; b < nb; ++b) {
-                w[L.mel_wit + 2 * ((size_t)b * nfast + i)] = w[L.wud + 2 * (k0 + b)];
-                w[L.mel_wit + 2 * ((size_t)b * nfast + i) + 1] = w[L.wud + 2 * (k0 + b) + 1];
+        // PHYSICAL order and read bases of the items the unrolled trips take (slot = lane + lanes-per-frame * trip).  In logical
+        // (ascending-bin) order the 32 lanes of a ds_read_b32 group start their item 2-8 bins apart, i.e. three to five of them on every
+        // LDS bank (banks are mod 32 for these reads): the sparse-mel reads were 3-way conflicted (31 % of the kernel's LDS cycles,
+        // profiles/r03_final_pmc.csv).  Here a trip holds at most one item per start class (read base mod 32; mod 16 at 16 lanes per
+        // frame, where a lane group holds two frames whose rows sit 16 banks apart), so its 8 (4) reads -- constant offsets from the
+        // base -- are conflict-free.  The freedom that makes this a perfect matching for the reference filterbanks (91 / 91 and 89 / 89
+        // items): an item shorter than the trip's 8 (4) bins may start its reads up to (8 - bins) bins EARLY, the leading bins meeting
+        // zero slopes.  Maximum bipartite matching items -> (class, trip) by augmenting paths; what stays unmatched (other filterbanks)
+        // takes a free slot at its natural base.  A slot's descriptor carries the item's LOGICAL index (bits 21+): the item sums are
+        // stored, and read by the log phase, in logical order.
+        const int nfast = mel_items_fast(L.nc), lpf = L.nc / 16, trips = mel_trips(L.nc);
+        const int classes = lpf >= 32 ? 32 : 16;
+        const int nf = std::min(n, nfast);
+        std::vector<int32_t> logical(items, items + n);
+        std::vector<int> owner(classes * trips, -1);            // (class, trip) -> item
+        std::vector<int> slot_of(nf, -1);                       // item -> class * trips + trip
+        auto allowed = [&](int i, int c) {                      // can item i read from a base of class c?  (-1: no; else the base)
+            const int k0 = logical[i] & 1023, nb = (logical[i] >> 10) & 15;
+            for (int d = 0; d <= kMelItemBins - nb && k0 - d >= 0; ++d)
+                if ((k0 - d) % classes == c) return k0 - d;
+            return -1;
+        };
+        std::vector<char> seen;
+        std::function<bool(int)> place = [&](int i) -> bool {
+            for (int c = 0; c < classes; ++c) {
+                if (allowed(i, c) < 0) continue;
+                for (int t = 0; t < trips; ++t) {
+                    const int sidx = c * trips + t;
+                    if (seen[sidx]) continue;
+                    seen[sidx] = 1;
+                    if (owner[sidx] < 0 || place(owner[sidx])) { owner[sidx] = i; slot_of[i] = sidx; return true; }
+                }
+            }
+            return false;
+        };
+        for (int i = 0; i < nf; ++i) { seen.assign(classes * trips, 0); (void)place(i); }
+        // lanes of a trip: the 16-lane halves of the sum store (ds_write_b64: 16-lane groups) prefer distinct logical indices mod 16
+        std::vector<int> phys(nfast, -1), base_of(nf, 0);
+        std::vector<int> fill(trips, 0);
+        std::vector<std::vector<int>> trip_items(trips);
+        for (int i = 0; i < nf; ++i)
+            if (slot_of[i] >= 0 && owner[slot_of[i]] == i) { trip_items[slot_of[i] % trips].push_back(i); base_of[i] = allowed(i, slot_of[i] / trips); }
+        std::vector<int> leftovers;
+        for (int i = 0; i < nf; ++i)
+            if (!(slot_of[i] >= 0 && owner[slot_of[i]] == i)) { leftovers.push_back(i); base_of[i] = logical[i] & 1023; }
+        for (int t = 0; t < trips; ++t) {
+            std::vector<int>& v = trip_items[t];
+            while ((int)v.size() < lpf && !leftovers.empty()) { v.push_back(leftovers.back()); leftovers.pop_back(); }
+            TCR_REQUIRE((int)v.size() <= lpf, "front-end: mel item matching overfilled a trip");
+            std::vector<int> lanes(lpf, -1);
+            std::vector<char> used16(lpf, 0);                   // [half * 16 + residue]
+            std::vector<int> later;
+            for (int i : v) {                                   // first pass: a half whose residue class is still free
+                bool done = false;
+                for (int h = 0; h < lpf / 16 && !done; ++h) {
+                    if (used16[h * 16 + i % 16]) continue;
+                    for (int l = h * 16; l < h * 16 + 16; ++l)
+                        if (lanes[l] < 0) { lanes[l] = i; used16[h * 16 + i % 16] = 1; done = true; break; }
+                }
+                if (!done) later.push_back(i);
+            }
+            for (int i : later)
+                for (int l = 0; l < lpf; ++l)
+                    if (lanes[l] < 0) { lanes[l] = i; break; }
+            for (int l = 0; l < lpf; ++l) phys[t * lpf + l] = lanes[l];
+        }
+        TCR_REQUIRE(leftovers.empty(), "front-end: mel item slots exhausted");
+        constexpr int kDummyItem = 255;             // logical index of an empty slot: a cell of the item-sum arrays nobody reads
+        for (int slot = 0; slot < nfast; ++slot) {
+            const int i = phys[slot];
+            if (i < 0) { items[slot] = kDummyItem << 21; continue; }
+            const int k0 = logical[i] & 1023, nb = (logical[i] >> 10) & 15, kb = base_of[i];
+            items[slot] = kb | (nb << 10) | (logical[i] & (127 << 14)) | (i << 21);        // (bin field = the READ BASE, <= the item's first bin)
+            for (int b = 0; b < kMelItemBins; ++b) {
+                const bool in = kb + b >= k0 && kb + b < k0 + nb;
+                w[L.mel_wit + 2 * ((size_t)b * nfast + slot)] = in ? w[L.wud + 2 * (kb + b)] : 0.f;
+                w[L.mel_wit + 2 * ((size_t)b * nfast + slot) + 1] = in ? w[L.wud + 2 * (kb + b) + 1] : 0.f;
             }
         }
+        for (int i = nfast; i < n; ++i) items[i] = (logical[i] & ((1 << 21) - 1)) | (i << 21);      // (slow path: logical == physical, true first bin)
     }
     // DCT-II as MFMA A fragments (coefficient tile ct, k-step s over the mel index)
     for (int ct = 0; ct < nm / 16; ++ct)

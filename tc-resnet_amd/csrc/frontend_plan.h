@@ -19,7 +19,8 @@ struct FrontendPlanLayout {
     size_t dcth;       // float  [n_coef][n_mel/2]   DCT-II rows folded by the even/odd symmetry
     // Sparse mel for the packed kernel, load-balanced: every mel-edge segment is cut into items of <= mel_item_bins(nc) bins, one
     // lane per item (a segment's bins used to be one lane's loop: 2 .. 20 bins, the wave waited for the longest).
-    size_t mel_items;  // int32  [kMelItemsMax]   first bin | bins << 10 | segment << 14
+    size_t mel_items;  // int32  [kMelItemsMax]   first bin | bins << 10 | segment << 14 | logical item index << 21; slots < mel_items_fast() in the
+                       //        bank-conflict-free PHYSICAL order of the unrolled trips (frontend_plan.cpp), the rest in logical order
     size_t mel_ifirst; // int32  [nseg + 2]       first item of segment j; [nseg] = [nseg + 1] = number of items
     size_t mel_wit;    // float2 [mel_item_bins][mel_items_fast]  (up, down) slopes of bin b of item i, zero past the item's end and for
                        //                        items the filterbank does not have: the kernel's LDS copy (bin-major: a trip's lanes read
