@@ -1538,20 +1538,32 @@ static int backward_lazy(const TrainCtx& c, float* grads, const LevelPlan* plan)
     } else {
         TCR_TRY(lazy_last_block_sums(c, lastb.b, c.s));
         if (lastb.down >= 0) TCR_TRY(lazy_last_block_sums(c, lastb.down, c.s));
+        // A fork (event record on the main chain) per BN unit.  An event record between two kernels costs ~6 us of dispatch gap (the
+        // forward, which records none, shows none), so ONE fork per block was tried -- the fork behind (conv_b, shortcut)'s finalize also
+        // releasing the previous block's conv_a filter gradient: TCResNet8 975 vs 949 us per step, 98 frames 1492 vs 1443 -- SLOWER: the
+        // filter gradients that start ~70 us later end later, and the step is bound by the total work of all streams, not by the main
+        // chain's gaps.  Kept behind TCR_TUNE_WGRAD_STREAM = 3.
+        const bool fork_per_unit = tune_get(TCR_TUNE_WGRAD_STREAM) != 3 || !multi;
+        int pending_a = -1;                                 // conv_a whose filter gradient waits for the next fork
         for (int bi = nb - 1; bi >= 0; --bi) {
             const Block& b = net->blocks[bi];
-            if (b.down >= 0) {
-                TCR_TRY(launch_bn_bwd_finalize2(lazy_finalize_args(c, b.b, grads), lazy_finalize_args(c, b.down, grads), c.s));
-                // the shortcut's filter gradient first: conv_b's is the longer one and nothing waits for either  (A/B: the shortcut's on
-                // conv_a's stream instead: 995 vs 950 us per TCResNet8 step, 1517 vs 1448 at 98 frames -- it delays conv_a's)
-                TCR_TRY(fork(s_b));
-                TCR_TRY(lazy_wgrad(c, b.down, s_b));
-                TCR_TRY(lazy_wgrad(c, b.b, s_b));
-                TCR_TRY(launch_d(lazy_args_b(c, bi)));
-            } else {
-                TCR_TRY(finish_unit(b.b, true));
+            if (b.down >= 0) TCR_TRY(launch_bn_bwd_finalize2(lazy_finalize_args(c, b.b, grads), lazy_finalize_args(c, b.down, grads), c.s));
+            else TCR_TRY(launch_bn_bwd_finalize(lazy_finalize_args(c, b.b, grads), c.s));
+            // the shortcut's filter gradient first: conv_b's is the longer one and nothing waits for either  (A/B: the shortcut's on
+            // conv_a's stream instead: 995 vs 950 us per TCResNet8 step, 1517 vs 1448 at 98 frames -- it delays conv_a's)
+            TCR_TRY(fork(s_b));
+            if (b.down >= 0) TCR_TRY(lazy_wgrad(c, b.down, s_b));
+            TCR_TRY(lazy_wgrad(c, b.b, s_b));
+            if (pending_a >= 0) {                           // (ordered behind the same record: s_a waits for the event s_b waits for)
+                if (s_a != s_b && hipStreamWaitEvent(s_a, net->ev_fork, 0) != hipSuccess) { set_error("tcr_net_backward: stream fork failed"); return TCR_ERR_HIP; }
+                TCR_TRY(lazy_wgrad(c, pending_a, s_a));
+                pending_a = -1;
             }
-            TCR_TRY(finish_unit(b.a, true));
+            TCR_TRY(launch_d(lazy_args_b(c, bi)));
+            TCR_TRY(launch_bn_bwd_finalize(lazy_finalize_args(c, b.a, grads), c.s));
+            if (fork_per_unit || bi == 0) { TCR_TRY(fork(s_a)); TCR_TRY(lazy_wgrad(c, b.a, s_a)); }
+            else pending_a = b.a;
+            TCR_TRY(launch_d(lazy_args_a(c, bi)));
         }
         TCR_TRY(finish_unit(0, true));
     }
