@@ -398,7 +398,7 @@ const char* tcr_kernel_name(int index);
 enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the shape fits, 1: scalar-fed VALU conv, 2: as 0 */
        TCR_TUNE_FRONTEND = 1,    /* 0 / 5: packed-FP32 kernel (default); 1..4: scalar-FP32 kernel, variant (v-1): bit0 wave-local phase ordering, bit1 sample prefetch */
        TCR_TUNE_CONV_B = 2,      /* MFMA conv activations: 0 straight from global/L1 (default), 1 via an LDS image; 3: wide 1x1 convs on the register-fed kernel instead of the LDS-tiled one, DS-CNN conv_1 not fused with the first depthwise layer */
-       TCR_TUNE_NET_FUSED = 3,   /* eval forward: 0 one fused LDS-resident kernel for the whole net (default; layers of the flagship shapes run compile-time-specialised), 1 per-layer kernels, 2 fused with the features copied to LDS, 3 fused, generic layer walk only */
+       TCR_TUNE_NET_FUSED = 3,   /* eval forward: 0 one fused LDS-resident kernel for the whole net (default; layers of the flagship shapes run compile-time-specialised), 1 per-layer kernels, 2 fused with the features copied to LDS, 3 fused, generic layer walk only, 4 the round-2 static-shape layer, 7 fused without the bank-aligned utterance strides (A/B arm) */
        TCR_TUNE_FUSED_GROUP = 4, /* utterances per workgroup group of the fused kernel (0: largest that fits 64 KB of LDS) */
        TCR_TUNE_FUSED_WAVES = 5, /* fused kernel: waves per workgroup (4, 8, 16) + 100 * weight-ring depth (4, 8, 16); 0: default */
        TCR_TUNE_CONV_KSPLIT = 6, /* train-mode conv / data-gradient: waves sharing one 32-position group's reduction (0 auto, 1, 2, 4) */
@@ -414,7 +414,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_WGRAD_TILES = 16, /* 9-tap filter gradients (16-byte-load kernel): output-channel tiles per launch (0: default 3; a layer of more tiles is split into launches that share one slab) */
        TCR_TUNE_DOWN_DGRAD = 17,  /* TC-ResNet backward, a block's 1x1 shortcut conv: 0 its data gradient runs early on the side stream and writes the block-input gradient first, conv_a's adds onto it (default for nets of <= 48 channels, where it measured faster; 2: for every net); 1 conv_a's first, the shortcut's added behind it on the main stream (bitwise the same sums: one addition, commuted) */
        TCR_TUNE_BWD_LAZY_CFG = 18, /* lazy backward geometry: utterances per group + 100 * waves per job (0: cost model) + 10000 * (out channels * 10 + layers) to address one kernel of the net */
-       TCR_TUNE_COUNT = 19 };
+       TCR_TUNE_PHASE_STATIC = 19, /* training forward phases of TCResNet8-1.0 / TCResNet14-1.5 at 49 / 98 frames: 0 compile-time-shaped kernels, utterance stride in LDS padded to the bank pattern (default); bit 0: generic layer walk; bit 1: unpadded stride (A/B arms, all bitwise) */
+       TCR_TUNE_COUNT = 20 };
 int tcr_tune(int knob, int value);
 
 /* The library's internal streams (hipStream_t), one set per device and process.  HIP multiplexes streams onto a few hardware queues

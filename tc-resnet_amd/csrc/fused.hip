@@ -39,8 +39,8 @@ __device__ __forceinline__ void fused_layer(const FusedArgs& a, const FusedLayer
     const int tpi = L.tin + 2 * kHalo, tpo = L.tout + 2 * kHalo;
     float* yout = lds + a.buf_off[L.out_buf];
     const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
-    const int out_sz = a.buf_sz[L.out_buf];
-    const int res_sz = L.res_buf >= 0 ? a.buf_sz[L.res_buf] : 0;
+    const int out_sz = L.out_sz;
+    const int res_sz = L.res_sz;
     const int npos = ng * L.tout;
     const int ncp = (npos + 31) / 32;               // column pairs (32 positions)
     const int nrt = (L.cout + 15) / 16;             // row tiles (16 output channels)
@@ -149,8 +149,8 @@ __device__ __forceinline__ void fused_layer_t(const FusedArgs& a, const FusedLay
     static_assert(CIN % 4 == 0, "channel quads");
     float* yout = lds + a.buf_off[L.out_buf];
     const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
-    const int out_sz = a.buf_sz[L.out_buf];
-    const int res_sz = L.res_buf >= 0 ? a.buf_sz[L.res_buf] : 0;
+    const int out_sz = L.out_sz;
+    const int res_sz = L.res_sz;
     const int npos = ng * TOUT;
     const int ncp = (npos + 31) / 32;
     const float* w = a.params + L.w_off;
@@ -254,16 +254,23 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
     static_assert(CIN % 4 == 0, "channel quads");
     float* yout = lds + a.buf_off[L.out_buf];
     const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
-    const int out_sz = a.buf_sz[L.out_buf];
-    const int res_sz = L.res_buf >= 0 ? a.buf_sz[L.res_buf] : 0;
+    const int out_sz = L.out_sz;
+    const int res_sz = L.res_sz;
     const int npos = ng * TOUT;
     const int ncp = (npos + 31) / 32;
     const float* w = a.params + L.w_off;
     const float* scale = a.ss + L.ss_off;
     const float* shift = scale + L.c_pad;
+    // Which of a job's 32 positions a lane's two tile columns hold (the columns of the implicit GEMM are independent: any assignment
+    // gives the same sums).  One ds_read_b32 serves lanes (q, q + 1) x 16 columns against 32 banks: with stride 2 consecutive columns
+    // are 2 floats apart and the odd row pitch puts row q + 1 on the other bank parity; with stride 1 the columns of a tile are every
+    // OTHER position (tile 0 the even, tile 1 the odd ones) for the same picture.  The host pads the per-utterance stride so that the
+    // pattern continues across the utterances of a group (net.cpp: fused_strides).  PMC, TCResNet8 at 49 frames: see OPTLOG.md.
+    constexpr bool IL = S == 1;
     for (int job = wave; job < ncp * NRT; job += NW) {
         const int cp = job / NRT, m = job - cp * NRT;
-        const int p0 = min(cp * 32 + r, npos - 1), p1 = min(cp * 32 + 16 + r, npos - 1);
+        const int c0 = IL ? cp * 32 + 2 * r : cp * 32 + r, c1 = IL ? c0 + 1 : c0 + 16;
+        const int p0 = min(c0, npos - 1), p1 = min(c1, npos - 1);
         const int g0 = p0 / TOUT, g1 = p1 / TOUT;
         const int t0 = p0 - g0 * TOUT, t1 = p1 - g1 * TOUT;
         const float* wp = w + q * COUT + min(m * 16 + r, COUT - 1);
@@ -328,7 +335,7 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const bool pv = cp * 32 + nt * 16 + r < npos;
+            const bool pv = (nt == 0 ? c0 : c1) < npos;
             const int g = nt == 0 ? g0 : g1, t = nt == 0 ? t0 : t1;
             const f32x4 ac = nt == 0 ? acc0 : acc1;
             const int base = g * out_sz + kHalo + t;
@@ -360,7 +367,7 @@ __device__ __forceinline__ void fused_conv0_s(const FusedArgs& a, const FusedLay
     constexpr int TPI = T0 + 2 * kHalo, TPO = TPI, TOUT = T0, PADLO = 1;
     constexpr int WSTEP = 4 * COUT, XSTEP = 4 * TPI;
     float* yout = lds + a.buf_off[L.out_buf];
-    const int out_sz = a.buf_sz[L.out_buf];
+    const int out_sz = L.out_sz;
     const int npos = ng * TOUT;
     const int nct = (npos + 15) / 16;
     const float* w = a.params + L.w_off;
@@ -413,7 +420,7 @@ __device__ __forceinline__ void fused_head_s(const FusedArgs& a, float* lds, con
     static_assert(FC % 4 == 0 && NCLS + 2 <= 16, "one 16-row MFMA tile holds the logits and the two range outputs");
     constexpr int TP = FT + 2 * kHalo;
     const float* fb = lds + a.buf_off[a.feat_buf];
-    const int fsz = a.buf_sz[a.feat_buf];
+    const int fsz = a.feat_sz;
     float* pooled = lds + a.buf_off[(a.feat_buf + 1) % 3];
     const int lane = tid & 63, r = lane & 15, q = lane >> 4;
     // wave 0: the weight fragments are requested before the pooling phase (their latency hides behind it)
@@ -505,7 +512,7 @@ template <int NT>
 __device__ __forceinline__ void fused_head(const FusedArgs& a, float* lds, const int n0, const int ng, const int tid) {
     {
         const float* fb = lds + a.buf_off[a.feat_buf];
-        const int fsz = a.buf_sz[a.feat_buf], tp = a.feat_t + 2 * kHalo;
+        const int fsz = a.feat_sz, tp = a.feat_t + 2 * kHalo;
         float* pooled = lds + a.buf_off[(a.feat_buf + 1) % 3];         // any buffer other than the feature buffer
         for (int i = tid; i < ng * a.feat_c; i += NT) {
             const int g = i / a.feat_c, c = i - g * a.feat_c;
@@ -564,7 +571,7 @@ __device__ __forceinline__ void fused_layer_sel(const FusedArgs& a, const FusedL
                                                 float* lds, const int ng, const int wave, const int r, const int q) {
     if constexpr (WD < 0) fused_layer_t<NW, K, S, CIN, COUT, TIN>(a, L, xin, in_sz, lds, ng, wave, r, q);
     else {
-        if constexpr (HALO) fused_zero_halo<NW * 64, COUT, (TIN + S - 1) / S>(lds + a.buf_off[L.out_buf], a.buf_sz[L.out_buf], ng, (int)threadIdx.x);
+        if constexpr (HALO) fused_zero_halo<NW * 64, COUT, (TIN + S - 1) / S>(lds + a.buf_off[L.out_buf], L.out_sz, ng, (int)threadIdx.x);
         fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES>(a, L, xin, in_sz, lds, ng, wave, r, q);
     }
 }
@@ -584,13 +591,13 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
 #else
 #define TCR_TC8_BARRIER __syncthreads()
 #endif
-#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9), (K_ != 1 && LI != 9)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.buf_sz[a.layer[LI].in_buf], lds, ng, wave, r, q)
+#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9), (K_ != 1 && LI != 9)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, ng, wave, r, q)
     for (int grp = blockIdx.x; grp < (TCR_WHATIF(512) ? 0 : a.n_groups); grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
         if constexpr (WD < 0) fused_layer_sel<NW, 3, 1, 40, 16, T0, WD, false>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
         else if (!TCR_WHATIF(64)) {
-            fused_zero_halo<NT, 16, T0>(lds + a.buf_off[a.layer[0].out_buf], a.buf_sz[a.layer[0].out_buf], ng, tid);
+            fused_zero_halo<NT, 16, T0>(lds + a.buf_off[a.layer[0].out_buf], a.layer[0].out_sz, ng, tid);
             fused_conv0_s<NW, T0>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
         }
         TCR_TC8_BARRIER;
@@ -633,11 +640,11 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc14w_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int row = a.in_c * a.in_tp;
-#define TCR_L(LI, K_, S_, CI_, CO_, T_, RES_, HALO_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, 0, RES_, HALO_>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.buf_sz[a.layer[LI].in_buf], lds, ng, wave, r, q)
+#define TCR_L(LI, K_, S_, CI_, CO_, T_, RES_, HALO_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, 0, RES_, HALO_>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, ng, wave, r, q)
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
-        fused_zero_halo<NT, 24, T0>(lds + a.buf_off[a.layer[0].out_buf], a.buf_sz[a.layer[0].out_buf], ng, tid);
+        fused_zero_halo<NT, 24, T0>(lds + a.buf_off[a.layer[0].out_buf], a.layer[0].out_sz, ng, tid);
         fused_conv0_g<NW>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
         __syncthreads();
         TCR_L(1, 1, 2, 24, 36, T0, false, false);       // block0: shortcut conv + first conv (same input rows: one phase)
@@ -729,7 +736,7 @@ __device__ __forceinline__ void fused_conv0_g(const FusedArgs& a, const FusedLay
     const int cout = L.cout, tout = L.tout, tpi = L.tin + 2 * kHalo, tpo = tout + 2 * kHalo;
     const int wstep = 4 * cout, xstep = 4 * tpi;
     float* yout = lds + a.buf_off[L.out_buf];
-    const int out_sz = a.buf_sz[L.out_buf];
+    const int out_sz = L.out_sz;
     const int npos = ng * tout;
     const int nct = (npos + 15) / 16, nrt = (cout + 15) / 16;
     const float* w = a.params + L.w_off;
@@ -784,7 +791,7 @@ __device__ __forceinline__ void fused_head_g(const FusedArgs& a, float* lds, con
     const int fc = a.feat_c, ft = a.feat_t, nc = a.nc;
     const int tp = ft + 2 * kHalo;
     const float* fb = lds + a.buf_off[a.feat_buf];
-    const int fsz = a.buf_sz[a.feat_buf];
+    const int fsz = a.feat_sz;
     float* pooled = lds + a.buf_off[(a.feat_buf + 1) % 3];
     const int lane = tid & 63, r = lane & 15, q = lane >> 4;
     const float inv_fc = 1.0f / (float)fc;
@@ -874,12 +881,12 @@ __global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
 
         for (int li = 0; li < a.n_layers; ++li) {
             const FusedLayer L = a.layer[li];
-            fused_zero_halo_g<NT>(lds + a.buf_off[L.out_buf], a.buf_sz[L.out_buf], ng, L.cout, L.tout, tid);
+            fused_zero_halo_g<NT>(lds + a.buf_off[L.out_buf], L.out_sz, ng, L.cout, L.tout, tid);
             if (li == 0 && a.in_global) {
                 if (L.k == 3 && L.cin == 40 && L.stride == 1 && L.pad_lo == 1) fused_conv0_g<NW>(a, L, a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
                 else fused_layer<NW, R>(a, L, a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
             } else {
-                fused_layer<NW, R>(a, L, lds + a.buf_off[L.in_buf], a.buf_sz[L.in_buf], lds, ng, wave, r, q);
+                fused_layer<NW, R>(a, L, lds + a.buf_off[L.in_buf], L.in_sz, lds, ng, wave, r, q);
             }
             if (!L.no_barrier) __syncthreads();         // (a block's shortcut conv and its first conv read the same input: one phase)
         }

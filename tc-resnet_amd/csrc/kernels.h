@@ -177,6 +177,9 @@ struct FusedLayer {
     int in_buf, out_buf, res_buf;       // LDS buffer ids (res_buf < 0: none)
     int w_off, ss_off, c_pad;           // float offsets into params / scale-shift table
     int no_barrier;                     // the next layer reads the same input and writes another buffer: no s_barrier in between
+    // floats per utterance of this layer's input / output / shortcut rows (<= buf_sz of the buffer): the host pads the stride of a
+    // layer's output so that the 32 lanes of one LDS read of its consumer fall into 32 distinct banks (net.cpp: fused_strides)
+    int in_sz, out_sz, res_sz;
 };
 
 struct FusedArgs {
@@ -192,6 +195,7 @@ struct FusedArgs {
     int in_c, in_tp;            // feature rows: channels x padded length
     int feat_buf;               // buffer holding the last block output
     int feat_c, feat_t, nc;
+    int feat_sz;                // floats per utterance of the last block output
     int fc_off, fc2_off;
     int in_global;              // the first layer reads the feature rows straight from global memory (no LDS copy)
     FusedLayer layer[kFusedMaxLayers];

@@ -393,6 +393,34 @@ static int forward_infer_fused(const tcr_net& net, const float* params, const fl
         ok &= add(b.b, 2, 1, b.down >= 0 ? 0 : 1);
     }
     if (!ok || net.param_floats >= (int64_t)1 << 31) return 1;
+    // Per-utterance stride of every layer's output rows.  One LDS read of a consumer conv serves 2 input channels x 16 columns
+    // (fused.hip: fused_layer_s); within an utterance the 16 columns are 2 floats apart (stride 2: consecutive positions; stride 1:
+    // every other position), and with out_sz = 2 * T_out(consumer) (stride 2) or T_in (stride 1) modulo 32 the column -> bank
+    // pattern runs on unbroken into the next utterance of the group: 32 lanes, 32 banks.  (<= 31 floats of pad per utterance and
+    // buffer; knob TCR_TUNE_NET_FUSED = 7: no padding, the A/B arm.)
+    const bool pad_strides = tune_get(TCR_TUNE_NET_FUSED) != 7;
+    for (int i = 0; i < a.n_layers; ++i) {
+        FusedLayer& P = a.layer[i];
+        int need = (int)align_up((int64_t)P.cout * tcr_padded_len(P.tout), 4), want = -1;
+        for (int j = i + 1; j < a.n_layers; ++j) {
+            const FusedLayer& C = a.layer[j];
+            if (C.in_buf == P.out_buf && want < 0) want = C.stride == 2 ? 2 * C.tout : C.stride == 1 ? C.tin : -1;
+            if (C.out_buf == P.out_buf) break;              // overwritten: no later reader
+        }
+        if (pad_strides && want >= 0) while ((need - want) % 32 != 0) ++need;
+        if (P.res_buf == P.out_buf)                         // identity shortcut, updated in place: the stride of the rows it adds onto
+            for (int j = i - 1; j >= 0; --j) if (a.layer[j].out_buf == P.out_buf) { need = a.layer[j].out_sz; break; }
+        P.out_sz = need;
+        if (need > sz[P.out_buf]) sz[P.out_buf] = need;
+    }
+    const int feat_row = a.layer[0].cin * tcr_padded_len(a.layer[0].tin);
+    for (int i = 0; i < a.n_layers; ++i) {
+        FusedLayer& C = a.layer[i];
+        C.in_sz = feat_row; C.res_sz = 0;
+        for (int j = i - 1; j >= 0; --j) if (a.layer[j].out_buf == C.in_buf) { C.in_sz = a.layer[j].out_sz; break; }
+        if (C.res_buf >= 0) for (int j = i - 1; j >= 0; --j) if (a.layer[j].out_buf == C.res_buf) { C.res_sz = a.layer[j].out_sz; break; }
+    }
+    a.feat_sz = a.layer[a.n_layers - 1].out_sz;
     const int per_utt = sz[0] + sz[1] + sz[2];
     // Policy (scripts/fused_sweep.py, B = 4096, TCResNet8-1.0 / TCResNet14-1.5 at 49 and 98 frames): the largest group of
     // up to 8 utterances whose activations fit the CU's 160 KB of LDS (more positions per layer = fuller MFMA tiles and

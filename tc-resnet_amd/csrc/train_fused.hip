@@ -52,7 +52,9 @@ __device__ __forceinline__ void phase_layer(const TrainPhaseArgs& a, const Phase
         if (own) { cp = wave / nrt + it * cp_step; m = m_own; if (cp >= ncp) break; }
         else { const int job = wave + it * NW; if (job >= ncp * nrt) break; cp = job / nrt; m = job - cp * nrt; }
         const int aidx = q * L.cout + min(m * 16 + r, L.cout - 1);
-        const int p0 = min(cp * 32 + r, npos - 1), p1 = min(cp * 32 + 16 + r, npos - 1);
+        // which of the job's 32 positions this lane's two columns hold: see phase_layer_s
+        const int c0 = L.stride == 1 ? cp * 32 + 2 * r : cp * 32 + r, c1 = L.stride == 1 ? c0 + 1 : c0 + 16;
+        const int p0 = min(c0, npos - 1), p1 = min(c1, npos - 1);
         const int g0 = (int)(((float)p0 + 0.5f) * inv_tout), g1 = (int)(((float)p1 + 0.5f) * inv_tout);
         const int t0 = p0 - g0 * L.tout, t1 = p1 - g1 * L.tout;
         const int xo0 = g0 * a.in_sz + q * tpi + t0 * L.stride + kHalo - L.pad_lo;
@@ -86,7 +88,7 @@ if (++c4 == C4) { c4 = 0; off = ++j; }                                          
             if (s0 + i < nsteps) TCR_PHASE_STEP(ar[i], )
 #undef TCR_PHASE_STEP
         // ---- epilogue: raw output -> global (interior only), per-channel sums of this job's valid positions ----
-        const bool v0 = cp * 32 + r < npos, v1 = cp * 32 + 16 + r < npos;
+        const bool v0 = c0 < npos, v1 = c1 < npos;
         float s1[4], s2[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -139,29 +141,14 @@ if (++c4 == C4) { c4 = 0; off = ++j; }                                          
     }
 }
 
-template <int NW, int R>
-__global__ __launch_bounds__(NW * 64) void train_phase_kernel(const TrainPhaseArgs a) {
-    constexpr int NT = NW * 64;
-    float* lds = reinterpret_cast<float*>(dyn_lds());
-    float* stat = lds + a.stat_off;                        // [NW][n_layers][2][cstat]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, q = lane >> 4;
+// Staging: build the input activation of the group's `ng` utterances (contiguous rows in global memory) in LDS, and materialise it
+// for backward.  SU elements per thread and trip: all their loads are issued before the first dependent use (a one-element loop
+// serialises a global round trip per element).  tp / row: padded row length and floats per utterance of the source rows.
+template <int NT>
+__device__ __forceinline__ void phase_stage(const TrainPhaseArgs& a, float* lds, const int n0, const int ng, const int tid, const int tp, const int row) {
     const PhaseSrc& S = a.src;
-    const int tp = S.t + 2 * kHalo;
-    const int row = S.c * tp;                              // floats per utterance of the source rows
     const float inv_tp = 1.0f / (float)tp;
-    const int nstat = NW * a.n_layers * 2 * a.cstat;
-    for (int i = tid; i < nstat; i += NT) stat[i] = 0.f;
-
-    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
-        const int n0 = grp * a.group;
-        const int ng = min(a.group, a.batch - n0);
-        __syncthreads();                                   // (previous group's convolutions are done with the LDS rows)
-        // ---- staging: build the input activation of the group (contiguous rows in global memory) ----
-        // SU elements per thread and trip: all their loads are issued before the first dependent use (a one-element loop
-        // serialises a global round trip per element).
+    {
         const size_t gbase = (size_t)n0 * row;
         const int total = ng * row;
         const float inv_row = 1.0f / (float)row;
@@ -200,6 +187,159 @@ __global__ __launch_bounds__(NW * 64) void train_phase_kernel(const TrainPhaseAr
                 if (S.kind == 2 && S.s_kind == 1 && S.out_s) S.out_s[gbase + i] = sv;
             }
         }
+    }
+}
+
+// The same layer with its shape known at COMPILE time (the phases of TCResNet8-1.0 and TCResNet14-1.5 at 49 / 98 frames), the K loop
+// of the eval kernel's static layer (fused.hip: fused_layer_s): taps rolled, a tap's weight fragments in two half-tap register sets that
+// are refilled for the next tap behind the other half's MFMAs, LDS operands at immediate offsets, division by constants.  Same job ->
+// wave dealing, same accumulation order, same order of the statistics sums: bitwise the generic layer.
+// Columns: one ds_read_b32 serves input channels (q, q + 1) x 16 columns against 32 banks.  With stride 2 consecutive positions are 2
+// floats apart and the odd row pitch puts channel q + 1 on the other bank parity; with stride 1 a tile's columns are every OTHER position
+// (tile 0 the even, tile 1 the odd ones of the job's 32) for the same picture; in_sz is padded so that the pattern runs on into the
+// next utterance of the group (configure_phase).
+template <int NW, int K, int S, int CIN, int COUT, int TIN>
+__device__ __forceinline__ void phase_layer_s(const TrainPhaseArgs& a, const PhaseLayer& L, const float* __restrict__ xin, float* wstat,
+                                              const int n0, const int ng, const int wave, const int r_in, const int q_in) {
+    const int oz = opaque_zero();          // (per-lane address arithmetic stays inside the group loop)
+    const int r = r_in + oz, q = q_in + oz;
+    constexpr int TOUT = (TIN + S - 1) / S;
+    constexpr int PADT = ((TOUT - 1) * S + K - TIN) > 0 ? ((TOUT - 1) * S + K - TIN) : 0;
+    constexpr int PADLO = PADT / 2;
+    constexpr int TPI = TIN + 2 * kHalo, TPO = TOUT + 2 * kHalo;
+    constexpr int C4 = CIN / 4, NRT = (COUT + 15) / 16;
+    constexpr int WSTEP = 4 * COUT, XSTEP = 4 * TPI;
+    constexpr bool IL = S == 1;
+    constexpr bool OWN = (NW % NRT) == 0;
+    constexpr int CP_STEP = OWN ? NW / NRT : 0;
+    static_assert(CIN % 4 == 0, "channel quads");
+    const int npos = ng * TOUT;
+    const int ncp = (npos + 31) / 32;
+    const float* w = a.params + L.w_off;
+    const int in_sz = a.in_sz;
+    float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int m_own = wave % NRT;
+    for (int it = 0;; ++it) {
+        int cp, m;
+        if (OWN) { cp = wave / NRT + it * CP_STEP; m = m_own; if (cp >= ncp) break; }
+        else { const int job = wave + it * NW; if (job >= ncp * NRT) break; cp = job / NRT; m = job - cp * NRT; }
+        const int c0 = IL ? cp * 32 + 2 * r : cp * 32 + r, c1 = IL ? c0 + 1 : c0 + 16;
+        const int p0 = min(c0, npos - 1), p1 = min(c1, npos - 1);
+        const int g0 = p0 / TOUT, g1 = p1 / TOUT;
+        const int t0 = p0 - g0 * TOUT, t1 = p1 - g1 * TOUT;
+        const float* wp = w + q * COUT + min(m * 16 + r, COUT - 1);
+        const float* x0 = xin + g0 * in_sz + q * TPI + t0 * S + kHalo - PADLO;
+        const float* x1 = xin + g1 * in_sz + q * TPI + t1 * S + kHalo - PADLO;
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int H0 = C4 / 2, H1 = C4 - H0;
+        float wa[H0 > 0 ? H0 : 1], wb[H1];
+#pragma unroll
+        for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[c4 * WSTEP];
+#pragma unroll
+        for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(H0 + c4) * WSTEP];
+#pragma unroll 1
+        for (int j = 0; j < K; ++j) {
+            const int jn = min(j + 1, K - 1);                           // (the last tap refills with itself: branch-free)
+            {
+                float b0[H0 > 0 ? H0 : 1], b1[H0 > 0 ? H0 : 1];
+#pragma unroll
+                for (int c4 = 0; c4 < H0; ++c4) { b0[c4] = x0[c4 * XSTEP + j]; b1[c4] = x1[c4 * XSTEP + j]; }
+#pragma unroll
+                for (int c4 = 0; c4 < H0; ++c4) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c4], b0[c4], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c4], b1[c4], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[(jn * C4 + c4) * WSTEP];
+            }
+            {
+                float b0[H1], b1[H1];
+#pragma unroll
+                for (int c4 = 0; c4 < H1; ++c4) { b0[c4] = x0[(H0 + c4) * XSTEP + j]; b1[c4] = x1[(H0 + c4) * XSTEP + j]; }
+#pragma unroll
+                for (int c4 = 0; c4 < H1; ++c4) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[c4], b0[c4], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[c4], b1[c4], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(jn * C4 + H0 + c4) * WSTEP];
+            }
+        }
+        // ---- epilogue: raw output -> global (interior only), per-channel sums of this job's valid positions ----
+        const bool v0 = c0 < npos, v1 = c1 < npos;
+        float s1[4], s2[4];
+        float* o0 = L.raw + ((size_t)(n0 + g0) * COUT + m * 16 + q * 4) * TPO + kHalo + t0;
+        float* o1 = L.raw + ((size_t)(n0 + g1) * COUT + m * 16 + q * 4) * TPO + kHalo + t1;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float y0 = v0 ? acc0[reg] : 0.f, y1 = v1 ? acc1[reg] : 0.f;
+            s1[reg] = y0 + y1;
+            s2[reg] = fmaf(y0, y0, y1 * y1);
+            if (COUT % 16 == 0 || m * 16 + q * 4 + reg < COUT) {
+                if (v0) o0[reg * TPO] = acc0[reg];
+                if (v1) o1[reg * TPO] = acc1[reg];
+            }
+        }
+        if (OWN) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { ps1[reg] += s1[reg]; ps2[reg] += s2[reg]; }
+            continue;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            s1[reg] = row16_sum(s1[reg]);
+            s2[reg] = row16_sum(s2[reg]);
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = m * 16 + q * 4 + reg;
+                if (COUT % 16 == 0 || co < COUT) {
+                    wstat[co] += s1[reg];
+                    wstat[a.cstat + co] += s2[reg];
+                }
+            }
+        }
+    }
+    if (OWN) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            ps1[reg] = row16_sum(ps1[reg]);
+            ps2[reg] = row16_sum(ps2[reg]);
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = m_own * 16 + q * 4 + reg;
+                if (COUT % 16 == 0 || co < COUT) {
+                    wstat[co] += ps1[reg];
+                    wstat[a.cstat + co] += ps2[reg];
+                }
+            }
+        }
+    }
+}
+
+template <int NW, int R>
+__global__ __launch_bounds__(NW * 64) void train_phase_kernel(const TrainPhaseArgs a) {
+    constexpr int NT = NW * 64;
+    float* lds = reinterpret_cast<float*>(dyn_lds());
+    float* stat = lds + a.stat_off;                        // [NW][n_layers][2][cstat]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const PhaseSrc& S = a.src;
+    const int tp = S.t + 2 * kHalo;
+    const int row = S.c * tp;                              // floats per utterance of the source rows
+    const int nstat = NW * a.n_layers * 2 * a.cstat;
+    for (int i = tid; i < nstat; i += NT) stat[i] = 0.f;
+
+    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+        const int n0 = grp * a.group;
+        const int ng = min(a.group, a.batch - n0);
+        __syncthreads();                                   // (previous group's convolutions are done with the LDS rows)
+        phase_stage<NT>(a, lds, n0, ng, tid, tp, row);
         if (a.n_layers == 0) continue;
         __syncthreads();
         for (int li = 0; li < a.n_layers; ++li)
@@ -219,11 +359,79 @@ __global__ __launch_bounds__(NW * 64) void train_phase_kernel(const TrainPhaseAr
     }
 }
 
+// A phase with compile-time layer shapes: CIN x TIN input rows, one or two (K1 > 0) convolutions over them (the host lists a block's
+// shortcut conv first).  Everything around the layers is the generic kernel's.
+template <int NW, int CIN, int TIN, int K0, int S0, int CO0, int K1, int S1, int CO1>
+__global__ __launch_bounds__(NW * 64) void train_phase_s_kernel(const TrainPhaseArgs a) {
+    constexpr int NT = NW * 64;
+    constexpr int NL = K1 > 0 ? 2 : 1;
+    constexpr int tp = TIN + 2 * kHalo, row = CIN * tp;
+    float* lds = reinterpret_cast<float*>(dyn_lds());
+    float* stat = lds + a.stat_off;                        // [NW][n_layers][2][cstat]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int nstat = NW * NL * 2 * a.cstat;
+    for (int i = tid; i < nstat; i += NT) stat[i] = 0.f;
+    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+        const int n0 = grp * a.group;
+        const int ng = min(a.group, a.batch - n0);
+        __syncthreads();
+        phase_stage<NT>(a, lds, n0, ng, tid, tp, row);
+        __syncthreads();
+        phase_layer_s<NW, K0, S0, CIN, CO0, TIN>(a, a.layer[0], lds, stat + (wave * NL + 0) * 2 * a.cstat, n0, ng, wave, r, q);
+        if constexpr (K1 > 0) phase_layer_s<NW, K1, S1, CIN, CO1, TIN>(a, a.layer[1], lds, stat + (wave * NL + 1) * 2 * a.cstat, n0, ng, wave, r, q);
+    }
+    __syncthreads();
+    for (int li = 0; li < NL; ++li) {
+        const PhaseLayer& L = a.layer[li];
+        for (int i = tid; i < 2 * L.cout; i += NT) {
+            const int which = i / L.cout, co = i - which * L.cout;
+            float s = 0.f;
+            for (int wv = 0; wv < NW; ++wv) s += stat[((wv * NL + li) * 2 + which) * a.cstat + co];
+            L.partial[((size_t)blockIdx.x * 2 + which) * L.cout + co] = s;
+        }
+    }
+}
+
+typedef void (*PhaseKernel)(const TrainPhaseArgs);
+// the compile-time instance for this phase (8 waves), or nullptr
+static PhaseKernel static_phase_kernel(const TrainPhaseArgs& a) {
+    if (a.nw != 8 || a.n_layers < 1 || (tune_get(TCR_TUNE_PHASE_STATIC) & 1)) return nullptr;
+    const PhaseLayer& A = a.layer[0];
+    const PhaseLayer& B = a.layer[1];
+    const int k1 = a.n_layers == 2 ? B.k : 0, s1 = a.n_layers == 2 ? B.stride : 0, co1 = a.n_layers == 2 ? B.cout : 0;
+#define TCR_PS(CIN_, TIN_, K0_, S0_, CO0_, K1_, S1_, CO1_)                                                                         \
+    if (a.src.c == CIN_ && a.src.t == TIN_ && A.k == K0_ && A.stride == S0_ && A.cout == CO0_ && k1 == K1_ && s1 == S1_ && co1 == CO1_) \
+        return train_phase_s_kernel<8, CIN_, TIN_, K0_, S0_, CO0_, K1_, S1_, CO1_>;
+#define TCR_PS_NET(T0_, C0_, C1_, C2_, C3_)                                                                                        \
+    TCR_PS(40, T0_, 3, 1, C0_, 0, 0, 0)                                                                                            \
+    TCR_PS(C0_, T0_, 1, 2, C1_, 9, 2, C1_) TCR_PS(C1_, (T0_ + 1) / 2, 9, 1, C1_, 0, 0, 0)                                                 \
+    TCR_PS(C1_, (T0_ + 1) / 2, 1, 2, C2_, 9, 2, C2_)                                                                               \
+    TCR_PS(C2_, ((T0_ + 1) / 2 + 1) / 2, 9, 1, C2_, 0, 0, 0)                                                                        \
+    TCR_PS(C2_, ((T0_ + 1) / 2 + 1) / 2, 1, 2, C3_, 9, 2, C3_)                                                                      \
+    TCR_PS(C3_, (((T0_ + 1) / 2 + 1) / 2 + 1) / 2, 9, 1, C3_, 0, 0, 0)
+    TCR_PS_NET(49, 16, 24, 32, 48)          // TCResNet8-1.0 (BASELINE.json configs[2])
+    TCR_PS_NET(98, 16, 24, 32, 48)
+    TCR_PS_NET(49, 24, 36, 48, 72)          // TCResNet14-1.5 (configs[3]): the identity blocks' convs have the shapes of the second convs
+    TCR_PS_NET(98, 24, 36, 48, 72)
+#undef TCR_PS_NET
+#undef TCR_PS
+    return nullptr;
+}
+
 // fills the launch geometry; false when the phase cannot be configured (caller falls back to the per-layer kernels)
 static bool configure_phase(TrainPhaseArgs& a, size_t* lds_out, int* grid_out) {
     const PhaseSrc& S = a.src;
     const int tp = S.t + 2 * kHalo;
-    const int in_sz = (S.c * tp + 3) / 4 * 4;
+    // floats per utterance in LDS: 2 * T_out (stride 2) or T_in (stride 1) modulo 32, so that the column -> bank pattern of the
+    // layers' operand reads runs on unbroken into the next utterance of the group (phase_layer_s)
+    int in_sz = (S.c * tp + 3) / 4 * 4;
+    if (a.n_layers > 0 && !(tune_get(TCR_TUNE_PHASE_STATIC) & 2)) {
+        const int want = a.layer[0].stride == 2 ? 2 * a.layer[0].tout : a.layer[0].tin;
+        while ((in_sz - want) % 32 != 0) ++in_sz;
+    }
     int cstat = 16;
     for (int i = 0; i < a.n_layers; ++i) {
         if (a.layer[i].cin % 4 != 0 || a.layer[i].cin != S.c || a.layer[i].tin != S.t) return false;
@@ -260,7 +468,8 @@ int launch_train_phase(TrainPhaseArgs a, int* rows_out, hipStream_t s) {
     int grid;
     if (!configure_phase(a, &lds, &grid)) return 1;
     if (rows_out) *rows_out = grid;
-    void (*kern)(const TrainPhaseArgs) = a.nw == 4 ? train_phase_kernel<4, 4> : train_phase_kernel<8, 4>;
+    PhaseKernel kern = static_phase_kernel(a);
+    if (!kern) kern = a.nw == 4 ? train_phase_kernel<4, 4> : train_phase_kernel<8, 4>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();

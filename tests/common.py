@@ -561,3 +561,29 @@ def check_dscnn_mask_paths_agree(lib, size, batch, seed=5):
     assert float((stats[4] - stats[3]).abs().max()) < 2e-6 * max(1.0, float(stats[3].abs().max()))
     assert float((logits[4] - logits[3]).abs().max()) < 2e-5
     assert float((grads[4] - grads[3]).abs().max()) < 5e-3 * max(1.0, float(grads[3].abs().max()))
+
+
+def check_phase_kernel_variants(lib, name, width, batch, t=49, seed=8):
+    """Training forward: the compile-time-shaped phase kernels with the bank-aligned utterance stride (default) are BITWISE the generic
+    layer walk and the unpadded stride (TCR_TUNE_PHASE_STATIC bits 0 / 1): same jobs, same accumulation and statistics order."""
+    import tcresnet_amd as T
+    dev = device_of(lib)
+    rng = np.random.RandomState(seed)
+    f = 40
+    x = torch.from_numpy(rng.uniform(-2, 2, (batch, t, f)).astype(np.float32)).to(dev)
+    feat = T.features_to_planar(x, lib=lib)
+    labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
+    ch = R.tcresnet_channels(name, float(width))
+    outs = []
+    try:
+        for v in (0, 1, 2, 3):
+            lib.tcr_tune(19, v)
+            net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)
+            net.init_xavier(1)
+            logits, _, loss = net.forward_train(feat, labels, keep_prob=0.5, seed=9)
+            outs.append((logits.clone(), float(loss), net.backward().clone(), net.stats.clone()))
+    finally:
+        lib.tcr_tune(19, 0)
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and outs[0][1] == o[1] and torch.equal(outs[0][2], o[2]) and torch.equal(outs[0][3], o[3])
+    assert float(outs[0][2].abs().max()) > 0

@@ -210,3 +210,8 @@ def test_prefetch_submit_point_policy(emu_lib):
     n8 = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, 49, 12, lib=emu_lib)
     n14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, 49, 12, lib=emu_lib)
     assert FeaturePrefetcher.submit_point(n8) == "before_forward" and FeaturePrefetcher.submit_point(n14) == "before_forward"
+
+
+@pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 11, 49), ("TCResNet14", 1.5, 5, 49), ("TCResNet8", 1.0, 3, 98)])
+def test_static_phase_kernels_are_bitwise_the_generic_walk(emu_lib, name, width, batch, t):
+    Cm.check_phase_kernel_variants(emu_lib, name, width, batch, t)

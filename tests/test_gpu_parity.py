@@ -335,7 +335,8 @@ def test_every_kernel_path_agrees(hip_lib):
         for name, knobs in (("per-layer mfma", {3: 1}), ("per-layer mfma, LDS image", {3: 1, 2: 1}), ("per-layer valu", {3: 1, 0: 1}),
                             ("fused g=3", {4: 3}), ("fused g=4, 4 waves", {4: 4, 5: 404}), ("fused, features staged in LDS", {3: 2}),
                             ("fused g=8, 16 waves, ring 8", {4: 8, 5: 816}), ("fused, generic layer walk (no compile-time shapes)", {3: 3}),
-                            ("fused, generic walk, 4 waves", {3: 3, 5: 404})):
+                            ("fused, generic walk, 4 waves", {3: 3, 5: 404}),
+                            ("fused, utterance strides not padded to the bank pattern", {3: 7})):
             for k, v in knobs.items():
                 hip_lib.tcr_tune(k, v)
             results[name] = net.forward_infer(feat0)[0].clone()
@@ -568,3 +569,10 @@ def test_inference_pipeline_equals_sequential(hip_lib, mode, depth, width, batch
     n = len(wavs) * 3
     for k in range(n - pipe.depth, n):
         assert torch.equal(pipe.out[(7 + k) % pipe.depth][0], want[k % 7])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 4096, 49), ("TCResNet14", 1.5, 1030, 49), ("TCResNet8", 1.0, 515, 98),
+                                                ("TCResNet14", 1.5, 259, 98)])
+def test_static_phase_kernels_are_bitwise_the_generic_walk(hip_lib, name, width, batch, t):
+    Cm.check_phase_kernel_variants(hip_lib, name, width, batch, t)
