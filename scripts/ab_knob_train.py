@@ -48,5 +48,14 @@ for fr in FRAMES:
             for v in VALUES:
                 lib.tcr_tune(KNOB, v)
                 res.setdefault(v, []).append(timeit(train))
+        if os.environ.get("CHECK"):
+            gs = {}
+            for v in VALUES:
+                lib.tcr_tune(KNOB, v)
+                net.init_xavier(0)
+                net.forward_train(feat, lab, keep_prob=0.5, seed=1)
+                gs[v] = net.backward().clone()
+            g0 = gs[VALUES[0]]
+            print("   gradient max |diff| / max |g| vs first value: " + "  ".join(f"{v}: {float((gs[v] - g0).abs().max() / g0.abs().max()):.2e}" for v in VALUES[1:]))
         lib.tcr_tune(KNOB, 0)
         print(f"{name} {fr} frames: " + "  ".join(f"{v}: {min(t):.0f}" for v, t in res.items()), flush=True)

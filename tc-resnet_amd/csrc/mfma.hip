@@ -1112,9 +1112,14 @@ __device__ __forceinline__ void wgrad4_trip(f32x4 (&acc)[K][NCO], const float* x
     }
 }
 
-template <int K, int S, int NCO, bool SAFE, bool FLY>
-__global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a) {
-    __shared__ float s_acc[K * 16 * NCO * 16];
+// NWV waves per workgroup (4, 8, 12 or 16): a wave takes every NWV-th utterance of the workgroup's chunk.  With four waves the 9-tap
+// layers of TCResNet8 put 1 .. 1.5 waves on a SIMD (128 split-K chunks x 1 .. 3 input-channel tiles), and every trip's operand loads --
+// an L2 / HBM round trip -- are waited out in front of its MFMAs; more waves per workgroup hide them without more slabs to reduce.  The
+// waves are combined in LDS in a fixed order: wave w adds onto slab w / 4 in round w % 4, the slabs are added in order on the way out.
+template <int K, int S, int NCO, bool SAFE, bool FLY, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void conv_wgrad_mfma4_kernel(const WgradArgs a) {
+    constexpr int SLAB = K * 16 * NCO * 16, NG = NWV / 4;
+    __shared__ float s_acc[NG * SLAB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -1147,7 +1152,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a
     const int n_end = min(n_begin + a.utt_per_block, a.batch);
     const int xlane = cic * a.tpi + a.xoff;
     const int xmax = a.tpi - 1 - a.xoff;            // last element of a row, relative to xr
-    for (int n = n_begin + wave; n < n_end; n += 4) {
+    for (int n = n_begin + wave; n < n_end; n += NWV) {
         const float* xr = a.x + (size_t)n * a.cin * a.tpi + xlane;
         const float* dr = a.dy + (size_t)n * a.cout_all * a.tpo;
         const float* rr = FLY ? a.fly.raw + (size_t)n * a.cout_all * a.tpo : nullptr;
@@ -1156,9 +1161,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a
         for (; a.tout - t0 > 12; t0 += 16) wgrad4_trip<K, S, NCO, 16, SAFE, FLY>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax, rr, kk);
         for (; t0 < a.tout; t0 += 8) wgrad4_trip<K, S, NCO, 8, SAFE, FLY>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax, rr, kk);
     }
-    // combine the 4 waves in LDS (fixed order), then write the slab
+    // combine the waves in LDS (fixed order), then write the slab
+    float* sa = s_acc + (wave >> 2) * SLAB;
     for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
+        if ((wave & 3) == wv) {
 #pragma unroll
             for (int j = 0; j < K; ++j)
 #pragma unroll
@@ -1167,19 +1173,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma4_kernel(const WgradArgs a
                     for (int reg = 0; reg < 4; ++reg) {
                         const int row = q * 4 + reg;        // ci within the tile
                         const int idx = ((j * 16 + row) * NCO + m) * 16 + r;
-                        if (wv == 0) s_acc[idx] = acc[j][m][reg];
-                        else s_acc[idx] += acc[j][m][reg];
+                        if (wv == 0) sa[idx] = acc[j][m][reg];
+                        else sa[idx] += acc[j][m][reg];
                     }
         }
         __syncthreads();
     }
     float* dst = a.partial + (size_t)blockIdx.x * K * a.cin_pad * a.cout_pad;
-    for (int i = threadIdx.x; i < K * 16 * NCO * 16; i += 256) {
+    for (int i = threadIdx.x; i < SLAB; i += NWV * 64) {
         const int col = i % (NCO * 16);
         const int row = (i / (NCO * 16)) % 16;
         const int j = i / (NCO * 16 * 16);
         const int cig = blockIdx.y * 16 + row;
-        if (cig < a.cin_pad && a.pcol + col < a.cout_pad) dst[((size_t)j * a.cin_pad + cig) * a.cout_pad + a.pcol + col] = s_acc[i];
+        float v = s_acc[i];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) v += s_acc[g * SLAB + i];
+        if (cig < a.cin_pad && a.pcol + col < a.cout_pad) dst[((size_t)j * a.cin_pad + cig) * a.cout_pad + a.pcol + col] = v;
     }
 }
 
@@ -1419,11 +1428,25 @@ size_t wgrad_partial_floats(int k, int cin, int cout, int batch, bool fine) {
     return slab > pw ? slab : pw;
 }
 
+// waves per workgroup of the on-the-fly 9-tap filter gradient (TCR_TUNE_WGRAD_WAVES: 0 policy, else 4 / 8 / 12 / 16)
+static int wgrad4_waves(int nco) {
+    const int k = tune_get(TCR_TUNE_WGRAD_WAVES);
+    if (k == 4 || k == 8 || k == 12 || k == 16) return nco >= 3 && k > 8 ? 8 : k;      // (three tiles: 12 / 16 waves would spill)
+    return 4;
+}
+
 template <int K, int S, bool SAFE>
 static int launch_wgrad4_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s) {
 #define TCR_W4(NCO_)                                                                                                            \
     if (a.fly.raw) hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, NCO_, SAFE, true>), grid, dim3(256), 0, s, a);            \
     else hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, NCO_, SAFE, false>), grid, dim3(256), 0, s, a)
+    // more waves per workgroup: the on-the-fly 9-tap layers of up to three output tiles (every conv of TCResNet8's lazy backward)
+    if constexpr (K == 9 && !SAFE) {
+        const int nwv = a.fly.raw ? wgrad4_waves(nco) : 4;
+#define TCR_W4W(NCO_, NWV_) if (nco == NCO_ && nwv == NWV_) { hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, NCO_, SAFE, true, NWV_>), grid, dim3(NWV_ * 64), 0, s, a); return check_launch("conv_wgrad_mfma4_kernel"); }
+        TCR_W4W(1, 8) TCR_W4W(1, 12) TCR_W4W(1, 16) TCR_W4W(2, 8) TCR_W4W(2, 12) TCR_W4W(2, 16) TCR_W4W(3, 8) TCR_W4W(3, 12) TCR_W4W(3, 16)
+#undef TCR_W4W
+    }
     switch (nco) {
         case 1: TCR_W4(1); break;
         case 2: TCR_W4(2); break;

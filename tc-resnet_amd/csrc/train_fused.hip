@@ -25,6 +25,20 @@ namespace tcr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Timing what-ifs of the compile-time-shaped phases (scripts/build_whatif_src.sh compiles this file with -DTCR_PHASE_WHATIF=<mask> into
+// side libraries; WRONG results, never the product build): 1 no MFMAs, 2 weights of tap 0 only, 4 no staging loads, 8 the staged
+// activation is not materialised, 16 no raw-output stores, 32 no statistics, 64 no convolutions, 128 no staging.
+#ifndef TCR_PHASE_WHATIF
+#define TCR_PHASE_WHATIF 0
+#endif
+#define TCR_PWHATIF(bit) ((TCR_PHASE_WHATIF & (bit)) != 0)
+#if TCR_PHASE_WHATIF & 1
+__device__ __forceinline__ f32x4 phase_nomfma(float a, float b, f32x4 c) { c[0] += a; c[1] += b; return c; }
+#define TCR_PMFMA(A, B, C) phase_nomfma((A), (B), (C))
+#else
+#define TCR_PMFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+#endif
+
 // One convolution of the phase for the group's `ng` utterances: input rows in LDS, raw output to global, statistics to the
 // wave's LDS row `wstat` ([2][cstat]: sums, sums of squares).
 template <int NW, int R>
@@ -159,8 +173,8 @@ __device__ __forceinline__ void phase_stage(const TrainPhaseArgs& a, float* lds,
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 ix[u] = min(i0 + u * NT, total - 1);
-                va[u] = S.a[gbase + ix[u]];
-                vs[u] = S.kind == 2 ? S.s[gbase + ix[u]] : 0.f;
+                va[u] = TCR_PWHATIF(4) ? 1.f : S.a[gbase + ix[u]];
+                vs[u] = S.kind == 2 && !TCR_PWHATIF(4) ? S.s[gbase + ix[u]] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
@@ -183,8 +197,8 @@ __device__ __forceinline__ void phase_stage(const TrainPhaseArgs& a, float* lds,
                     x = fmaxf(x, 0.f);
                 }
                 lds[g * a.in_sz + rem] = x;
-                if (S.out_x) S.out_x[gbase + i] = x;
-                if (S.kind == 2 && S.s_kind == 1 && S.out_s) S.out_s[gbase + i] = sv;
+                if (S.out_x && !(TCR_PWHATIF(8) && x != 12345.f)) S.out_x[gbase + i] = x;
+                if (S.kind == 2 && S.s_kind == 1 && S.out_s && !(TCR_PWHATIF(8) && x != 12345.f)) S.out_s[gbase + i] = sv;
             }
         }
     }
@@ -239,15 +253,15 @@ __device__ __forceinline__ void phase_layer_s(const TrainPhaseArgs& a, const Pha
         for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(H0 + c4) * WSTEP];
 #pragma unroll 1
         for (int j = 0; j < K; ++j) {
-            const int jn = min(j + 1, K - 1);                           // (the last tap refills with itself: branch-free)
+            const int jn = TCR_PWHATIF(2) ? 0 : min(j + 1, K - 1);                           // (the last tap refills with itself: branch-free)
             {
                 float b0[H0 > 0 ? H0 : 1], b1[H0 > 0 ? H0 : 1];
 #pragma unroll
                 for (int c4 = 0; c4 < H0; ++c4) { b0[c4] = x0[c4 * XSTEP + j]; b1[c4] = x1[c4 * XSTEP + j]; }
 #pragma unroll
                 for (int c4 = 0; c4 < H0; ++c4) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c4], b0[c4], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c4], b1[c4], acc1, 0, 0, 0);
+                    acc0 = TCR_PMFMA(wa[c4], b0[c4], acc0);
+                    acc1 = TCR_PMFMA(wa[c4], b1[c4], acc1);
                 }
 #pragma unroll
                 for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[(jn * C4 + c4) * WSTEP];
@@ -258,8 +272,8 @@ __device__ __forceinline__ void phase_layer_s(const TrainPhaseArgs& a, const Pha
                 for (int c4 = 0; c4 < H1; ++c4) { b0[c4] = x0[(H0 + c4) * XSTEP + j]; b1[c4] = x1[(H0 + c4) * XSTEP + j]; }
 #pragma unroll
                 for (int c4 = 0; c4 < H1; ++c4) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[c4], b0[c4], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[c4], b1[c4], acc1, 0, 0, 0);
+                    acc0 = TCR_PMFMA(wb[c4], b0[c4], acc0);
+                    acc1 = TCR_PMFMA(wb[c4], b1[c4], acc1);
                 }
 #pragma unroll
                 for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(jn * C4 + H0 + c4) * WSTEP];
@@ -276,10 +290,11 @@ __device__ __forceinline__ void phase_layer_s(const TrainPhaseArgs& a, const Pha
             s1[reg] = y0 + y1;
             s2[reg] = fmaf(y0, y0, y1 * y1);
             if (COUT % 16 == 0 || m * 16 + q * 4 + reg < COUT) {
-                if (v0) o0[reg * TPO] = acc0[reg];
-                if (v1) o1[reg * TPO] = acc1[reg];
+                if (v0 && !(TCR_PWHATIF(16) && acc0[reg] != 12345.f)) o0[reg * TPO] = acc0[reg];
+                if (v1 && !(TCR_PWHATIF(16) && acc1[reg] != 12345.f)) o1[reg * TPO] = acc1[reg];
             }
         }
+        if (TCR_PWHATIF(32)) continue;
         if (OWN) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) { ps1[reg] += s1[reg]; ps2[reg] += s2[reg]; }
@@ -378,8 +393,9 @@ __global__ __launch_bounds__(NW * 64) void train_phase_s_kernel(const TrainPhase
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
         __syncthreads();
-        phase_stage<NT>(a, lds, n0, ng, tid, tp, row);
+        if (!TCR_PWHATIF(128)) phase_stage<NT>(a, lds, n0, ng, tid, tp, row);
         __syncthreads();
+        if (TCR_PWHATIF(64)) continue;
         phase_layer_s<NW, K0, S0, CIN, CO0, TIN>(a, a.layer[0], lds, stat + (wave * NL + 0) * 2 * a.cstat, n0, ng, wave, r, q);
         if constexpr (K1 > 0) phase_layer_s<NW, K1, S1, CIN, CO1, TIN>(a, a.layer[1], lds, stat + (wave * NL + 1) * 2 * a.cstat, n0, ng, wave, r, q);
     }

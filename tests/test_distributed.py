@@ -224,7 +224,7 @@ def test_train_audio_cli_two_ranks_hip(hip_lib, tmp_path):
     _cli_two_ranks("hip", tmp_path, True)
 
 
-def _bench_plain_command(env_extra, batch):
+def _bench_plain_command(env_extra, batch, legs_ok=True):
     """`python bench.py --gpus 2 ...` as a PLAIN command (no launcher, WORLD_SIZE unset): bench.py launches its own two ranks under
     torch.distributed.run, rank 0 prints the one JSON line."""
     import json
@@ -233,7 +233,7 @@ def _bench_plain_command(env_extra, batch):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--batch", str(batch),
-           "--no-cpu-baseline", "--legs", "train"]
+           "--no-cpu-baseline"]           # (several ranks: the default legs are the training leg alone)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -241,6 +241,9 @@ def _bench_plain_command(env_extra, batch):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 2 * batch and out["value"] > 0
+    if not legs_ok:
+        return out
+    assert "secondary_legs" not in out and "dscnn_l_forward" not in out
     assert out["collectives_per_step"] == {"forward": 0, "train": 1.0}        # replicas only / ONE all-reduce of the gradient arena
     assert out["train"]["value"] > 0 and out["train"]["collectives_per_step"] == 1.0
     return out
@@ -250,6 +253,14 @@ def test_bench_self_launches_two_ranks(emu_lib):
     """CPU rehearsal (emulator build, gloo): the launcher, rendezvous, barriers, max-over-ranks timing and the JSON contract."""
     out = _bench_plain_command({"TCR_BENCH_EMU": EMU}, 4)
     assert "rehearsal" in out and out["collective_backend"].startswith("gloo")
+
+
+@pytest.mark.parametrize("how", ["raise", "hang"])
+def test_bench_keeps_the_headline_when_a_secondary_leg_fails(emu_lib, how):
+    """Several ranks: a leg that raises, or hangs (a collective that never completes) until the watchdog fires, still leaves ONE JSON
+    line with the headline and exit code 0."""
+    out = _bench_plain_command({"TCR_BENCH_EMU": EMU, "TCR_BENCH_FAIL_LEG": how, "TCR_BENCH_LEG_TIMEOUT": "2"}, 4, legs_ok=False)
+    assert "train" not in out and ("injected" if how == "raise" else "not finished") in out["secondary_legs"]["error"]
 
 
 @pytest.mark.gpu
