@@ -164,10 +164,10 @@ def main():
     labels[torch.arange(B), (torch.arange(B) + rank * B) % 12] = 1.0
 
     # ---------------- headline: eval forward, 49x40 front-end ----------------
-    # One step = one batch through the fused MFCC kernel + the whole-network fused kernel.  Whole batches ALTERNATE between two streams
-    # that have hardware queues of their own (tcresnet_amd.pipeline.InferencePipeline, mode "alternate": batch k's two kernels back to
-    # back on one stream, batch k+1's on the other; every step computes its own batch, outputs bitwise the one-stream sequence's:
-    # tests/test_gpu_parity.py::test_inference_pipeline_equals_sequential) -- 6-7 % more batches per second than the one-stream
+    # One step = one batch through the fused MFCC kernel + the whole-network fused kernel.  Whole batches ALTERNATE between three streams
+    # that have hardware queues of their own (tcresnet_amd.pipeline.InferencePipeline, mode "alternate", ways 3: batch k's two kernels back
+    # to back on one stream, batch k+1's on the next, three batches in flight -- 256 us per batch against 261 with two streams, 267 with four; every step computes its own batch, outputs bitwise the one-stream sequence's:
+    # tests/test_gpu_parity.py::test_inference_pipeline_equals_sequential) -- 8-9 % more batches per second than the one-stream
     # sequence, which is timed first (its two HIP-event intervals add up to its step, and its front-end interval is the dominant
     # kernel's SOLO duration: co-running, each kernel stretches to ~260 us and no longer describes itself).
     fe, net = build("4020")
@@ -193,7 +193,7 @@ def main():
     pipelined = not EMU and not ranks_share_gpu_()
     if pipelined:
         from tcresnet_amd.pipeline import InferencePipeline
-        pipe = InferencePipeline(fe, net, B, mode="alternate")
+        pipe = InferencePipeline(fe, net, B, mode="alternate", ways=3)
         step_out = pipe.out
     # (1) clock pre-warm + the one-stream sequence: labelled, untimed by the contract (outside the K timed steps and the W warm-up steps).
     #     The first ~50 launches on an idle GPU run ~15 % slower whatever --warmup says; the sequence's sampled events give the solo kernels.
@@ -209,7 +209,7 @@ def main():
         c_seq[0] += 1
 
     dt_seq = timed(seq_counted, nseq, 0, dist_on) if nseq else 0.0
-    # (2) the headline: K timed steps after W warm-up steps (behind a labelled, untimed pre-warm of the two-stream schedule itself)
+    # (2) the headline: K timed steps after W warm-up steps (behind a labelled, untimed pre-warm of the multi-stream schedule itself)
     if pipelined:
         for _ in range(max(0, args.prewarm) // 2):
             pipe.submit(wav)
@@ -270,7 +270,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"TCResNet8-1.0 eval forward, waveform->softmax, batch {B}/GPU, 49x40 MFCC (40/20 ms, FFT 1024), 12 classes",
                    "global_batch": world * B, "parallelism": f"dp{world} (utterance shards, no collective)", "collective_backend": dist.get_backend() if dist_on else None,
-                   "schedule": "whole batches alternating between two streams (InferencePipeline 'alternate')" if pipelined else "one stream"},
+                   "schedule": "whole batches alternating between three streams, three in flight (InferencePipeline 'alternate', ways 3)" if pipelined else "one stream"},
         "collective_backend": coll, "collectives_per_step": {"forward": 0},       # (eval forward: replicas only; the training legs add theirs below)
         "roofline": roof,
         # the co-running pair: algorithmic flops of BOTH kernels of a step / the step time of the timed region
@@ -281,7 +281,7 @@ def main():
         "sequential": {"ms_per_step": round(dt_seq / nseq * 1e3, 4) if nseq else None, "steps": nseq,
                        "what": "the same batches on ONE stream (front-end, network back to back), timed in this run ahead of the warm-up steps"},
         "bitwise_equal_to_sequential": bitwise,
-        ("batch_latency_ms_p10_p50_p90" if pipelined else "step_ms_p10_p50_p90"): [pct(0.1), pct(0.5), pct(0.9)],     # (pipelined: e0 -> e2 of a batch on its own stream, two batches in flight)
+        ("batch_latency_ms_p10_p50_p90" if pipelined else "step_ms_p10_p50_p90"): [pct(0.1), pct(0.5), pct(0.9)],     # (pipelined: e0 -> e2 of a batch on its own stream, three batches in flight)
         "event_timed_steps": len(timed_ev),
         "pre_warm_launches": max(0, args.prewarm) + (max(0, args.prewarm) // 2 if pipelined else 0),
         "whole_path_fp32_frac": round(whole_tf / FP32_PEAK_TFLOPS, 4),

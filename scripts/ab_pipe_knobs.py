@@ -32,12 +32,14 @@ def run(pipe, n=200, warm=60):
     return (time.perf_counter() - t0) / n * 1e6
 
 
-pipe = InferencePipeline(fe, net, B, mode="alternate")
+WAYS = [int(v) for v in os.environ.get("WAYS", "2").split(",")]
+pipes = {w: InferencePipeline(fe, net, B, mode="alternate", ways=w) for w in WAYS}
 res = {}
 for rnd in range(ROUNDS):
     for spec in SETS:
-        apply(spec)
-        res.setdefault(spec, []).append(run(pipe))
-        apply(spec, False)
+        for w in WAYS:
+            apply(spec)
+            res.setdefault(f"{spec} ways={w}", []).append(run(pipes[w]))
+            apply(spec, False)
 for spec, ts in res.items():
     print(f"{spec or 'defaults':>24}: " + "  ".join(f"{t:.1f}" for t in ts) + " us per batch", flush=True)

@@ -13,7 +13,7 @@ from ._lib import padded_len
 
 
 _STREAMS = {}
-_ROLE_INDEX = {"frontend": 2, "network": 3}
+_ROLE_INDEX = {"frontend": 2, "network": 3, "aux0": 0, "aux1": 1}      # (0 / 1: the training step's filter-gradient streams, idle during inference)
 
 
 def shared_stream(dev, role: str) -> "torch.cuda.Stream":
@@ -37,27 +37,37 @@ def shared_stream(dev, role: str) -> "torch.cuda.Stream":
 class InferencePipeline:
     """mode "handoff": the front-end stream hands every batch's features to the network stream (events between the kernels; `depth`
     feature / output buffers).  mode "alternate": whole batches alternate between the two streams -- a batch's front-end and network run
-    back to back on ONE stream, with no event between them, while the other stream works on the next batch; each stream owns one
-    feature buffer, one output pair and one network workspace (stream order alone protects them).  Measured at batch 4096, TCResNet8:
+    back to back on ONE stream, with no event between them, while the other stream(s) work on the next batch(es) (`ways` = 2 .. 4 streams =
+    batches in flight); each stream owns one feature buffer, one output pair and one network workspace (stream order alone protects them).  Measured at batch 4096, TCResNet8:
     sequential 284 us per batch, handoff three deep 272, alternate: see DESIGN.md section 7."""
 
-    def __init__(self, frontend, net, batch: int, depth: int = 2, mode: str = "handoff"):
+    def __init__(self, frontend, net, batch: int, depth: int = 2, mode: str = "handoff", ways: int = 2, fe_rounds="auto"):
         if mode not in ("handoff", "alternate"):
             raise ValueError(f"InferencePipeline: unknown mode {mode!r}")
+        if not 2 <= int(ways) <= 4:
+            raise ValueError(f"InferencePipeline: ways = {ways} (2 .. 4 streams)")
         self.mode = mode
         if mode == "alternate":
-            depth = 2
+            depth = int(ways)                           # batches in flight = streams
         self.fe, self.net, self.batch, self.depth = frontend, net, int(batch), int(depth)
         dev = frontend.device
         self.s_fe, self.s_net = shared_stream(dev, "frontend"), shared_stream(dev, "network")
+        self._streams = [self.s_fe, self.s_net] + [shared_stream(dev, r) for r in ("aux0", "aux1")[:max(0, depth - 2)]] if mode == "alternate" else None
         self.feat = [torch.empty((batch, frontend.n_coef, padded_len(frontend.n_frames)), device=dev) for _ in range(depth)]
         self.out = [(torch.empty((batch, net.num_classes), device=dev), torch.empty((batch, net.num_classes), device=dev))
                     for _ in range(depth)]
         if mode == "alternate":
-            self._ws = [net.new_workspace(batch, False) for _ in range(2)]      # one per stream
+            self._ws = [net.new_workspace(batch, False) for _ in range(depth)]  # one per stream
         else:
             self._ws = None
             self.net.workspace(batch, False)             # allocate before the streams start
+        # Frames per front-end workgroup while the kernels of other batches run next to it: the launcher's round count (tcr_tune knob
+        # TCR_TUNE_FRONTEND = 10 + rounds) is fitted to the front-end running alone -- 7 rounds of 8 frames at batch 4096 --; with two or
+        # three batches in flight the longest chunks (8 rounds: fewer, longer-lived workgroups) measured 254.7 against 258.2 us per batch
+        # (scripts/ab_pipe_knobs.py).  "auto": 8 rounds in mode "alternate" for the 1024-point FFT; None: the launcher's choice.
+        if fe_rounds == "auto":
+            fe_rounds = 8 if (mode == "alternate" and frontend.cfg.nfft == 1024) else None
+        self.fe_rounds = fe_rounds
         self._fe_done: List[torch.cuda.Event] = [torch.cuda.Event() for _ in range(depth)]
         self._net_done: List[torch.cuda.Event] = [torch.cuda.Event() for _ in range(depth)]
         self._k = 0
@@ -70,12 +80,12 @@ class InferencePipeline:
         i = self._k % self.depth
         cur = torch.cuda.current_stream(self.fe.device)
         if self.mode == "alternate":
-            st = (self.s_fe, self.s_net)[i]
+            st = self._streams[i]
             with torch.cuda.stream(st):
                 st.wait_stream(cur)                             # the caller produced `wav` on its current stream
                 if events is not None:
                     events[0].record(st)
-                self.fe(wav, out=self.feat[i])
+                self._frontend(wav, self.feat[i])
                 if events is not None:
                     events[1].record(st)
                 self.net.forward_infer(self.feat[i], out=self.out[i], workspace=self._ws[i])
@@ -101,14 +111,24 @@ class InferencePipeline:
         self._k += 1
         return self.out[i]
 
+    def _frontend(self, wav, out):
+        if self.fe_rounds is None:
+            return self.fe(wav, out=out)
+        lib = self.fe.lib
+        lib.tcr_tune(1, 10 + int(self.fe_rounds))       # (read by the launcher at launch time; restored right behind it)
+        try:
+            return self.fe(wav, out=out)
+        finally:
+            lib.tcr_tune(1, 0)
+
     def done_event(self, slot: int) -> "torch.cuda.Event":
         """The event recorded behind the network of the batch last submitted into output slot `slot` (= submit index % depth)."""
         return self._net_done[slot]
 
     def sync(self):
         cur = torch.cuda.current_stream(self.fe.device)
-        cur.wait_stream(self.s_fe)
-        cur.wait_stream(self.s_net)
+        for st in (self._streams or (self.s_fe, self.s_net)):
+            cur.wait_stream(st)
 
 
 class FeaturePrefetcher:

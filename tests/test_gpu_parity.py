@@ -537,7 +537,7 @@ def test_multi_stream_backward_repeats_bitwise(hip_lib, family):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,depth", [("handoff", 2), ("handoff", 3), ("alternate", 2)])
+@pytest.mark.parametrize("mode,depth", [("handoff", 2), ("handoff", 3), ("alternate", 2), ("alternate", 3), ("alternate", 4)])
 @pytest.mark.parametrize("width,batch", [(1.0, 2048), (1.5, 96)])
 def test_inference_pipeline_equals_sequential(hip_lib, mode, depth, width, batch):
     """The two-stream inference pipelines (tcresnet_amd.pipeline.InferencePipeline: front-end stream -> network stream, or whole batches
@@ -551,7 +551,8 @@ def test_inference_pipeline_equals_sequential(hip_lib, mode, depth, width, batch
     wavs = [(base.roll(k, 0) * (1.0 - 0.05 * k)).repeat((batch + 63) // 64, 1)[:batch].contiguous() for k in range(7)]
     want = [net.forward_infer(fe(w))[0].clone() for w in wavs]
     assert not torch.equal(want[0], want[1])
-    pipe = InferencePipeline(fe, net, batch, depth=depth, mode=mode)
+    pipe = InferencePipeline(fe, net, batch, depth=depth, mode=mode, ways=depth if mode == "alternate" else 2)      # (alternate: streams = batches in flight)
+    assert pipe.depth == depth
     got = []
     for k, w in enumerate(wavs):
         out = pipe.submit(w)
