@@ -28,7 +28,8 @@ def timeit(n=25, warm=6):
         e0.record(); train(); e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
     return sorted(ts)[len(ts) // 2]
-lib.tcr_tune(9, 2); ref = timeit(); lib.tcr_tune(9, 0)
+LAZY = int(os.environ.get("LAZY", "3"))        # 3: lazy forced (the default policy keeps nets of > 48 channels on the per-layer chain)
+lib.tcr_tune(9, 2); ref = timeit(); lib.tcr_tune(9, LAZY)
 base = timeit()
 print(f"{name} {fr} frames: per-layer {ref:.0f} us, lazy (cost model) {base:.0f} us", flush=True)
 # data-gradient kernels of the net: (out channels, layers): conv_b of block i -> (ch[i+1], 1); conv_a -> (ch[i], 2 with a shortcut conv else 1)

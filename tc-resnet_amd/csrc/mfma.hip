@@ -129,6 +129,12 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
 // loads) and the staged dy is also written to dy_out for the filter gradient -- every element is staged exactly once across the
 // grid --, so the bn_bwd_apply pass (3 tensor passes, 0.2 ms per layer in the backward's main chain) disappears.  Sums: the 16 positions of a tile column
 // block live in the 16 lanes of a DPP row -> row16_sum; the two position halves (wn) meet in LDS; one partial row per workgroup.
+// Timing what-ifs (scripts/build_whatif_src.sh mfma TCR_PW_WHATIF <mask>; wrong results, never the product build): 1 no global loads
+// after the first chunk, 2 no LDS stores after the first chunk, 4 no barrier in the chunk loop, 8 no MFMAs, 16 no output stores.
+#ifndef TCR_PW_WHATIF
+#define TCR_PW_WHATIF 0
+#endif
+#define TCR_PWW(bit) ((TCR_PW_WHATIF & (bit)) != 0)
 template <int MT, int NT, int EPI, int MODE>
 __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
     constexpr int KC = 12;                  // input channels per chunk = 3 MFMA k-steps
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const bool more = ch + 1 < nchunks;
-        if (more) load_chunk((ch + 1) * KC);
+        if (more && !TCR_PWW(1)) load_chunk((ch + 1) * KC);
         const int steps = min(KC / 4, (a.cin - ch * KC) >> 2);      // (last chunk of a Cin that is not a multiple of 12)
         const float* sw = s_w[buf] + aoff;
         const float* sx = s_x[buf] + boff;
@@ -249,11 +255,14 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (TCR_PWW(8)) { acc[m][nt][0] += af[m] + bf[nt]; continue; }
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+                    }
             }
         }
-        if (more) store_chunk(buf ^ 1);
-        __syncthreads();
+        if (more && !TCR_PWW(2)) store_chunk(buf ^ 1);
+        if (!TCR_PWW(4)) __syncthreads();
     }
 
     // (lean addressing: see conv_mfma_store)
@@ -280,6 +289,7 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
                         if (a.relu) v = fmaxf(v, 0.f);
                     }
                     float* o = yb + co * a.tpo;
+                    if (TCR_PWW(16) && v != 12345.f) continue;
                     o[0] = v;
                     if (EPI == MF_AFFINE) {
                         if (first) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
                     if (a.relu) v = fmaxf(v, 0.f);
                 }
                 const size_t off = yo[nt] + (size_t)(cc * a.tpo);
-                if (ok) {
+                if (ok && !(TCR_PWW(16) && v != 12345.f)) {
                     float* o = a.y + off;
                     o[0] = v;
                     if (EPI == MF_AFFINE) {

@@ -32,6 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TCR_PHASE_WHATIF 0
 #endif
 #define TCR_PWHATIF(bit) ((TCR_PHASE_WHATIF & (bit)) != 0)
+#ifndef TCR_PHASE_SU
+#define TCR_PHASE_SU 4        // staged elements per thread and trip
+#endif
 #if TCR_PHASE_WHATIF & 1
 __device__ __forceinline__ f32x4 phase_nomfma(float a, float b, f32x4 c) { c[0] += a; c[1] += b; return c; }
 #define TCR_PMFMA(A, B, C) phase_nomfma((A), (B), (C))
@@ -166,7 +169,7 @@ __device__ __forceinline__ void phase_stage(const TrainPhaseArgs& a, float* lds,
         const size_t gbase = (size_t)n0 * row;
         const int total = ng * row;
         const float inv_row = 1.0f / (float)row;
-        constexpr int SU = 4;
+        constexpr int SU = TCR_PHASE_SU;
         for (int i0 = tid; i0 < total; i0 += NT * SU) {
             float va[SU], vs[SU];
             int ix[SU];
