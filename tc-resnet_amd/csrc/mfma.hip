@@ -1218,8 +1218,18 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
     const int ci = r % cin;
     const int j = r / cin;
     const size_t off = ((size_t)j * cin_pad + ci) * cout_pad + co;
+    // a lane's slabs are added in order, but their loads are independent: eight in flight per trip (one load per trip serialises a
+    // memory round trip per slab: 32 of them for 128 slabs -- the step's LAST kernels, 20 us on an otherwise idle chip)
     float s = 0.f;
-    for (int c = part; c < nchunk; c += 4) s += partial[(size_t)c * slab + off];
+    int c = part;
+    for (; c + 28 < nchunk; c += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(c + 4 * u) * slab + off];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < nchunk; c += 4) s += partial[(size_t)c * slab + off];
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     if (live && part == 0) dw[((size_t)j * cin + ci) * cout_all + co_base + co] = s;
@@ -1438,7 +1448,9 @@ size_t wgrad_partial_floats(int k, int cin, int cout, int batch, bool fine) {
     return slab > pw ? slab : pw;
 }
 
-// waves per workgroup of the on-the-fly 9-tap filter gradient (TCR_TUNE_WGRAD_WAVES: 0 policy, else 4 / 8 / 12 / 16)
+// waves per workgroup of the on-the-fly 9-tap filter gradient (TCR_TUNE_WGRAD_WAVES: 0 policy, else 4 / 8 / 12 / 16).  (The first conv's
+// 3-tap gradient -- the step's last one, alone on the chip -- with 16 waves: 916 vs 906 us per step: two utterances per wave do not pay
+// for the sixteen-wave combine.)
 static int wgrad4_waves(int nco) {
     const int k = tune_get(TCR_TUNE_WGRAD_WAVES);
     if (k == 4 || k == 8 || k == 12 || k == 16) return nco >= 3 && k > 8 ? 8 : k;      // (three tiles: 12 / 16 waves would spill)
