@@ -27,47 +27,68 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int c0 = 0; c0 < a.c; c0 += 4) {
-        const int c = c0 + q;
-        const bool cv = c < a.c;
-        const int cc = cv ? c : a.c - 1;
-        // B operand: pooled (and dropped-out) feature of (utterance r, channel c)
-        const float* row = a.feat + ((size_t)n * a.c + cc) * a.tp + kHalo;
-        float sum = 0.f;
-        // eight loads in flight per trip, added in frame order (bitwise the one-load-per-trip loop, which paid a full memory round trip
-        // per frame: 64 workgroups x 12 channel quads x 13 dependent loads = 27 us at the head of the training step's backward)
+    // Four channel quads per trip: their 4 x 8 feature loads and 4 x MT weight loads are all requested before the first sum (one quad per
+    // trip paid a memory round trip per quad -- 12 in a row for 48 channels on 64 workgroups: 26 us at the head of the training step's
+    // backward).  Frames are added in frame order and the K-steps run in channel order: bitwise the one-quad loop.
+    constexpr int CQ = 4;
+    for (int c0 = 0; c0 < a.c; c0 += 4 * CQ) {
+        float sum[CQ], afv[CQ][MT];
+        const float* row[CQ];
+#pragma unroll
+        for (int j = 0; j < CQ; ++j) {
+            const int cc = min(c0 + 4 * j + q, a.c - 1);
+            row[j] = a.feat + ((size_t)n * a.c + cc) * a.tp + kHalo;
+            sum[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < CQ; ++j) {
+            const int c = c0 + 4 * j + q;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int o = m * 16 + r;                                   // A operand: Wcat[c][o]
+                float af = 0.f;
+                if (c < a.c) {
+                    if (o < a.nc) af = a.wfc[(size_t)c * a.nc + o];
+                    else if (o < a.nc + 2 && a.wfc2) af = a.wfc2[(size_t)c * 2 + (o - a.nc)];
+                }
+                afv[j][m] = af;
+            }
+        }
         for (int t0 = 0; t0 < a.t; t0 += 8) {
-            float v[8];
+            float v[CQ][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = row[min(t0 + i, a.t - 1)];
+            for (int j = 0; j < CQ; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (t0 + i < a.t) sum += v[i];
+                for (int i = 0; i < 8; ++i) v[j][i] = row[j][min(t0 + i, a.t - 1)];
+#pragma unroll
+            for (int j = 0; j < CQ; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (t0 + i < a.t) sum[j] += v[j][i];
         }
-        float pooled = sum / (float)a.t;                                    // tc_resnet.py:43
-        if (TRAIN) {
-            float ds = a.pool_scale > 0.f ? a.pool_scale : 1.0f / (float)a.t;     // d(pooled)/d(position)
-            if (a.keep_prob < 1.0f) {                                       // tf.nn.dropout: div(x, keep_prob) * mask
-                const float rnd = uniform01(a.seed, (uint64_t)(a.sample_offset + n) * (uint64_t)a.c + (uint64_t)cc);
-                const bool keep = rnd < a.keep_prob;
-                pooled = keep ? pooled / a.keep_prob : 0.f;
-                ds = keep ? ds / a.keep_prob : 0.f;
-            }
-            if (uv && cv) {
-                a.dropped[(size_t)n * a.c + c] = pooled;
-                a.dscale[(size_t)n * a.c + c] = ds;
-            }
-        }
-        const float bf = cv ? pooled : 0.f;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int o = m * 16 + r;                                       // A operand: Wcat[c][o]
-            float af = 0.f;
-            if (cv) {
-                if (o < a.nc) af = a.wfc[(size_t)c * a.nc + o];
-                else if (o < a.nc + 2 && a.wfc2) af = a.wfc2[(size_t)c * 2 + (o - a.nc)];
+        for (int j = 0; j < CQ; ++j) {
+            if (c0 + 4 * j >= a.c) break;                                   // (wave-uniform: the quads past the last channel)
+            const int c = c0 + 4 * j + q;
+            const bool cv = c < a.c;
+            const int cc = cv ? c : a.c - 1;
+            float pooled = sum[j] / (float)a.t;                             // tc_resnet.py:43
+            if (TRAIN) {
+                float ds = a.pool_scale > 0.f ? a.pool_scale : 1.0f / (float)a.t;     // d(pooled)/d(position)
+                if (a.keep_prob < 1.0f) {                                   // tf.nn.dropout: div(x, keep_prob) * mask
+                    const float rnd = uniform01(a.seed, (uint64_t)(a.sample_offset + n) * (uint64_t)a.c + (uint64_t)cc);
+                    const bool keep = rnd < a.keep_prob;
+                    pooled = keep ? pooled / a.keep_prob : 0.f;
+                    ds = keep ? ds / a.keep_prob : 0.f;
+                }
+                if (uv && cv) {
+                    a.dropped[(size_t)n * a.c + c] = pooled;
+                    a.dscale[(size_t)n * a.c + c] = ds;
+                }
             }
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[m], 0, 0, 0);
+            const float bf = cv ? pooled : 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(afv[j][m], bf, acc[m], 0, 0, 0);
         }
     }
 
