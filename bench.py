@@ -107,7 +107,7 @@ def main():
     if args.no_extras or args.legs == "none":
         legs = set()
     elif args.legs == "all":
-        legs = set(LEGS) if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 else {"train"}      # (several ranks: see "secondary legs" below)
+        legs = set(LEGS) if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and os.environ.get("TCR_BENCH_FORCE_DIST") != "1" else {"train"}      # (several ranks: see "secondary legs" below)
     else:
         legs = set(x for x in args.legs.split(",") if x)
         if legs - set(LEGS):
@@ -125,7 +125,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or unset WORLD_SIZE and let bench.py launch its ranks)")
-    dist_on = world > 1
+    # (TCR_BENCH_FORCE_DIST=1 with WORLD_SIZE=1: the process group, barriers and all-reduces of the N > 1 path in a group of one rank --
+    #  how a 1-GPU box sends them through RCCL; tests/test_distributed.py)
+    dist_on = world > 1 or os.environ.get("TCR_BENCH_FORCE_DIST") == "1"
     if EMU:
         lib = T._lib.load_from(EMU, "emu")
         dev = torch.device("cpu")

@@ -10,6 +10,7 @@ shards by utterance:
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -29,7 +30,8 @@ class DataParallel:
         self.net = net
         self.group = group
         self.sync_bn = bool(sync_bn)
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # (TCR_DP_FORCE=1: collectives also in a group of ONE rank -- the only way a 1-GPU box can send this code through RCCL: tests)
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("TCR_DP_FORCE") == "1")
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
         if self.enabled and ranks_share_gpu() and hasattr(net, "lib"):

@@ -269,3 +269,30 @@ def test_bench_self_launches_two_ranks_hip(hip_lib):
     identical command without TCR_BENCH_BACKEND runs one rank per GPU over RCCL)."""
     out = _bench_plain_command({"TCR_BENCH_BACKEND": "gloo"}, 256)
     assert "rehearsal" not in out and out["collective_backend"].startswith("gloo")
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_goes_through_rccl(hip_lib):
+    """The N > 1 control flow of bench.py (process group with device_id, barriers, max-over-ranks all-reduce, the training leg's
+    gradient all-reduce) in a group of ONE rank over backend "nccl" = RCCL: what a 1-GPU box can check of the RCCL path before the
+    driver's multi-GPU runs (two ranks cannot share a GPU under RCCL)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                "TCR_BENCH_FORCE_DIST": "1", "TCR_DP_FORCE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--prewarm", "4", "--batch", "512",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["collective_backend"] == "RCCL (backend nccl)" and out["n_gpus"] == 1 and out["value"] > 0
+    assert "secondary_legs" not in out, out["secondary_legs"]
+    assert out["train"]["value"] > 0 and out["collectives_per_step"] == {"forward": 0, "train": 1.0}
