@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4s
-CHECK=1 KNOB=21 VALUES=0,2,3 NETS=8 FRAMES=49,98 ROUNDS=3 timeout 400 python scripts/ab_knob_train.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4s/ab_conv0c.log
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/r4s/pytest_all.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r4s/pytest_all.log

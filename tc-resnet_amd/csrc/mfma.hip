@@ -1421,6 +1421,215 @@ static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float
     return launch_wgrad_reduce(scratch, dw, a.nchunk, 1, cin, cout, a.cin_pad, a.cout_pad, cout, 0, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged filter gradient (round 4).  The 16-byte-load kernel above gives every wave whole utterances: each trip is a global
+// round trip in front of its MFMAs, a wave accumulates ALL K x NCO tiles (72 .. 108 accumulator registers: one or two waves per SIMD),
+// and x / dy are fetched once per 16-row input tile.  Here a workgroup of NINE waves walks its chunk of utterances in stages of `ub`:
+//   STAGE   the stage's x rows (Cin x Tp) and dy rows (Cout x Tp) are CONTIGUOUS blocks of the planar layout: coalesced 16-byte loads
+//           into registers one stage ahead, then into the other LDS buffer (one barrier per stage).  dy is built while it is staged when
+//           the unit's BN backward is applied on the fly (WgradFly: k1 (dz - k2 - (raw - mean) k3), bn_bwd_apply's expression; the
+//           coefficients sit in an LDS table), and every position outside [0, T) is stored as zero.
+//   MFMA    wave w owns tap j = w of a 9-tap filter with all its (input tile, output tile) pairs -- for the 3-tap first conv (tap, input
+//           tile) = (w % 3, w / 3) -- : per 4 positions CPW A fragments (x at the tap's offset) + NCO B fragments (dy) from LDS feed
+//           CPW x NCO MFMAs.  No wave shares an accumulator with another: the slab is written straight from the registers.
+// D[row = ci][col = co] as in the kernels above, same slab layout, same deferred reduction.  Another summation order than the kernels
+// above (utterances in order within a workgroup): results agree to rounding.  Built for the first conv only (wgrad_lds_instance).
+// ---------------------------------------------------------------------------------------------
+struct WgradLdsArgs {
+    const float* x;         // [B][Cin][Tpi]
+    const float* dy;        // [B][Cout][Tpo] (fly.raw: the unit's gz)
+    float* partial;         // [nchunk][K][Cin_pad][Cout_pad]
+    int batch, cin, cout, cin_pad, cout_pad, tpi, tout, tpo, stride, xoff, utt_per_block, ub;
+    WgradFly fly;
+};
+
+template <int K, int NCI, int NCO, bool FLY>
+__global__ __launch_bounds__(576) void conv_wgrad_lds_kernel(const WgradLdsArgs a) {
+    constexpr int NW = 9, NT = NW * 64, XI = 2;
+    constexpr int CPW = K == 9 ? NCI : 1;               // input-channel tiles per wave
+    static_assert(K == 9 || (K == 3 && NCI == 3), "wave <-> (tap, input tile) maps");
+    float* lds = reinterpret_cast<float*>(dyn_lds());
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int xsz = a.cin * a.tpi, dsz = a.cout * a.tpo;            // floats per utterance (multiples of 4: launcher)
+    const int bufsz = a.ub * (xsz + dsz);
+    float* tab = lds + 2 * bufsz;                                   // FLY: [cout][8] = k1, k2, k3, mean, own-mask scale / shift
+    if (FLY) {
+        for (int i = tid; i < a.cout; i += NT) {
+            tab[i * 8 + 0] = a.fly.k1[i]; tab[i * 8 + 1] = a.fly.k2[i]; tab[i * 8 + 2] = a.fly.k3[i]; tab[i * 8 + 3] = a.fly.mean[i];
+            tab[i * 8 + 4] = a.fly.self_scale ? a.fly.self_scale[i] : 0.f;          // (no own mask: fmaf(raw, 0, 1) > 0 always)
+            tab[i * 8 + 5] = a.fly.self_scale ? a.fly.self_shift[i] : 1.f;
+            tab[i * 8 + 6] = 0.f; tab[i * 8 + 7] = 0.f;
+        }
+    }
+    const int n_begin = blockIdx.x * a.utt_per_block;
+    const int n_end = min(n_begin + a.utt_per_block, a.batch);
+    const int nstages = (n_end - n_begin + a.ub - 1) / a.ub;
+    const float inv_dsz = 1.0f / (float)dsz, inv_tpo = 1.0f / (float)a.tpo;
+
+    f32x4 xr[XI], gr[XI], rr[XI];
+    auto load_stage = [&](int st) {
+        const int n0 = n_begin + st * a.ub;
+        const int nu = min(a.ub, n_end - n0);
+        const f32x4* xs = reinterpret_cast<const f32x4*>(a.x + (size_t)n0 * xsz);
+        const f32x4* gs = reinterpret_cast<const f32x4*>(a.dy + (size_t)n0 * dsz);
+        const f32x4* rs = FLY ? reinterpret_cast<const f32x4*>(a.fly.raw + (size_t)n0 * dsz) : nullptr;
+        const int nx4 = nu * xsz / 4, nd4 = nu * dsz / 4;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int ix = tid + i * NT;
+            xr[i] = xs[min(ix, nx4 - 1)];
+            gr[i] = gs[min(ix, nd4 - 1)];
+            if (FLY) rr[i] = rs[min(ix, nd4 - 1)];
+        }
+    };
+    auto store_stage = [&](int st, int buf) {
+        const int n0 = n_begin + st * a.ub;
+        const int nu = min(a.ub, n_end - n0);
+        const int nx4 = nu * xsz / 4, nd4 = nu * dsz / 4;
+        float* xb = lds + buf * bufsz;
+        float* db = xb + a.ub * xsz;
+        // (a short last stage: the tap offsets of the last row's last positions read up to 16 floats past the staged rows -- times a zero
+        //  dy, but the LDS there may never have been written)
+        if (nu < a.ub && tid < 4) reinterpret_cast<f32x4*>(xb + nu * xsz)[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int ix = tid + i * NT;
+            if (ix < nx4) reinterpret_cast<f32x4*>(xb)[ix] = xr[i];
+            if (ix < nd4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int f = 4 * ix + e;
+                    const int u = fast_div(f, dsz, inv_dsz);
+                    const int rem = f - u * dsz;
+                    const int ch = fast_div(rem, a.tpo, inv_tpo);
+                    const int tt = rem - ch * a.tpo - kHalo;
+                    float d = gr[i][e];
+                    if (FLY) {
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(tab + ch * 8);
+                        const float msc = tab[ch * 8 + 4], msh = tab[ch * 8 + 5];
+                        const float y = rr[i][e];
+                        if (!(fmaf(y, msc, msh) > 0.f)) d = 0.f;
+                        d = c0[0] * (d - c0[1] - (y - c0[3]) * c0[2]);
+                    }
+                    v[e] = (tt >= 0 && tt < a.tout) ? d : 0.f;
+                }
+                reinterpret_cast<f32x4*>(db)[ix] = v;
+            }
+        }
+    };
+
+    f32x4 acc[CPW][NCO];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+#pragma unroll
+        for (int m = 0; m < NCO; ++m) acc[i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int j = K == 9 ? wave : wave % 3;                     // this wave's tap
+    const int cit0 = K == 9 ? 0 : wave / 3;                     // ... and first input-channel tile
+    int xrow[CPW], drow[NCO];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) xrow[i] = min((cit0 + i) * 16 + r, a.cin - 1) * a.tpi + q * a.stride + j + a.xoff;   // (rows past Cin: clamped, never read back)
+#pragma unroll
+    for (int m = 0; m < NCO; ++m) drow[m] = min(m * 16 + r, a.cout - 1) * a.tpo + kHalo + q;
+
+    if (nstages > 0) load_stage(0);
+    __syncthreads();                                            // (the coefficient table)
+    if (nstages > 0) store_stage(0, 0);
+    __syncthreads();
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstages) load_stage(st + 1);
+        const int nu = min(a.ub, n_end - (n_begin + st * a.ub));
+        const float* xb = lds + buf * bufsz;
+        const float* db = xb + a.ub * xsz;
+        for (int u = 0; u < nu; ++u) {
+            const float* xu = xb + u * xsz;
+            const float* du = db + u * dsz;
+            for (int t0 = 0; t0 < a.tout; t0 += 4) {
+                float af[CPW], bf[NCO];
+#pragma unroll
+                for (int i = 0; i < CPW; ++i) af[i] = xu[xrow[i] + t0 * a.stride];
+#pragma unroll
+                for (int m = 0; m < NCO; ++m) bf[m] = du[drow[m] + t0];
+#pragma unroll
+                for (int i = 0; i < CPW; ++i)
+#pragma unroll
+                    for (int m = 0; m < NCO; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[m], acc[i][m], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nstages) store_stage(st + 1, buf ^ 1);
+        __syncthreads();
+    }
+    float* dst = a.partial + (size_t)blockIdx.x * K * a.cin_pad * a.cout_pad + (size_t)j * a.cin_pad * a.cout_pad;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+#pragma unroll
+        for (int m = 0; m < NCO; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cig = (cit0 + i) * 16 + q * 4 + reg, col = m * 16 + r;
+                if (cig < a.cin_pad && col < a.cout_pad) dst[(size_t)cig * a.cout_pad + col] = acc[i][m][reg];
+            }
+}
+
+// Shapes with an instance of the LDS-staged kernel: the 3-tap first conv (40 coefficients = three input tiles, one or two output tiles).
+// Measured with instances for the 9-tap layers too (one wave per tap), whole training step at batch 4096, 16-byte-load kernel -> LDS-staged
+// for the first conv only / for every layer: TCResNet8 909 -> 894 / 899 us, 98 frames 1361 -> 1294 / 1344, TCResNet14-1.5 2753 -> 2712 / 2819,
+// 98 frames 4391 -> 4322 / 4491.  On ONE stream the 9-tap instances save 50 (TCResNet8) / 220 us (TCResNet14-1.5) of kernel time, next to
+// the data-gradient chain they take it back: they are the heavier neighbours.  Only the first conv's instance is built.
+static bool wgrad_lds_instance(int k, int cin, int cout) {
+    const int nci = ceil_div(cin, 16), nco = ceil_div(cout, 16);
+    return k == 3 && nci == 3 && (nco == 1 || nco == 2);
+}
+static bool wgrad_lds_shape(int k, int cin, int cout) { return tune_get(TCR_TUNE_WGRAD_LDS) != 1 && wgrad_lds_instance(k, cin, cout); }
+// Split-K workgroups of a layer -- decided by the SHAPE alone, so that the slab buffer, the launch and the deferred reduction agree
+// whichever kernel runs: the LDS-staged kernel is one workgroup per chunk (no input-tile dimension in its grid), 256 of them (512: +35 us
+// per TCResNet8 step, 1024: +110: slab traffic and the reduction).
+static int wgrad_nchunk(int k, int cin, int cout, int batch, bool fine) {
+    if (!wgrad_lds_shape(k, cin, cout)) return wgrad_chunks_for(batch, fine);
+    int n = ceil_div(batch, 4);
+    if (n > 256) n = 256;
+    return n < 1 ? 1 : n;
+}
+
+// launches the LDS-staged kernel when the shape has an instance and the operands are 16-byte aligned; 1: not covered (nothing launched)
+static int launch_wgrad_lds(int k, int stride, int pad_lo, const float* x, const float* dy, float* scratch, int batch, int cin, int cout,
+                            int tpi, int tout, int tpo, int nchunk, const WgradFly* fly, hipStream_t s) {
+    if (!wgrad_lds_shape(k, cin, cout)) return 1;
+    const int nci = ceil_div(cin, 16), nco = ceil_div(cout, 16);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool f = fly && fly->raw;
+    if ((cin * tpi) % 4 || (cout * tpo) % 4 || !al16(x) || !al16(dy) || (f && !al16(fly->raw))) return 1;
+    WgradLdsArgs a;
+    if (f) a.fly = *fly;
+    a.x = x; a.dy = dy; a.partial = scratch; a.batch = batch; a.cin = cin; a.cout = cout; a.cin_pad = nci * 16; a.cout_pad = nco * 16;
+    a.tpi = tpi; a.tout = tout; a.tpo = tpo; a.stride = stride; a.xoff = kHalo - pad_lo;
+    a.utt_per_block = ceil_div(batch, nchunk);
+    // utterances per stage: enough 4-position steps per barrier (>= 8), within two 16-byte loads per thread and tensor
+    const int steps = ceil_div(tout, 4);
+    int ub = ceil_div(8, steps);
+    if (ub > a.utt_per_block) ub = a.utt_per_block;
+    while (ub > 1 && (ub * cin * tpi > 8 * 576 || ub * cout * tpo > 8 * 576)) --ub;
+    if (ub < 1 || ub * cin * tpi > 8 * 576 || ub * cout * tpo > 8 * 576) return 1;
+    a.ub = ub;
+    const size_t lds = ((size_t)2 * ub * (cin * tpi + cout * tpo) + (size_t)cout * 8 + 64) * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    const dim3 grid(ceil_div(batch, a.utt_per_block));
+    void (*kern)(const WgradLdsArgs) = nullptr;
+#define TCR_WL(K_, NCI_, NCO_) if (k == K_ && nci == NCI_ && nco == NCO_) kern = f ? conv_wgrad_lds_kernel<K_, NCI_, NCO_, true> : conv_wgrad_lds_kernel<K_, NCI_, NCO_, false>;
+    TCR_WL(3, 3, 1) TCR_WL(3, 3, 2)
+#undef TCR_WL
+    if (!kern) return 1;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(576), lds, s, a);
+    return check_launch("conv_wgrad_lds_kernel");
+}
+
 int wgrad_chunks(int batch) {
     int n = ceil_div(batch, 16);        // >= 16 utterances (4 per wave) per workgroup
     if (n > 128) n = 128;           // (measured at batch 4096: 64 / 256 / 512 split-K workgroups are 3-15 % slower per training step)
@@ -1443,7 +1652,7 @@ size_t wgrad_partial_floats(int k, int cin, int cout, int batch, bool fine) {
     const int cin_pad = ceil_div(cin, 16) * 16;
     const int cs = cout > 80 ? 80 : cout;
     const int cout_pad = ceil_div(cs, 16) * 16;
-    const size_t slab = (size_t)wgrad_chunks_for(batch, fine) * k * cin_pad * cout_pad;
+    const size_t slab = (size_t)max(wgrad_chunks_for(batch, fine), wgrad_lds_instance(k, cin, cout) ? min(ceil_div(batch, 4), 256) : 0) * k * cin_pad * cout_pad;       // (whatever the knob says later)
     const size_t pw = (k == 1 && cin > 80 && cout > 80) ? (size_t)pw_wgrad_chunks(batch) * cin_pad * (ceil_div(cout, 16) * 16) : 0;   // pw_wgrad_lds_kernel
     return slab > pw ? slab : pw;
 }
@@ -1511,7 +1720,7 @@ WgradReduceEntry conv_wgrad_entry(int k, int cin, int cout, int batch, const flo
     WgradReduceEntry e;
     e.partial = scratch; e.dw = dw; e.k = k; e.cin = cin; e.cout = cout;
     e.cin_pad = ceil_div(cin, 16) * 16; e.cout_pad = ceil_div(cout, 16) * 16;
-    e.nchunk = ceil_div(batch, ceil_div(batch, wgrad_chunks_for(batch, fine)));
+    e.nchunk = ceil_div(batch, ceil_div(batch, wgrad_nchunk(k, cin, cout, batch, fine)));
     return e;
 }
 
@@ -1528,8 +1737,15 @@ int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, con
     a.cout_pad = ceil_div(cout, 16) * 16;
     a.tpi = tpi; a.tout = tout; a.tpo = tpo; a.stride = stride;
     a.xoff = kHalo - pad_lo;
-    const int nchunk = wgrad_chunks_for(batch, fine);
+    const int nchunk = wgrad_nchunk(k, cin, cout, batch, fine);
     a.utt_per_block = ceil_div(batch, nchunk);
+    {
+        const int rc = launch_wgrad_lds(k, stride, pad_lo, x, dy, scratch, batch, cin, cout, tpi, tout, tpo, nchunk, fly, s);
+        if (rc != 1) {
+            if (rc == TCR_OK && entry) *entry = conv_wgrad_entry(k, cin, cout, batch, scratch, nullptr, fine);
+            return rc;
+        }
+    }
     const dim3 grid(ceil_div(batch, a.utt_per_block), a.cin_pad / 16);
     const int nco = a.cout_pad / 16;
     // 9-tap layers of 4-5 channel tiles (TCResNet14-1.5's 72 channels): 36-45 accumulator tiles leave ONE wave per SIMD, and the side

@@ -1469,6 +1469,9 @@ static BnBwdFinalizeArgs lazy_finalize_args(const TrainCtx& c, int li, float* gr
 
 // filter gradient of unit li on stream `ws`, dy computed where it is loaded
 static int lazy_wgrad(const TrainCtx& c, int li, hipStream_t ws) {
+#if defined(TCR_NET_WHATIF) && (TCR_NET_WHATIF & 1)      // timing what-if (scripts/build_whatif_src.sh): no filter-gradient launches; wrong results
+    if (li != 0 || (TCR_NET_WHATIF & 2)) return TCR_OK;
+#endif
     const tcr_net& net = *c.net;
     const ConvLayer& l = net.layers[li];
     const LazySrc src = lazy_src_of(c, li);

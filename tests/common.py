@@ -587,3 +587,32 @@ def check_phase_kernel_variants(lib, name, width, batch, t=49, seed=8):
     for o in outs[1:]:
         assert torch.equal(outs[0][0], o[0]) and outs[0][1] == o[1] and torch.equal(outs[0][2], o[2]) and torch.equal(outs[0][3], o[3])
     assert float(outs[0][2].abs().max()) > 0
+
+
+def check_first_conv_wgrad_kernels_agree(lib, name, width, batch, t=49, seed=12):
+    """The first conv's filter gradient from the LDS-staged nine-wave kernel (default) against the 16-byte-load kernel
+    (TCR_TUNE_WGRAD_LDS = 1): another summation order, so to rounding -- and every other gradient bitwise."""
+    import tcresnet_amd as T
+    dev = device_of(lib)
+    rng = np.random.RandomState(seed)
+    f = 40
+    x = torch.from_numpy(rng.uniform(-2, 2, (batch, t, f)).astype(np.float32)).to(dev)
+    feat = T.features_to_planar(x, lib=lib)
+    labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
+    ch = R.tcresnet_channels(name, float(width))
+    grads = []
+    try:
+        for v in (0, 1):
+            lib.tcr_tune(21, v)
+            net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)
+            net.init_xavier(1)
+            net.forward_train(feat, labels, keep_prob=0.5, seed=9)
+            grads.append(net.backward().clone())
+    finally:
+        lib.tcr_tune(21, 0)
+    n0 = 3 * f * ch[0]                      # the first conv's filter leads the parameter arena
+    a, b = grads
+    assert torch.equal(a[n0:], b[n0:])
+    scale = float(b[:n0].abs().max())
+    assert scale > 0 and float((a[:n0] - b[:n0]).abs().max()) <= 2e-5 * scale, (float((a[:n0] - b[:n0]).abs().max()), scale)
+    assert not torch.equal(a[:n0], b[:n0]) or batch < 8

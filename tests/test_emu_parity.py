@@ -215,3 +215,8 @@ def test_prefetch_submit_point_policy(emu_lib):
 @pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 11, 49), ("TCResNet14", 1.5, 5, 49), ("TCResNet8", 1.0, 3, 98)])
 def test_static_phase_kernels_are_bitwise_the_generic_walk(emu_lib, name, width, batch, t):
     Cm.check_phase_kernel_variants(emu_lib, name, width, batch, t)
+
+
+@pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 13, 49), ("TCResNet14", 1.5, 6, 98)])
+def test_first_conv_filter_gradient_kernels_agree(emu_lib, name, width, batch, t):
+    Cm.check_first_conv_wgrad_kernels_agree(emu_lib, name, width, batch, t)

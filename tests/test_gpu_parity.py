@@ -577,3 +577,9 @@ def test_inference_pipeline_equals_sequential(hip_lib, mode, depth, width, batch
                                                 ("TCResNet14", 1.5, 259, 98)])
 def test_static_phase_kernels_are_bitwise_the_generic_walk(hip_lib, name, width, batch, t):
     Cm.check_phase_kernel_variants(hip_lib, name, width, batch, t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 4096, 49), ("TCResNet14", 1.5, 1031, 98), ("TCResNet8", 1.0, 3, 49)])
+def test_first_conv_filter_gradient_kernels_agree(hip_lib, name, width, batch, t):
+    Cm.check_first_conv_wgrad_kernels_agree(hip_lib, name, width, batch, t)
