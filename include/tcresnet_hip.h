@@ -417,7 +417,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_PHASE_STATIC = 19, /* training forward phases of TCResNet8-1.0 / TCResNet14-1.5 at 49 / 98 frames: 0 compile-time-shaped kernels, utterance stride in LDS padded to the bank pattern (default); bit 0: generic layer walk; bit 1: unpadded stride (A/B arms, all bitwise) */
        TCR_TUNE_WGRAD_WAVES = 20, /* on-the-fly 9-tap filter gradients: waves per workgroup (0: policy; 4, 8, 12, 16) */
        TCR_TUNE_WGRAD_LDS = 21,  /* first conv's filter gradient: 0 the LDS-staged nine-wave kernel (default), 1 the 16-byte-load kernel */
-       TCR_TUNE_COUNT = 22 };
+       TCR_TUNE_LAZY_STAGE = 22, /* lazy backward: 0 the group's rows staged with 16-byte loads (default), 1 a dword gather per interior element (bitwise the same) */
+       TCR_TUNE_COUNT = 23 };
 int tcr_tune(int knob, int value);
 
 /* The library's internal streams (hipStream_t), one set per device and process.  HIP multiplexes streams onto a few hardware queues

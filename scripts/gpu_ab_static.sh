@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4s
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/r4s/pytest_all.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r4s/pytest_all.log
+CHECK=1 KNOB=22 VALUES=1,0 NETS=8 FRAMES=49,98 ROUNDS=3 timeout 600 python scripts/ab_knob_train.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4s/ab_vecstage.log
+CHECK=1 TUNE=9=3 KNOB=22 VALUES=1,0 NETS=14 FRAMES=49 ROUNDS=2 timeout 600 python scripts/ab_knob_train.py 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r4s/ab_vecstage.log

@@ -95,6 +95,47 @@ __global__ __launch_bounds__(kLzNW * 64) void bwd_lazy_kernel(const BwdLazyArgs 
             const float* cf = coef + (si ? 8 * a.src[0].c : 0);
             const size_t gbase = (size_t)n0 * S.c * tp;
             const int nrows = ng * S.c;
+            // The group's rows are ONE contiguous block of the planar layout (halos included) and the image has the same pitch: 16-byte
+            // loads of gz and raw, all of a trip's in flight before the first use, one 16-byte LDS store per four elements; halo positions
+            // are stored as zero by a select (no separate zero pass).  (Round-4 first form: a dword gather per interior element, two
+            // trips of four: 2.5x the vector-memory instructions and one more round trip per staging.)
+            if (a.vec_stage) {
+                const int tot4 = nrows * tp / 4;
+                const float inv_tp = 1.0f / (float)tp, inv_c = 1.0f / (float)S.c;
+                const f32x4* g4 = reinterpret_cast<const f32x4*>(S.gz + gbase);
+                const f32x4* r4 = reinterpret_cast<const f32x4*>(S.raw + gbase);
+                constexpr int SV = 2;
+                for (int f0 = tid; f0 < tot4; f0 += NT * SV) {
+                    f32x4 vg[SV], vr[SV];
+#pragma unroll
+                    for (int u = 0; u < SV; ++u) {
+                        const int f = min(f0 + u * NT, tot4 - 1);
+                        vg[u] = (TCR_LAZY_WHATIF & 2) ? (f32x4){1.f, 1.f, 1.f, 1.f} : g4[f];
+                        vr[u] = (TCR_LAZY_WHATIF & 2) ? (f32x4){1.f, 1.f, 1.f, 1.f} : r4[f];
+                    }
+#pragma unroll
+                    for (int u = 0; u < SV; ++u) {
+                        const int f = f0 + u * NT;
+                        if (f >= tot4) break;
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int idx = 4 * f + e;
+                            const int row = fast_div(idx, tp, inv_tp);
+                            const int tt = idx - row * tp - kHalo;
+                            const int g = fast_div(row, S.c, inv_c);
+                            const float* cp = cf + (row - g * S.c) * 8;
+                            float dz = vg[u][e];
+                            const float y = vr[u][e];
+                            if (!(fmaf(y, cp[4], cp[5]) > 0.f)) dz = 0.f;
+                            const float d = cp[0] * (dz - cp[1] - (y - cp[3]) * cp[2]);      // == bn_bwd_apply_kernel
+                            o[e] = (tt >= 0 && tt < S.t) ? d : 0.f;
+                        }
+                        reinterpret_cast<f32x4*>(img)[f] = o;
+                    }
+                }
+                continue;
+            }
             const int total = nrows * S.t;
             const float inv_t = 1.0f / (float)S.t, inv_c = 1.0f / (float)S.c;
             for (int e0 = tid; e0 < total; e0 += NT * SU) {
@@ -427,6 +468,11 @@ static bool configure_lazy(BwdLazyArgs& a, size_t* lds_out, int* grid_out) {
     const int slots = kLzNW / a.ks;
     a.img_off[0] = 0;
     a.img_off[1] = a.group * a.src[0].c * (a.src[0].t + 2 * kHalo);
+    a.vec_stage = tune_get(TCR_TUNE_LAZY_STAGE) != 1;
+    for (int i = 0; i < a.n_layers; ++i) {
+        const LazySrc& S = a.src[i];
+        if ((S.c * (S.t + 2 * kHalo)) % 4 != 0 || (reinterpret_cast<uintptr_t>(S.gz) & 15) || (reinterpret_cast<uintptr_t>(S.raw) & 15)) a.vec_stage = 0;
+    }
     a.red_off = a.group * per_utt;
     a.stat_off = a.red_off + slots * (a.ks > 1 ? a.ks - 1 : 1) * a.mt * 8 * 64;
     a.coef_off = a.stat_off + slots * 4 * a.cstat;

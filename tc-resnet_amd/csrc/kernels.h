@@ -335,6 +335,7 @@ struct BwdLazyArgs {
     int batch;
     // (set by the launcher)
     int group, n_groups, ks, mt, nw, qmax, taps;
+    int vec_stage;          // staging with 16-byte loads / LDS stores (rows a multiple of four floats per utterance, aligned tensors)
     int img_off[2], red_off, stat_off, coef_off, ecoef_off, cstat;
     int nu[2];              // output positions per utterance of stride phase 0 / 1
     int cnt[2][2], dmin[2][2], wbase[2][2];     // [layer][phase]: taps, first dy offset, float offset of the phase's weights in wt
