@@ -1,6 +1,6 @@
 // What a fork costs on the forking stream: a chain of short kernels on stream A, after each of them a kernel on stream B that
 // depends on it -- (0) no fork at all, (1) hipEventRecord(A) + hipStreamWaitEvent(B), (2) the kernel itself bumps a counter in
-// signal memory and B waits for it with hipStreamWaitValue32 (no packet on A).
+// signal memory and B waits for it with hipStreamWaitValue32 (no packet on A), (3) hipStreamWriteValue32 on A instead of the event.
 //   hipcc --offload-arch=gfx950 -O3 scripts/micro/fork_gap.hip -o scripts/micro/fork_gap && scripts/micro/fork_gap
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -36,8 +36,8 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int N = 40, iters = argc > 1 ? atoi(argv[1]) : 400;
     unsigned expect = 0;
-    for (int mode = 0; mode < 3; ++mode) {
-        if (mode == 2 && !can) break;
+    for (int mode = 0; mode < 4; ++mode) {
+        if (mode >= 2 && !can) break;
         double best = 1e30, best_all = 1e30;
         for (int rep = 0; rep < 8; ++rep) {
             CK(hipDeviceSynchronize());
@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
                 hipLaunchKernelGGL(work, dim3(64), dim3(256), 0, A, pa, iters, mode == 2 ? sig : nullptr);
                 if (mode == 1) { CK(hipEventRecord(ev, A)); CK(hipStreamWaitEvent(B, ev, 0)); }
                 if (mode == 2) { ++expect; CK(hipStreamWaitValue32(B, sig, expect, hipStreamWaitValueGte, 0xffffffffu)); }
+                if (mode == 3) { ++expect; CK(hipStreamWriteValue32(A, sig, expect, 0)); CK(hipStreamWaitValue32(B, sig, expect, hipStreamWaitValueGte, 0xffffffffu)); }
                 if (mode != 0) hipLaunchKernelGGL(work, dim3(64), dim3(256), 0, B, pb, iters, nullptr);
             }
             CK(hipEventRecord(e1, A));
@@ -60,7 +61,7 @@ int main(int argc, char** argv) {
             if (all < best_all) best_all = all;
         }
         printf("mode %d (%s): stream A %.1f us per kernel, everything done after %.1f us per kernel\n", mode,
-               mode == 0 ? "no fork" : mode == 1 ? "event record + wait" : "kernel-written counter + hipStreamWaitValue32", best * 1e3 / N, best_all * 1e3 / N);
+               mode == 0 ? "no fork" : mode == 1 ? "event record + wait" : mode == 2 ? "kernel-written counter + hipStreamWaitValue32" : "hipStreamWriteValue32 + hipStreamWaitValue32", best * 1e3 / N, best_all * 1e3 / N);
     }
     unsigned h = 0;
     CK(hipMemcpy(&h, sig, 4, hipMemcpyDeviceToHost));
