@@ -616,3 +616,33 @@ def check_first_conv_wgrad_kernels_agree(lib, name, width, batch, t=49, seed=12)
     scale = float(b[:n0].abs().max())
     assert scale > 0 and float((a[:n0] - b[:n0]).abs().max()) <= 2e-5 * scale, (float((a[:n0] - b[:n0]).abs().max()), scale)
     assert not torch.equal(a[:n0], b[:n0]) or batch < 8
+
+
+def check_backward_knob_variants(lib, knob, values, bitwise, name="TCResNet8", width=1.0, batch=19, t=49, seed=14, rtol=2e-5):
+    """Backward variants behind one tcr_tune knob give the default's gradients: bitwise where the arithmetic order is the same
+    (TCR_TUNE_LAZY_STAGE = 22), to rounding where the summation order differs (TCR_TUNE_WGRAD_WAVES = 20)."""
+    import tcresnet_amd as T
+    dev = device_of(lib)
+    rng = np.random.RandomState(seed)
+    f = 40
+    x = torch.from_numpy(rng.uniform(-2, 2, (batch, t, f)).astype(np.float32)).to(dev)
+    feat = T.features_to_planar(x, lib=lib)
+    labels = torch.from_numpy(R.synth_labels(batch).astype(np.float32)).to(dev)
+    ch = R.tcresnet_channels(name, float(width))
+    grads = []
+    try:
+        for v in (0,) + tuple(values):
+            lib.tcr_tune(knob, v)
+            net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)
+            net.init_xavier(1)
+            net.forward_train(feat, labels, keep_prob=0.5, seed=9)
+            grads.append(net.backward().clone())
+    finally:
+        lib.tcr_tune(knob, 0)
+    scale = float(grads[0].abs().max())
+    assert scale > 0
+    for g in grads[1:]:
+        if bitwise:
+            assert torch.equal(grads[0], g), float((grads[0] - g).abs().max())
+        else:
+            assert float((grads[0] - g).abs().max()) <= rtol * scale, (float((grads[0] - g).abs().max()), scale)

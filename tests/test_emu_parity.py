@@ -220,3 +220,11 @@ def test_static_phase_kernels_are_bitwise_the_generic_walk(emu_lib, name, width,
 @pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 13, 49), ("TCResNet14", 1.5, 6, 98)])
 def test_first_conv_filter_gradient_kernels_agree(emu_lib, name, width, batch, t):
     Cm.check_first_conv_wgrad_kernels_agree(emu_lib, name, width, batch, t)
+
+
+def test_lazy_backward_staging_forms_are_bitwise(emu_lib):
+    Cm.check_backward_knob_variants(emu_lib, 22, (1,), True)
+
+
+def test_filter_gradient_waves_per_workgroup_agree(emu_lib):
+    Cm.check_backward_knob_variants(emu_lib, 20, (8, 16), False, batch=37)

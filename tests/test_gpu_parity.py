@@ -583,3 +583,14 @@ def test_static_phase_kernels_are_bitwise_the_generic_walk(hip_lib, name, width,
 @pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 4096, 49), ("TCResNet14", 1.5, 1031, 98), ("TCResNet8", 1.0, 3, 49)])
 def test_first_conv_filter_gradient_kernels_agree(hip_lib, name, width, batch, t):
     Cm.check_first_conv_wgrad_kernels_agree(hip_lib, name, width, batch, t)
+
+
+@pytest.mark.gpu
+def test_lazy_backward_staging_forms_are_bitwise(hip_lib):
+    Cm.check_backward_knob_variants(hip_lib, 22, (1,), True, batch=4096)
+    Cm.check_backward_knob_variants(hip_lib, 22, (1,), True, batch=517, t=98)
+
+
+@pytest.mark.gpu
+def test_filter_gradient_waves_per_workgroup_agree(hip_lib):
+    Cm.check_backward_knob_variants(hip_lib, 20, (8, 12, 16), False, batch=4096)
