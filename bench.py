@@ -195,7 +195,7 @@ def main():
     pipelined = not EMU and not ranks_share_gpu_()
     if pipelined:
         from tcresnet_amd.pipeline import InferencePipeline
-        pipe = InferencePipeline(fe, net, B, mode="alternate", ways=3)
+        pipe = InferencePipeline(fe, net, B, mode="alternate", ways=int(os.environ.get("TCR_BENCH_WAYS", "3")))     # (2 / 4: A/B arms)
         step_out = pipe.out
     # (1) clock pre-warm + the one-stream sequence: labelled, untimed by the contract (outside the K timed steps and the W warm-up steps).
     #     The first ~50 launches on an idle GPU run ~15 % slower whatever --warmup says; the sequence's sampled events give the solo kernels.
