@@ -237,7 +237,13 @@ int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t 
 // A workgroup owns kBnCB consecutive channels.  Sum of the per-workgroup partial rows (double accumulation, FIXED
 // order: chunk k goes to slice k % nparts, the slices are then added in order), spread over the whole workgroup; or
 // the pre-reduced sums (sync BN).  Returns through s_out[which * cb + (ch - c0)]; ends with a barrier.
-constexpr int kBnCB = 32;           // channels per finalize workgroup (64 columns x 8 slices of chunks)
+// channels per finalize workgroup: 32 columns x 16 slices of the partial rows.  (Round 4: 16 instead of 32 -- twice the workgroups, a thread
+// adds 32 rows of <= 512 in two trips of sixteen loads instead of four: TCResNet8 step 889 -> 866 us, TCResNet14-1.5 2737 -> 2730; 8: 867 /
+// 2744.  The slicing defines the summation order of every kernel that reduces partial rows: they all take it from here.)
+#ifndef TCR_BN_CB
+#define TCR_BN_CB 16
+#endif
+constexpr int kBnCB = TCR_BN_CB;
 // Conv epilogues (EpiSums) leave one row per workgroup / per utterance -- thousands, not <= 512: four channels per workgroup
 // there (8 columns = one 32-byte sector of a row x 64 slices, eight times the workgroups), so that a thread adds ~65 rows, sixteen
 // loads in flight: 17 us per finalize over 4160 rows.  (Measured: the 32-channel geometry 47 us, in the backward's dependency chain;
