@@ -412,7 +412,7 @@ class TCResNet(_Base):
         ws = self.workspace(b, True)
         logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
         probs = torch.empty_like(logits)
-        loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        loss = torch.empty(2, dtype=torch.float32, device=self.device)      # ([0]: written by the library; no fill kernel in front of the step)
         common = (self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(), labels.data_ptr(), b, gb,
                   float(keep_prob), int(seed), int(sample_offset), float(label_smoothing), ws.data_ptr(), ws.numel() * 4,
                   logits.data_ptr(), probs.data_ptr(), loss.data_ptr())
@@ -633,7 +633,7 @@ class DSCNN(_Base):
         ws = self.train_workspace(b)
         logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
         probs = torch.empty_like(logits)
-        loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        loss = torch.empty(2, dtype=torch.float32, device=self.device)      # ([0]: written by the library; no fill kernel in front of the step)
         common = (self._h, self.params.data_ptr(), self.stats.data_ptr(), feat.data_ptr(), labels.data_ptr(), b, gb, float(label_smoothing),
                   ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), loss.data_ptr())
         if sync_hook is None:
@@ -919,7 +919,7 @@ class Graph2D(_Base):
         ws = self.workspace(b, True)
         logits = torch.empty((b, self.num_classes), dtype=torch.float32, device=self.device)
         probs = torch.empty_like(logits)
-        loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        loss = torch.empty(2, dtype=torch.float32, device=self.device)      # ([0]: written by the library; no fill kernel in front of the step)
         common = (self._h, self.params.data_ptr(), self.stats.data_ptr(), x.data_ptr(), labels.data_ptr(), b, gb, int(seed), int(sample_offset),
                   float(label_smoothing), ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), loss.data_ptr())
         if sync_hook is None:
