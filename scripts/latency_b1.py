@@ -18,3 +18,19 @@ t0 = time.perf_counter()
 for _ in range(n):
     net.forward_waveform(fe, wav, out=out); torch.cuda.synchronize()
 print(f"B={B}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per call + sync", flush=True)
+st = torch.cuda.current_stream(dev)
+t0 = time.perf_counter()
+for _ in range(n):
+    net.forward_waveform(fe, wav, out=out); st.synchronize()
+print(f"B={B}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per call + stream synchronize", flush=True)
+ev = torch.cuda.Event()
+t0 = time.perf_counter()
+for _ in range(n):
+    net.forward_waveform(fe, wav, out=out); ev.record(st); ev.synchronize()
+print(f"B={B}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per call + event record / synchronize", flush=True)
+ev2 = torch.cuda.Event(blocking=False)
+t0 = time.perf_counter()
+for _ in range(n):
+    net.forward_waveform(fe, wav, out=out); ev2.record(st)
+    while not ev2.query(): pass
+print(f"B={B}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per call + event record / busy query", flush=True)
