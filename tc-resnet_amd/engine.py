@@ -180,6 +180,7 @@ class TCResNet(_Base):
         self.slots: Dict[str, torch.Tensor] = {}      # optimiser slots (arena-shaped)
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self._kver, self._fold_key, self._fold_ss, self._fold_event, self._fold_stream, self._fold_readers = 0, None, None, None, None, {}
+        self._fold_waited = set()
         self._wave_feat: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self.handoff = "level"         # cross-replica BN hand-off granularity: "level" (default) or "unit" (tcr_net_*_stage)
         self.reset_bn()
@@ -287,19 +288,21 @@ class TCResNet(_Base):
             if self._fold_ss is None:
                 self._fold_ss = torch.zeros(self.lib.tcr_net_frozen_floats(self._h), dtype=torch.float32, device=self.device)
             elif cur is not None and self._fold_readers:
-                for st, ev in self._fold_readers.items():   # forwards still reading the old table on other streams (the previous fold stream included)
-                    if st != cur.cuda_stream:
-                        cur.wait_event(ev)
+                for h, st in self._fold_readers.items():    # forwards that may still read the old table on other streams (the previous fold
+                    if h != cur.cuda_stream:                # stream included): everything issued on them so far
+                        cur.wait_stream(st)
             self.lib.check(self.lib.tcr_net_fold_bn(self._h, self.params.data_ptr(), self.stats.data_ptr(), self._fold_ss.data_ptr(),
                                                     self._stream()), "tcr_net_fold_bn")
             self._fold_key = key
             self._fold_readers = {}
+            self._fold_waited = set()
             if cur is not None:
                 self._fold_event = torch.cuda.Event()
                 self._fold_event.record(cur)
                 self._fold_stream = cur.cuda_stream
-        elif cur is not None and cur.cuda_stream != self._fold_stream:
-            cur.wait_event(self._fold_event)
+        elif cur is not None and cur.cuda_stream != self._fold_stream and cur.cuda_stream not in self._fold_waited:
+            cur.wait_event(self._fold_event)                # once per stream and fold: stream order covers the stream's later forwards
+            self._fold_waited.add(cur.cuda_stream)
         return self._fold_ss
 
     def forward_infer(self, feat: torch.Tensor, want_ranges: bool = False, out=None, workspace: Optional[torch.Tensor] = None):
@@ -324,13 +327,12 @@ class TCResNet(_Base):
 
     def _note_fold_reader(self):
         """A forward on the current stream has read the folded table: a refold issued from ANOTHER stream must wait for it (readers on
-        the fold stream itself are recorded too -- the next fold may come from a different stream)."""
+        the fold stream itself are noted too -- the next fold may come from a different stream).  Only the stream is noted -- the refold
+        waits for everything issued on it so far (`wait_stream`): no event record behind every forward (an event record costs the
+        stream a few microseconds of dispatch gap: per batch of the inference pipeline, per call of the batch-1 path)."""
         if self.device.type == "cuda":
             cur = torch.cuda.current_stream(self.device)
-            ev = self._fold_readers.get(cur.cuda_stream)
-            if ev is None:
-                ev = self._fold_readers[cur.cuda_stream] = torch.cuda.Event()
-            ev.record(cur)
+            self._fold_readers[cur.cuda_stream] = cur
 
     def forward_waveform(self, frontend: "Frontend", wav: torch.Tensor, want_ranges: bool = False, out=None, feat: Optional[torch.Tensor] = None):
         """Waveforms [B, n_samples] -> (logits, probs): front-end, BN fold when the weights changed since the last fold, and the network
@@ -370,6 +372,7 @@ class TCResNet(_Base):
         if refold:          # the call refolded in line (on the fold stream, no other readers): other streams order themselves behind THIS fold
             self._fold_key = ver
             self._fold_readers = {}
+            self._fold_waited = set()
             if self.device.type == "cuda":
                 st = torch.cuda.current_stream(self.device)
                 self._fold_event = torch.cuda.Event()
