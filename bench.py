@@ -341,9 +341,9 @@ def main():
             def step():
                 step_no[0] += 1
                 f = pf.get()
-                if early: pf.submit(wav)
+                if early: pf.submit(wav, input_ready=True)      # (the synthetic batch was written and synchronised before the legs began)
                 dp.forward_train(f, labels, keep_prob=0.5, seed=step_no[0])
-                if not early: pf.submit(wav)
+                if not early: pf.submit(wav, input_ready=True)
                 dp.backward()
                 net_.sgd_momentum_step(0.1, 0.9, 0.001)
 

@@ -167,7 +167,10 @@ class FeaturePrefetcher:
         self._k = 0                         # submits so far
         self._pending = None
 
-    def submit(self, wav: torch.Tensor):
+    def submit(self, wav: torch.Tensor, input_ready: bool = False):
+        """input_ready: the caller guarantees `wav` is complete (written and synchronised earlier): the front-end stream then does not
+        order itself behind the caller's current stream -- that ordering is an event record on the TRAINING stream, a few microseconds
+        of dispatch gap in every step."""
         i = self._k % 2
         if self.stream is None:
             self.fe(wav, out=self.feat[i])
@@ -176,7 +179,8 @@ class FeaturePrefetcher:
             return
         cur = torch.cuda.current_stream(self.fe.device)
         with torch.cuda.stream(self.stream):
-            self.stream.wait_stream(cur)                        # `wav` was produced on the caller's stream
+            if not input_ready:
+                self.stream.wait_stream(cur)                    # `wav` was produced on the caller's stream
             if self._free[i] is not None:
                 self.stream.wait_event(self._free[i])           # the step that consumed buffer i has been issued and finished
             self.fe(wav, out=self.feat[i])
