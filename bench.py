@@ -255,9 +255,9 @@ def main():
         roof = {"bound": "mfma", "achieved": round(fe_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fp_frac, 4)}
     else:
         roof = {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
-    traffic, traffic_src = pmc_traffic("frontend_pk_kernel<512,")
-    prof_avg_us, prof_src = profile_avg_us("frontend_pk_kernel<512,")
-    roof.update({"traffic": traffic, "traffic_source": traffic_src, "profile_avg_us": prof_avg_us, "profile_source": prof_src, "kernel": "frontend_pk_kernel<512, 10, false>", "kernel_ms": round(fe_ms, 4),
+    traffic, traffic_src = pmc_traffic("frontend_pk3_kernel<512,")
+    prof_avg_us, prof_src = profile_avg_us("frontend_pk3_kernel<512,")
+    roof.update({"traffic": traffic, "traffic_source": traffic_src, "profile_avg_us": prof_avg_us, "profile_source": prof_src, "kernel": "frontend_pk3_kernel<512, 10, false>", "kernel_ms": round(fe_ms, 4),
                  "kernel_ms_in_timed_region": round(fe_in, 4),
                  "note": "f32 VALU pipe; its 157.3 TFLOP/s peak equals the exact-f32 MFMA peak. kernel_ms: HIP-event-bracketed launches on the launch "
                          "stream in the one-stream sequence of this run (the kernel alone on the chip; every 8th step: an event record costs ~4 us of "
@@ -277,7 +277,7 @@ def main():
         "roofline": roof,
         # the co-running pair: algorithmic flops of BOTH kernels of a step / the step time of the timed region
         "pair_roofline": {"bound": "mfma", "achieved": round(whole_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(whole_tf / FP32_PEAK_TFLOPS, 4),
-                          "kernels": ["frontend_pk_kernel<512, 10, false>", "net_fused_tc8_kernel<8, 49, 0>"],
+                          "kernels": ["frontend_pk3_kernel<512, 10, false>", "net_fused_tc8_kernel<8, 49, 0>"],
                           "algorithmic_flops_per_step": B * (w["mfcc_flops"] + w["net_flops"])},
         "phases_ms": {"frontend": round(fe_ms, 4), "net": round(net_ms, 4), "frontend_in_timed_region": round(fe_in, 4), "net_in_timed_region": round(net_in, 4)},
         "sequential": {"ms_per_step": round(dt_seq / nseq * 1e3, 4) if nseq else None, "steps": nseq,

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libtcresnet_hip.so")
-SOURCES = ["tcr_common.cpp", "frontend_plan.cpp", "frontend.hip", "frontend_pk.hip", "conv.hip", "mfma.hip", "bn.hip", "head.hip",
+SOURCES = ["tcr_common.cpp", "frontend_plan.cpp", "frontend.hip", "frontend_pk.hip", "frontend_pk3.hip", "conv.hip", "mfma.hip", "bn.hip", "head.hip",
            "optim.hip", "net.cpp", "dscnn.hip", "dscnn_bwd.hip", "fused.hip", "train_fused.hip", "train_fused_bwd.hip", "bwd_lazy.hip", "augment.hip", "net2d_kernels.hip", "net2d.cpp"]
 HEADERS = ["tcr_common.h", "gfx950_isa.h", "frontend_plan.h", "frontend_args.h", "kernels.h", "net2d.h", os.path.join("..", "..", "include", "tcresnet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

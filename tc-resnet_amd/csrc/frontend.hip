@@ -332,6 +332,7 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     a.wav = wav;
     a.out = feat;
     a.window = p + L.window;
+    a.window_sgn = p + L.window_sgn;
     a.tw256 = reinterpret_cast<const float2*>(p + L.tw256);
     a.tw_combine = reinterpret_cast<const float2*>(p + L.tw_combine);
     a.tw_real = reinterpret_cast<const float2*>(p + L.tw_real);
@@ -353,12 +354,18 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     a.no_dct = cfg->method == 1;
     a.log_floor = cfg->method == 2;
     a.rounds = 0;
+    a.stagger = 0;
+    a.stagger_div = 1;
     a.aligned = ((cfg->n_samples | cfg->hop) & 1) == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0;
     const int grid = ceil_div(a.total_frames, 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int knob = tune_get(TCR_TUNE_FRONTEND);
-    if (knob == 0 || knob == 5 || knob >= 10) {           // default: packed-FP32 kernel (frontend_pk.hip) where its window specialisation applies
-        const int rc = launch_frontend_pk(cfg->nfft / 2, a, s);
+    if (knob == 0 || knob == 5 || knob >= 10) {           // default: packed-FP32 kernels where their window specialisation applies
+        if (tune_get(TCR_TUNE_FE_KERNEL) == 0) {          // three waves per SIMD (frontend_pk3.hip) for filterbanks its unrolled trips cover
+            const int rc = launch_frontend_pk3(cfg->nfft / 2, a, frontend_mel_item_count(*cfg), s);
+            if (rc != 1) return rc;
+        }
+        const int rc = launch_frontend_pk(cfg->nfft / 2, a, s);     // two waves per SIMD (frontend_pk.hip)
         if (rc != 1) return rc;
     }
     const int var = knob == 0 || knob == 5 || knob >= 10 ? 3 : (knob - 1) & 3;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void frontend_pk_kernel(const FrontendArgs 
     constexpr int NIT = mel_items_fast(NC);         // items of the unrolled trips
     __shared__ v2 s_wit[kMelItemBins * NIT];        // mel slopes [bin of the item][item], pre-scaled by 1/4 (1/2), zero past an item's end
     __shared__ int s_items[kItemsLds ? kMelItemsMax : 1];
-    static_assert(kMelItemsMax <= UNIT && NIT <= UNIT, "the item sums of a frame live in one transpose unit");
+    static_assert(kMelItemsMax < UNIT && NIT < UNIT, "the item sums of a frame (and the empty slots' cell, mel_dummy_item) live in one transpose unit");
 
     const int tid = threadIdx.x;
     const int f = tid / LPF;                // frame slot in the round

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "frontend_plan.h"
@@ -87,6 +88,11 @@ extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_pl
     std::memset(w, 0, L.words * 4);
 
     for (int i = 0; i < cfg->win; ++i) w[L.window + i] = (float)(0.5 - 0.5 * std::cos(2.0 * kPi * i / cfg->win));
+    for (int i = 0; i < cfg->win; ++i) {                    // (frontend_pk3.hip: lanes 8..15 of a 256-point unit transform x[n] (-1)^n)
+        const int np = i / (cfg->nfft / 256);               // index within the frame's even / odd (or only) complex sequence: l + 16 q
+        const bool neg = ((np >> 3) & 1) && ((np >> 4) & 1);
+        w[L.window_sgn + i] = neg ? -w[L.window + i] : w[L.window + i];
+    }
     for (int n1 = 0; n1 < 16; ++n1)
         for (int k2 = 0; k2 < 16; ++k2) {
             const double a = -2.0 * kPi * (double)(n1 * k2) / 256.0;
@@ -269,7 +275,9 @@ extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_pl
             for (int l = 0; l < lpf; ++l) phys[t * lpf + l] = lanes[l];
         }
         TCR_REQUIRE(leftovers.empty(), "front-end: mel item slots exhausted");
-        constexpr int kDummyItem = 255;             // logical index of an empty slot: a cell of the item-sum arrays nobody reads
+        const int kDummyItem = mel_dummy_item(L.nc, n);    // logical index of an empty slot: a cell of the item-sum rows nobody reads
+        static_assert(127 < (1 << 7) && kMelItemsMax < 256, "descriptor fields: segment 7 bits (14..20), logical index 8 bits (21..28)");
+        TCR_REQUIRE(L.nseg <= 127, "front-end: %d mel-edge segments do not fit the item descriptor's 7-bit field", L.nseg);
         for (int slot = 0; slot < nfast; ++slot) {
             const int i = phys[slot];
             if (i < 0) { items[slot] = kDummyItem << 21; continue; }
@@ -296,6 +304,24 @@ extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_pl
                 w[L.dct_tab + ((size_t)ct * (nm / 4) + s) * 64 + l] = v;
             }
     return TCR_OK;
+}
+
+int tcr::frontend_mel_item_count(const tcr_frontend_cfg& c) {
+    struct Entry { tcr_frontend_cfg cfg; int n; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry& e : cache)
+        if (std::memcmp(&e.cfg, &c, sizeof(c)) == 0) return e.n;
+    int n = -1;
+    if (c.nfft == 512 || c.nfft == 1024) {
+        const FrontendPlanLayout L = frontend_plan_layout(c);
+        std::vector<float> plan(L.words);
+        if (tcr_frontend_plan_init(&c, plan.data()) == TCR_OK) n = reinterpret_cast<const int32_t*>(plan.data() + L.mel_ifirst)[L.nseg];
+    }
+    if (cache.size() >= 64) cache.clear();
+    cache.push_back(Entry{c, n});
+    return n;
 }
 
 extern "C" int tcr_frontend_plan_mel_matrix(const tcr_frontend_cfg* cfg, const void* host_plan, float* out) {

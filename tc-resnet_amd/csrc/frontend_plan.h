@@ -25,6 +25,8 @@ struct FrontendPlanLayout {
     size_t mel_wit;    // float2 [mel_item_bins][mel_items_fast]  (up, down) slopes of bin b of item i, zero past the item's end and for
                        //                        items the filterbank does not have: the kernel's LDS copy (bin-major: a trip's lanes read
                        //                        consecutive items -> consecutive addresses), pre-scaled like `wud` is NOT (the kernel folds)
+    size_t window_sgn; // float  [win]           the window with the sign (-1)^q of frontend_pk3.hip's lanes 8..15: sample i of a frame is
+                       //                        radix-16 input q = n' >> 4 of lane l = n' & 15, n' = i / (nfft / 256); negated where l >= 8 and q is odd
     size_t dct_tab;    // float  [n_mel/16][n_mel/4][64]  DCT A fragments: tile ct, step s, lane l -> D[16 ct + (l & 15)][4 s + (l >> 4)] (0 past n_coef)
     size_t words;      // total size in words
 };
@@ -35,6 +37,16 @@ constexpr int mel_item_bins(int nc) { return nc == 512 ? 8 : 4; }
 // items the packed kernel handles with its unrolled trips (trips x lanes per frame); a filterbank with more items runs the rest in a slow loop
 constexpr int mel_trips(int nc) { return nc == 512 ? 3 : 6; }      // (the reference filterbank: 91 items of 8 bins at nfft 1024, 89 of 4 at nfft 512)
 constexpr int mel_items_fast(int nc) { return mel_trips(nc) * (nc / 16); }
+// Logical index the plan gives the EMPTY slots of the unrolled trips: a cell of the item-sum row no band ever reads.  A filterbank
+// whose items all fit the unrolled trips (n <= mel_items_fast) puts it right behind them, so the three-waves kernel's compact item-sum
+// rows (frontend_pk3.hip) hold it; a larger one (slow path, frontend_pk.hip only) behind the last possible item.
+constexpr int mel_dummy_item(int nc, int n_items) { return n_items <= mel_items_fast(nc) ? mel_items_fast(nc) : kMelItemsMax; }
+static_assert(kMelItemsMax < 255 && mel_items_fast(512) <= kMelItemsMax && mel_items_fast(256) <= kMelItemsMax,
+              "an item descriptor carries the logical index in 8 bits (bits 21..28), the empty slots' cell included");
+
+// Number of work items of the configuration's filterbank (what tcr_frontend_plan_init writes to mel_ifirst[nseg]); cached per
+// configuration.  -1: the configuration does not resolve.
+int frontend_mel_item_count(const tcr_frontend_cfg& c);
 
 inline FrontendPlanLayout frontend_plan_layout(const tcr_frontend_cfg& c) {
     FrontendPlanLayout l{};
@@ -53,6 +65,7 @@ inline FrontendPlanLayout frontend_plan_layout(const tcr_frontend_cfg& c) {
     l.mel_items = take(kMelItemsMax);
     l.mel_ifirst = take((size_t)l.nseg + 2);
     l.mel_wit = take(2 * (size_t)mel_item_bins(l.nc) * (size_t)mel_items_fast(l.nc));
+    l.window_sgn = take((size_t)c.win);
     l.dct_tab = take((size_t)(c.n_mel / 16) * (size_t)(c.n_mel / 4) * 64);
     l.words = o;
     return l;

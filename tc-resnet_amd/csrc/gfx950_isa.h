@@ -21,6 +21,13 @@ __device__ __forceinline__ int opaque_zero() {
     return z;
 }
 
+// The same zero, produced only after `dep` exists: pins loads whose address uses it behind the computation of `dep`.
+__device__ __forceinline__ int opaque_zero_after(float dep) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(dep));
+    return z;
+}
+
 typedef float v2 __attribute__((ext_vector_type(2)));
 typedef float v4 __attribute__((ext_vector_type(4)));
 

@@ -94,6 +94,12 @@ def check_frontend_edges(lib, tag):
         errs["scalar"] = np.abs(g2 - fx["mfcc"]).max(axis=(1, 2))
     finally:
         lib.tcr_tune(1, 0)
+    try:
+        lib.tcr_tune(23, 1)                                 # the two-waves-per-SIMD packed kernel (frontend_pk.hip)
+        g3 = fe.reference_view(fe(wav))[..., 0].cpu().numpy()
+        errs["packed2"] = np.abs(g3 - fx["mfcc"]).max(axis=(1, 2))
+    finally:
+        lib.tcr_tune(23, 0)
     fd = make_frontend(lib, fx["win"], fx["hop"], method="mfcc_deploy")
     gd = fd.reference_view(fd(wav))[..., 0].cpu().numpy()
     errs["deploy"] = np.abs(gd - fx["mfcc_deploy"]).max(axis=(1, 2))
@@ -101,6 +107,24 @@ def check_frontend_edges(lib, tag):
         assert e[:4].max() < MFCC_TOL, f"edge rows {tag} / {k}: per-row max abs err {e}"
         assert e[4:].max() < (0.5 if k == "deploy" else 1e-3), f"pure-tone rows {tag} / {k}: per-row max abs err {e}"
     return errs
+
+
+def check_frontend_kernels_bitwise(lib, batch):
+    """The three-waves-per-SIMD front-end (frontend_pk3.hip, default) against the two-waves kernel of rounds 2-4 (frontend_pk.hip,
+    knob 23 = 1): the same operations in the same order on every value -- bitwise, for both reference framings, every method, the
+    DS-CNN coefficient count and a ragged batch (partial last chunk, more chunks than workgroups at the larger size)."""
+    wav = to_dev(lib, np.concatenate([R.synth_waveforms(min(batch, 64), seed=5)] * ((batch + 63) // 64), axis=0)[:batch].copy())
+    cases = [(640, 320, "mfcc", 40), (480, 160, "mfcc", 40), (640, 320, "mfcc", 10), (640, 320, "log_mel_spectrogram", 40),
+             (480, 160, "log_mel_spectrogram", 40), (640, 320, "mfcc_deploy", 40), (480, 160, "mfcc_deploy", 40), (320, 160, "mfcc", 40)]
+    for win, hop, method, nc in cases:
+        fe = make_frontend(lib, win, hop, method=method, num_mfccs=nc)
+        new = fe(wav).clone()
+        try:
+            lib.tcr_tune(23, 1)
+            old = fe(wav).clone()
+        finally:
+            lib.tcr_tune(23, 0)
+        assert torch.equal(new, old), (win, hop, method, nc, float((new - old).abs().max()))
 
 
 def check_frontend_deploy(lib, tag):

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 OUT=tests/emu/_build
 mkdir -p $OUT/obj
 SRC="tc-resnet_amd/csrc"
-FILES="tcr_common.cpp frontend_plan.cpp frontend.hip frontend_pk.hip conv.hip mfma.hip bn.hip head.hip optim.hip net.cpp dscnn.hip dscnn_bwd.hip fused.hip train_fused.hip train_fused_bwd.hip bwd_lazy.hip augment.hip net2d_kernels.hip net2d.cpp"
+FILES="tcr_common.cpp frontend_plan.cpp frontend.hip frontend_pk.hip frontend_pk3.hip conv.hip mfma.hip bn.hip head.hip optim.hip net.cpp dscnn.hip dscnn_bwd.hip fused.hip train_fused.hip train_fused_bwd.hip bwd_lazy.hip augment.hip net2d_kernels.hip net2d.cpp"
 FLAGS="-std=c++17 -O2 -fPIC -x c++ -I tests/emu -Wall -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-unknown-pragmas -Wno-pass-failed"
 printf '%s\n' $FILES | xargs -P "$(nproc 2>/dev/null || echo 4)" -I{} /opt/rocm/lib/llvm/bin/clang++ $FLAGS -c $SRC/{} -o $OUT/obj/{}.o
 OBJS=""

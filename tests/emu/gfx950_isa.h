@@ -11,6 +11,7 @@ inline char* dyn_lds() {
 }
 
 __device__ __forceinline__ int opaque_zero() { return 0; }
+__device__ __forceinline__ int opaque_zero_after(float) { return 0; }
 
 typedef float v2 __attribute__((ext_vector_type(2)));
 typedef float v4 __attribute__((ext_vector_type(4)));

@@ -20,6 +20,10 @@ def test_frontend_edge_rows(emu_lib, tag):
     Cm.check_frontend_edges(emu_lib, tag)
 
 
+def test_frontend_three_wave_kernel_is_bitwise_the_two_wave_kernel(emu_lib):
+    Cm.check_frontend_kernels_bitwise(emu_lib, 5)
+
+
 def test_frontend_variants(emu_lib):
     fx = Cm.load("frontend_4020.npz")
     wav = torch.from_numpy(fx["wav"])

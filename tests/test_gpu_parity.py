@@ -104,6 +104,11 @@ def test_frontend_persistent_chunks_are_position_independent(hip_lib, win, hop):
     assert float((big[:64] - ref).abs().max()) < Cm.MFCC_TOL
 
 
+@pytest.mark.parametrize("batch", [5, 4099])
+def test_frontend_three_wave_kernel_is_bitwise_the_two_wave_kernel(hip_lib, batch):
+    Cm.check_frontend_kernels_bitwise(hip_lib, batch)
+
+
 def test_frontend_variants(hip_lib):
     fx = Cm.load("frontend_4020.npz")
     wav = Cm.to_dev(hip_lib, fx["wav"])
