@@ -107,7 +107,7 @@ def main():
     if args.no_extras or args.legs == "none":
         legs = set()
     elif args.legs == "all":
-        legs = set(LEGS) if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and os.environ.get("TCR_BENCH_FORCE_DIST") != "1" else {"train"}      # (several ranks: see "secondary legs" below)
+        legs = set(LEGS) if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and os.environ.get("TCR_BENCH_FORCE_DIST") != "1" else {"train", "train14"}      # (several ranks: the two legs whose gradient all-reduce crosses xGMI -- configs[2] and configs[3], TCResNet14-1.5 at global batch 4096 N; see "secondary legs" below)
     else:
         legs = set(x for x in args.legs.split(",") if x)
         if legs - set(LEGS):
@@ -376,7 +376,7 @@ def main():
             # ---------------- TCResNet14-1.5 training (configs[3]: global batch 32768 = 8 x 4096 over RCCL) ----------------
             net14 = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, fe.n_frames, 12, lib=lib, device=dev)
             net14.init_xavier(0)
-            out["train_tcresnet14_1.5"] = train_leg(fe, net14, floor(20, args.steps // 4), floor(10, args.warmup // 2))
+            out["train_tcresnet14_1.5"] = train_leg(fe, net14, floor(20, max(1, args.steps // 4)), floor(10, args.warmup // 2))
             out["train_tcresnet14_1.5"]["workload"] = (f"TCResNet14-1.5 train step, batch {B}/GPU (global {world * B}), 303 144 params"
                                                        + (f", {coll} all-reduce of the 1.21 MB gradient arena" if dist_on else ""))
             out["collectives_per_step"]["train_tcresnet14_1.5"] = out["train_tcresnet14_1.5"]["collectives_per_step"]

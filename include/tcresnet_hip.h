@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TCR_ABI_VERSION 2
+#define TCR_ABI_VERSION 3
 #define TCR_HALO 4
 #define TCR_MAX_BLOCKS 16
 
@@ -80,6 +80,12 @@ int tcr_frontend_plan_dct_matrix(const tcr_frontend_cfg* cfg, const void* host_p
  * mfccs_from_log_mel_spectrograms (datasets/preprocessors.py:68-94,191-193). */
 int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_dev, const float* wav, int batch,
                      float* feat, void* stream);
+/* The same with a per-call launch hint: `rounds` > 0 fixes the packed kernels' rounds of frames per persistent-workgroup chunk
+ * (clamped to what the kernel supports; 0 = the launcher's cost model, i.e. tcr_frontend_fwd).  A caller that runs the front-end
+ * next to other kernels (tcresnet_amd.pipeline) passes its own measured choice here instead of flipping the process-wide
+ * TCR_TUNE_FRONTEND knob around the launch.  Results do not depend on it. */
+int tcr_frontend_fwd_rounds(const tcr_frontend_cfg* cfg, const void* plan_dev, const float* wav, int batch,
+                            float* feat, int rounds, void* stream);
 
 /* "no_preprocessing" (datasets/preprocessors.py:45-49): re-layout a reference-shaped feature
  * tensor [batch][T][F] into the planar halo layout [batch][F][Tp], and back. */

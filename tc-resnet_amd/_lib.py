@@ -13,7 +13,7 @@ from typing import Optional
 
 HALO = 4
 MAX_BLOCKS = 16
-ABI_VERSION = 2            # == TCR_ABI_VERSION of include/tcresnet_hip.h these prototypes were written against
+ABI_VERSION = 3            # == TCR_ABI_VERSION of include/tcresnet_hip.h these prototypes were written against
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "lib", "libtcresnet_hip.so")
 
@@ -60,6 +60,7 @@ _PROTOTYPES = {
     "tcr_frontend_plan_mel_matrix": (C.c_int, [C.POINTER(FrontendCfg), _P, _P]),
     "tcr_frontend_plan_dct_matrix": (C.c_int, [C.POINTER(FrontendCfg), _P, _P]),
     "tcr_frontend_fwd": (C.c_int, [C.POINTER(FrontendCfg), _P, _P, C.c_int, _P, _P]),
+    "tcr_frontend_fwd_rounds": (C.c_int, [C.POINTER(FrontendCfg), _P, _P, C.c_int, _P, C.c_int, _P]),
     "tcr_features_to_planar": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "tcr_features_from_planar": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "tcr_tcresnet_create": (C.c_int, [C.POINTER(TCResNetCfg), C.POINTER(_P)]),

@@ -506,6 +506,12 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize2_kernel(const BnBwdFinali
 int launch_bn_bwd_finalize2(const BnBwdFinalizeArgs& a0, const BnBwdFinalizeArgs& b0, hipStream_t s) {
     BnBwdFinalizeArgs a = a0, b = b0;
     a.cbw = bn_finalize_cb(a.nchunk); b.cbw = bn_finalize_cb(b.nchunk);
+    // one launch serves both units with ONE thread count: the slicing of the partial rows (reduce_partials) is a function of the thread
+    // count and of cbw, so the units must agree on both; callers whose units differ get two launches (same results, one launch more)
+    if (bn_finalize_threads(a.nchunk) != bn_finalize_threads(b.nchunk) || a.cbw != b.cbw) {
+        const int rc = launch_bn_bwd_finalize(a0, s);
+        return rc != TCR_OK ? rc : launch_bn_bwd_finalize(b0, s);
+    }
     const int gx = max(ceil_div(a.c, a.cbw), ceil_div(b.c, b.cbw));
     hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(gx, 2), dim3(bn_finalize_threads(a.nchunk)), 0, s, a, b);
     return check_launch("bn_bwd_finalize2_kernel");

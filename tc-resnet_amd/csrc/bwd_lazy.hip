@@ -17,6 +17,9 @@
 //            DPP row (row16_sum) -> the slot's LDS row -> ONE partial row per workgroup, summed in double by bn_bwd_finalize.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "kernels.h"
 
@@ -442,7 +445,22 @@ static bool configure_lazy(BwdLazyArgs& a, size_t* lds_out, int* grid_out) {
         for (const auto& mrow : kMeasured)
             if (mrow[0] == a.out_c && mrow[1] == a.out_t && mrow[2] == a.n_layers && mrow[3] == a.src[0].c && mrow[4] == a.src[0].t)
                 knob = mrow[6] * 100 + mrow[5];
-    for (int g = 1; g <= 16; ++g) {
+    // The search below is pure in (shape, batch, knob): its result is memoised -- the plan of a net is asked for several times per BN unit
+    // and backward (rows of the finalize passes, the coverage test, the launch), always with the same answer.
+    struct GeoKey { int v[16]; };
+    struct GeoVal { GeoKey key; int g, ks; };
+    static std::mutex geo_mu;
+    static std::vector<GeoVal> geo_cache;
+    GeoKey key = {{a.out_c, a.out_t, a.n_layers, S, a.batch, knob, a.layer[0].k, a.layer[0].pad_lo, a.src[0].c, a.src[0].t,
+                   a.n_layers > 1 ? a.layer[1].k : 0, a.n_layers > 1 ? a.layer[1].pad_lo : 0, a.n_layers > 1 ? a.src[1].c : 0, a.n_layers > 1 ? a.src[1].t : 0,
+                   device_cus(), 0}};
+    bool cached = false;
+    {
+        std::lock_guard<std::mutex> lock(geo_mu);
+        for (const GeoVal& e : geo_cache)
+            if (std::memcmp(&e.key, &key, sizeof(key)) == 0) { best_g = e.g; best_ks = e.ks; cached = true; break; }
+    }
+    for (int g = 1; g <= 16 && !cached; ++g) {
         if (knob % 100 > 0 && g != knob % 100) continue;
         const int g_eff = min(g, a.batch);
         const int pairs0 = ceil_div(g_eff * a.nu[0], 32), pairs1 = S > 1 ? ceil_div(g_eff * a.nu[1], 32) : 0;
@@ -463,6 +481,11 @@ static bool configure_lazy(BwdLazyArgs& a, size_t* lds_out, int* grid_out) {
             if (best_g == 0 || cost < best) { best = cost; best_g = g; best_ks = ks; }
         }
     }
+    if (!cached) {
+        std::lock_guard<std::mutex> lock(geo_mu);
+        if (geo_cache.size() >= 256) geo_cache.clear();
+        geo_cache.push_back(GeoVal{key, best_g, best_ks});
+    }
     if (best_g == 0) return false;
     a.group = best_g; a.ks = best_ks; a.nw = kLzNW; a.n_groups = ceil_div(a.batch, a.group);
     const int slots = kLzNW / a.ks;
@@ -479,7 +502,8 @@ static bool configure_lazy(BwdLazyArgs& a, size_t* lds_out, int* grid_out) {
     a.ecoef_off = a.coef_off + coef_floats;
     *lds_out = lds_of(a.group, a.ks);
     *grid_out = min(a.n_groups, kPhaseMaxRows);
-    if (getenv("TCR_DEBUG_LAZY"))
+    static const bool debug_lazy = getenv("TCR_DEBUG_LAZY") != nullptr;
+    if (debug_lazy)
         fprintf(stderr, "bwd_lazy: out %dx%d layers %d src %dx%d stride %d -> group %d ks %d mt %d lds %zu grid %d chunks %lld/%lld\n", a.out_c, a.out_t, a.n_layers,
                 a.src[0].c, a.src[0].t, S, a.group, a.ks, a.mt, *lds_out, *grid_out, (long long)chunks[0], (long long)chunks[1]);
     return true;

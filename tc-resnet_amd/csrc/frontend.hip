@@ -322,6 +322,11 @@ using namespace tcr;
 
 extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_dev, const float* wav, int batch,
                                 float* feat, void* stream) {
+    return tcr_frontend_fwd_rounds(cfg, plan_dev, wav, batch, feat, 0, stream);
+}
+
+extern "C" int tcr_frontend_fwd_rounds(const tcr_frontend_cfg* cfg, const void* plan_dev, const float* wav, int batch,
+                                       float* feat, int rounds, void* stream) {
     TCR_REQUIRE(cfg && plan_dev && wav && feat, "tcr_frontend_fwd: null argument");
     TCR_REQUIRE(batch > 0, "tcr_frontend_fwd: batch must be positive (got %d)", batch);
     TCR_REQUIRE(cfg->nfft == 512 || cfg->nfft == 1024, "tcr_frontend_fwd: unresolved or unsupported configuration (nfft=%d)", cfg->nfft);
@@ -353,7 +358,7 @@ extern "C" int tcr_frontend_fwd(const tcr_frontend_cfg* cfg, const void* plan_de
     a.magnitude = cfg->method != 0;
     a.no_dct = cfg->method == 1;
     a.log_floor = cfg->method == 2;
-    a.rounds = 0;
+    a.rounds = rounds > 0 ? rounds : 0;        // (> 0: the caller's choice; the packed launchers clamp it, 0: their cost model)
     a.stagger = 0;
     a.stagger_div = 1;
     a.aligned = ((cfg->n_samples | cfg->hop) & 1) == 0 && (reinterpret_cast<uintptr_t>(wav) & 7) == 0;

@@ -421,6 +421,7 @@ int launch_frontend_pk(int nc, const FrontendArgs& a0, hipStream_t s) {
         }
         const int knob = tune_get(TCR_TUNE_FRONTEND);
         if (knob >= 10) best = min(max(knob - 10, 1), max_rounds);
+        if (a0.rounds > 0) best = min(a0.rounds, max_rounds);      // (tcr_frontend_fwd_rounds: the caller's per-call choice)
         a.rounds = best;
         grid = min(ceil_div(a.total_frames, best * fpr), slots);
         const int cap = tune_get(TCR_TUNE_FE_GRID);

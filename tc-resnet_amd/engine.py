@@ -109,8 +109,9 @@ class Frontend(_Base):
         return out
 
     # compute -----------------------------------------------------------------------------------
-    def __call__(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """wav [B, n_samples] or [B, n_samples, 1] -> planar features [B, n_coef, T + 2*HALO]."""
+    def __call__(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None, rounds: int = 0) -> torch.Tensor:
+        """wav [B, n_samples] or [B, n_samples, 1] -> planar features [B, n_coef, T + 2*HALO].  rounds > 0: a per-call launch hint
+        (rounds of frames per persistent-workgroup chunk, tcr_frontend_fwd_rounds); the features do not depend on it."""
         if wav.dim() == 3:
             if wav.shape[-1] != 1:
                 raise TcrError("front-end accepts single-channel audio only")     # tf.squeeze(audio, -1)
@@ -121,8 +122,8 @@ class Frontend(_Base):
         b = wav.shape[0]
         if out is None:
             out = torch.empty((b, self.cfg.n_coef, padded_len(self.cfg.n_frames)), dtype=torch.float32, device=self.device)
-        self.lib.check(self.lib.tcr_frontend_fwd(C.byref(self.cfg), self.plan.data_ptr(), wav.data_ptr(), b, out.data_ptr(),
-                                                 self._stream()), "tcr_frontend_fwd")
+        self.lib.check(self.lib.tcr_frontend_fwd_rounds(C.byref(self.cfg), self.plan.data_ptr(), wav.data_ptr(), b, out.data_ptr(),
+                                                        int(rounds), self._stream()), "tcr_frontend_fwd")
         return out
 
     def reference_view(self, feat: torch.Tensor) -> torch.Tensor:

@@ -187,8 +187,11 @@ class AudioNetModel(TFModel):
             # would have written put back.
             saved = self.engine.stats.clone()
             dp0 = self.data_parallel(sync_bn)
+            # (fresh dropout per session.run, as in the reference: a counter of its own -- self._step only moves with optimiser steps --
+            #  offset so that it never shares a seed with an optimisation step of the same run)
+            self._noop_step = getattr(self, "_noop_step", 0) + 1
             self.logits, self._outputs, loss_sum = dp0.forward_train(
-                self._preprocessor.planar, labels, keep_prob=self._keep_prob(), seed=self._step,
+                self._preprocessor.planar, labels, keep_prob=self._keep_prob(), seed=self._step + (1 << 24) + self._noop_step,
                 label_smoothing=float(getattr(self.args, "label_smoothing", 0.0)))
             self.engine.stats.copy_(saved)
             self._model_loss = dp0.mean_loss(loss_sum, wavs.shape[0])

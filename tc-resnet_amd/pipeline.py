@@ -112,14 +112,9 @@ class InferencePipeline:
         return self.out[i]
 
     def _frontend(self, wav, out):
-        if self.fe_rounds is None:
-            return self.fe(wav, out=out)
-        lib = self.fe.lib
-        lib.tcr_tune(1, 10 + int(self.fe_rounds))       # (read by the launcher at launch time; restored right behind it)
-        try:
-            return self.fe(wav, out=out)
-        finally:
-            lib.tcr_tune(1, 0)
+        # (a per-call launch argument, tcr_frontend_fwd_rounds: nothing process-wide is touched, other threads' / front-ends' launches and
+        #  a user's TCR_TUNE_FRONTEND setting are unaffected)
+        return self.fe(wav, out=out, rounds=int(self.fe_rounds or 0))
 
     def done_event(self, slot: int) -> "torch.cuda.Event":
         """The event recorded behind the network of the batch last submitted into output slot `slot` (= submit index % depth)."""

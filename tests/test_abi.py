@@ -35,7 +35,7 @@ def test_exports_every_declared_symbol(lib):
     for n in sorted(declared):
         assert hasattr(dll, n), f"{n} declared in include/tcresnet_hip.h but not exported"
     assert declared == set(T._lib.ABI_SYMBOLS), declared ^ set(T._lib.ABI_SYMBOLS)
-    assert lib.tcr_abi_version() == T._lib.ABI_VERSION == 2
+    assert lib.tcr_abi_version() == T._lib.ABI_VERSION == 3
     assert lib.tcr_kernel_name(0) == b"frontend_pk_kernel" and lib.tcr_kernel_name(999) is None
 
 

@@ -233,7 +233,7 @@ def _bench_plain_command(env_extra, batch, legs_ok=True):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--batch", str(batch),
-           "--no-cpu-baseline"]           # (several ranks: the default legs are the training leg alone)
+           "--no-cpu-baseline"]           # (several ranks: the default legs are the two training legs, configs[2] and configs[3])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -244,8 +244,11 @@ def _bench_plain_command(env_extra, batch, legs_ok=True):
     if not legs_ok:
         return out
     assert "secondary_legs" not in out and "dscnn_l_forward" not in out
-    assert out["collectives_per_step"] == {"forward": 0, "train": 1.0}        # replicas only / ONE all-reduce of the gradient arena
+    # replicas only / ONE all-reduce of the gradient arena per step, for TCResNet8-1.0 and for BASELINE configs[3] (TCResNet14-1.5, global batch 4096 N at full size)
+    assert out["collectives_per_step"] == {"forward": 0, "train": 1.0, "train_tcresnet14_1.5": 1.0}
     assert out["train"]["value"] > 0 and out["train"]["collectives_per_step"] == 1.0
+    t14 = out["train_tcresnet14_1.5"]
+    assert t14["value"] > 0 and t14["collectives_per_step"] == 1.0 and f"global {2 * batch}" in t14["workload"] and "all-reduce" in t14["workload"]
     return out
 
 
@@ -295,4 +298,5 @@ def test_bench_single_rank_goes_through_rccl(hip_lib):
     out = json.loads(lines[0])
     assert out["collective_backend"] == "RCCL (backend nccl)" and out["n_gpus"] == 1 and out["value"] > 0
     assert "secondary_legs" not in out, out["secondary_legs"]
-    assert out["train"]["value"] > 0 and out["collectives_per_step"] == {"forward": 0, "train": 1.0}
+    assert out["train"]["value"] > 0 and out["train_tcresnet14_1.5"]["value"] > 0
+    assert out["collectives_per_step"] == {"forward": 0, "train": 1.0, "train_tcresnet14_1.5": 1.0}
