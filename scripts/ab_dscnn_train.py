@@ -39,7 +39,8 @@ for size in os.environ.get("AB_SIZES", "L,M").split(","):
         ds.forward_train(feat, lab)
     def bwd():
         ds.backward()
-    for knob in (1, 2, 4, 0, 1, 2, 4, 0):
+    step()
+    for knob in [int(k) for k in os.environ.get("AB_KNOBS", "1,2,4,0,1,2,4,0").split(",")]:
         lib.tcr_tune(15, knob)
         t_f = timeit(fwd)
         t_b = timeit(bwd)

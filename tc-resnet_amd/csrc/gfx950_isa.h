@@ -32,6 +32,17 @@ typedef float v2 __attribute__((ext_vector_type(2)));
 typedef float v4 __attribute__((ext_vector_type(4)));
 
 
+// 16 bytes per lane, global -> LDS by the DMA path (global_load_lds_dwordx4): lane l's 16 bytes land at lds_wave_base + 16 l --
+// `lds_wave_base` must be wave-uniform, the global address is per lane.  Asynchronous: counted on vmcnt; a barrier built from
+// __syncthreads() drains it (its fence waits vmcnt(0)).
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(gsrc)),
+                                     reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_wave_base))), 16, 0, 0);
+}
+
+// waits for this wave's outstanding glds16 copies (and any other vector-memory load): s_waitcnt vmcnt(0)
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // a - i b = (a.x + b.y, a.y - b.x)
 __device__ __forceinline__ v2 c_submi(v2 a, v2 b) {
     v2 d;

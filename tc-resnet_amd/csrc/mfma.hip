@@ -1384,10 +1384,146 @@ __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) 
             }
 }
 
-static int pw_wgrad_chunks(int batch) {
-    int n = ceil_div(batch, 36);        // ~2 rounds of 9-block groups over 512 workgroup slots at batch 4096
+// ---------------------------------------------------------------------------------------------
+// The same filter gradient with the operand blocks copied global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers,
+// no ds_write pass) into TWO buffers: while the twelve waves of a workgroup multiply utterance n out of one buffer, utterance n + 1
+// lands in the other; one barrier per utterance.  One workgroup per CU (112 KB of LDS), three waves per SIMD: three groups of four
+// waves, every group the 2 x 2 arrangement of 3 x 3-tile waves of the kernel above (six LDS reads feed nine MFMAs) on every third
+// 4-position step of the utterance (rotating with the utterance: 17 steps = 6 + 6 + 5); the groups' accumulators meet in LDS at the end.
+// Round 4's kernel (above: register-staged, one buffer, two 4-wave workgroups per CU, two barriers and a 57 KB ds_write pass per
+// utterance) spent ~45 % of its time outside the MFMA loop.
+// The LDS image of a stage is the x block followed DIRECTLY by the dz block (a DMA instruction writes base + lane * 16: the image is
+// one contiguous run of float4); rows past the block's channel count: x rows are masked where the fragment leaves LDS, dz rows read the
+// zeroed space behind the image.
+// ---------------------------------------------------------------------------------------------
+template <bool XAFF>
+__global__ __launch_bounds__(768) void pw_wgrad_glds_kernel(const PwWgradArgs a) {
+    constexpr int BT = 96, NW = 12, NG = 3;
+    float* lds = reinterpret_cast<float*>(dyn_lds());
+    const int stage = 2 * BT * a.pp;                        // floats per buffer
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int grp = wave >> 2, w4 = wave & 3;
+    // XCD-aware workgroup -> (chunk, block) map of pw_wgrad_lds_kernel: a chunk's blocks run on ONE XCD and share its L2
+    const int nb = a.nby * a.nbz;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int chunk = (jj / nb) * 8 + xcd, blk = jj % nb;
+    if (chunk >= a.nchunk) return;
+    const int ci0 = (blk % a.nby) * BT, co0 = (blk / a.nby) * BT;
+    const int xrows = min(BT, a.cin - ci0), drows = min(BT, a.cout - co0);
+    const int xv = xrows * a.pp / 4, tv = xv + drows * a.pp / 4;        // float4 counts: x block, whole image (host checks divisibility)
+    for (int i = tid; i < 2 * stage; i += 64 * NW) lds[i] = 0.f;        // (the space behind an image stays zero: dz rows past Cout)
+    const int wm = (w4 >> 1) * 3, wn = (w4 & 1) * 3;
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int ao[3], bo[3];
+    float xsc[3], xsf[3];
+    bool aok[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int arow = (wm + m) * 16 + r;
+        aok[m] = arow < xrows;
+        ao[m] = arow * a.pp + kHalo + q;
+        bo[m] = xrows * a.pp + ((wn + m) * 16 + r) * a.pp + kHalo + q;
+        xsc[m] = (XAFF && aok[m]) ? a.x_scale[ci0 + arow] : 0.f;
+        xsf[m] = (XAFF && aok[m]) ? a.x_shift[ci0 + arow] : 0.f;
+    }
+    const int n_begin = chunk * a.utt_per_block;
+    const int n_end = min(n_begin + a.utt_per_block, a.batch);
+    const int nks = (a.p + 3) >> 2;                         // 4-position steps per utterance
+    // one stage: DMA instruction i of this wave covers float4 [(i * NW + wave) * 64, + 64) of the image
+    auto issue = [&](int n, int buf) {
+        const float4* xg4 = reinterpret_cast<const float4*>(a.x + ((size_t)n * a.cin + ci0) * a.pp);
+        const float4* dg4 = reinterpret_cast<const float4*>(a.dz + ((size_t)n * a.cout + co0) * a.pp);
+        float* dst = lds + buf * stage;
+        for (int v0 = wave * 64; v0 < tv; v0 += 64 * NW) {
+            const int v = v0 + lane;
+            if (v < tv) glds16(v < xv ? xg4 + v : dg4 + (v - xv), dst + v0 * 4);
+        }
+    };
+    __syncthreads();                                        // the zeroed buffers
+    if (n_begin < n_end) issue(n_begin, 0);
+    int rot = grp;                                          // this group's first step of the current utterance: (grp - i) mod 3
+    for (int n = n_begin; n < n_end; ++n) {
+        const int cur = (n - n_begin) & 1;
+        wait_dma();                                         // this wave's share of stage n has landed ...
+        __syncthreads();                                    // ... everybody's has; nobody still reads the other buffer
+        if (n + 1 < n_end) issue(n + 1, cur ^ 1);
+        const float* xs = lds + cur * stage;
+        if (rot < nks) {
+            float af[3], bf[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { af[m] = xs[ao[m] + 4 * rot]; bf[m] = xs[bo[m] + 4 * rot]; }
+            for (int ks = rot; ks < nks; ks += NG) {
+                const int k0 = 4 * ks;
+                float an[3], bn[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { an[m] = xs[ao[m] + k0 + 4 * NG]; bn[m] = xs[bo[m] + k0 + 4 * NG]; }   // (past the end: rows / zeroed space behind; never used)
+                const bool in = k0 + q < a.p;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) af[m] = XAFF ? ((in && aok[m]) ? fmaxf(fmaf(af[m], xsc[m], xsf[m]), 0.f) : 0.f) : (aok[m] ? af[m] : 0.f);
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < 3; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nn], acc[m][nn], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { af[m] = an[m]; bf[m] = bn[m]; }
+            }
+        }
+        rot = rot == 0 ? NG - 1 : rot - 1;
+    }
+    // the three groups' partial tiles: groups 1, 2 through LDS (fixed order: group 0 + group 1 + group 2)
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    if (grp > 0) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 3; ++nn) red[(((grp - 1) * 4 + w4) * 9 + m * 3 + nn) * 64 + lane] = acc[m][nn];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+    float* dst = a.partial + (size_t)chunk * a.cin_pad * a.cout_pad;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 3; ++nn) {
+            f32x4 t = acc[m][nn];
+#pragma unroll
+            for (int g = 0; g < NG - 1; ++g) {
+                const f32x4 o = red[((g * 4 + w4) * 9 + m * 3 + nn) * 64 + lane];
+                t[0] += o[0]; t[1] += o[1]; t[2] += o[2]; t[3] += o[3];
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ci = ci0 + (wm + m) * 16 + q * 4 + reg, co = co0 + (wn + nn) * 16 + r;
+                if (ci < a.cin_pad && co < a.cout_pad) dst[(size_t)ci * a.cout_pad + co] = t[reg];
+            }
+        }
+}
+
+// Chunks of utterances (split-K slabs).  The workgroups of a chunk -- one per 96 x 96 block of dW -- land on ONE XCD (see the kernel's
+// map), two per CU: a count that fills a whole number of rounds of an XCD's slots.  (Round 4 used ceil(batch / 36): at batch 4096 and
+// nine blocks that is 1026 workgroups on 1024 slots -- XCDs 0 and 1 ran a third round for one extra chunk each: +50 % on the kernel.)
+static int pw_wgrad_chunks(int batch, int cin, int cout, int wg_per_cu) {
+    const int nb = ceil_div(cin, 96) * ceil_div(cout, 96);
+    const int slots_per_xcd = max(1, wg_per_cu * device_cus() / 8);
+    const int one = 8 * max(1, slots_per_xcd / nb), two = 8 * max(1, 2 * slots_per_xcd / nb);      // chunks that fill one / two rounds
+    int n = ceil_div(batch, one) > 48 ? two : one;         // (two rounds once a chunk would hold more than 48 utterances: shorter tail)
     if (n > 128) n = 128;
+    if (n > batch) n = batch;
     return n < 1 ? 1 : n;
+}
+// round 4's register-staged kernel unless the knob asks for the DMA-staged one (measured: 573 vs 561 us per launch at 276 channels, 258 vs
+// 249 at 172 -- with one stage of lookahead both sit at ~3.8 us per utterance and CU, the operand blocks' L2 / HBM round trip, not the
+// 2.0 us of matrix work; a third LDS buffer does not fit: OPTLOG round 5)
+static bool pw_wgrad_use_glds() { return tune_get(TCR_TUNE_PW_WGRAD) == 1; }
+static int pw_wgrad_chunks(int batch, int cin, int cout) {      // (scratch sizing: the larger of the two kernels' slab counts)
+    return max(pw_wgrad_chunks(batch, cin, cout, 1), pw_wgrad_chunks(batch, cin, cout, 2));
 }
 
 static bool pw_wgrad_fits(int k, int stride, int cin, int cout, int tpi, int tpo) {
@@ -1404,7 +1540,26 @@ static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float
     a.x_scale = x_scale; a.x_shift = x_shift;
     a.x = x; a.dz = dy; a.partial = scratch; a.batch = batch; a.cin = cin; a.cout = cout;
     a.cin_pad = ceil_div(cin, 16) * 16; a.cout_pad = ceil_div(cout, 16) * 16; a.p = tout; a.pp = tpi;
-    a.utt_per_block = ceil_div(batch, pw_wgrad_chunks(batch));
+    const bool glds = pw_wgrad_use_glds();
+    a.utt_per_block = ceil_div(batch, pw_wgrad_chunks(batch, cin, cout, glds ? 1 : 2));
+    if (glds) {
+        const size_t lds2 = ((size_t)4 * 96 * tpi + 16) * sizeof(float);  // two buffers (+ pad: the one-step operand lookahead of the last row)
+        static size_t configured2 = 0;
+        if (lds2 > configured2) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_glds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_glds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) {
+                set_error("pw_wgrad_glds_kernel: cannot reserve %zu bytes of LDS", lds2);
+                return TCR_ERR_HIP;
+            }
+            configured2 = lds2;
+        }
+        a.nchunk = ceil_div(batch, a.utt_per_block); a.nby = ceil_div(cin, 96); a.nbz = ceil_div(cout, 96);
+        const dim3 grid2(ceil_div(a.nchunk, 8) * 8 * a.nby * a.nbz);
+        if (x_scale) hipLaunchKernelGGL(pw_wgrad_glds_kernel<true>, grid2, dim3(768), lds2, s, a);
+        else hipLaunchKernelGGL(pw_wgrad_glds_kernel<false>, grid2, dim3(768), lds2, s, a);
+        TCR_TRY(check_launch("pw_wgrad_glds_kernel"));
+        return launch_wgrad_reduce(scratch, dw, a.nchunk, 1, cin, cout, a.cin_pad, a.cout_pad, cout, 0, s);
+    }
     const size_t lds = ((size_t)2 * 96 * tpi + 16) * sizeof(float);      // (+ pad: the one-step operand lookahead)
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
@@ -1653,7 +1808,7 @@ size_t wgrad_partial_floats(int k, int cin, int cout, int batch, bool fine) {
     const int cs = cout > 80 ? 80 : cout;
     const int cout_pad = ceil_div(cs, 16) * 16;
     const size_t slab = (size_t)max(wgrad_chunks_for(batch, fine), wgrad_lds_instance(k, cin, cout) ? min(ceil_div(batch, 4), 256) : 0) * k * cin_pad * cout_pad;       // (whatever the knob says later)
-    const size_t pw = (k == 1 && cin > 80 && cout > 80) ? (size_t)pw_wgrad_chunks(batch) * cin_pad * (ceil_div(cout, 16) * 16) : 0;   // pw_wgrad_lds_kernel
+    const size_t pw = (k == 1 && cin > 80 && cout > 80) ? (size_t)pw_wgrad_chunks(batch, cin, cout) * cin_pad * (ceil_div(cout, 16) * 16) : 0;   // pw_wgrad_lds_kernel
     return slab > pw ? slab : pw;
 }
 

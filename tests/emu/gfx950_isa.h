@@ -17,6 +17,13 @@ typedef float v2 __attribute__((ext_vector_type(2)));
 typedef float v4 __attribute__((ext_vector_type(4)));
 
 
+// (host stand-in: the DMA copy done at once by the calling lane)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    memcpy(static_cast<char*>(lds_wave_base) + 16 * (threadIdx.x & 63), gsrc, 16);
+}
+
+__device__ __forceinline__ void wait_dma() {}
+
 // a - i b = (a.x + b.y, a.y - b.x)
 __device__ __forceinline__ v2 c_submi(v2 a, v2 b) {
     return (v2){a.x + b.y, a.y - b.x};
