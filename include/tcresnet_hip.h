@@ -427,7 +427,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_FE_KERNEL = 23,  /* packed-FP32 front-end: 0 the three-waves-per-SIMD kernel (frontend_pk3.hip: wave-local LDS regions, <= 168 registers; default), 1 the two-waves kernel of rounds 2-4 (frontend_pk.hip; also what filterbanks with more work items than the unrolled trips fall back to). Bitwise the same features. */
        TCR_TUNE_FE_STAGGER = 24, /* three-waves front-end: one-off start-up delay of (workgroup generation * 4 + wave) * value * 64 cycles that de-phases the twelve waves of a CU (0: none) */
        TCR_TUNE_PW_WGRAD = 25,   /* wide pointwise (DS-CNN 172 / 276 channels) filter gradient: 0 the register-staged kernel (two 4-wave workgroups per CU; default), 1 the DMA-staged kernel (global_load_lds into two LDS buffers, one 12-wave workgroup per CU, three split-K wave groups; measured 2 % slower) */
-       TCR_TUNE_COUNT = 26 };
+       TCR_TUNE_DEPLOY_F32 = 26, /* deploy-path MFCC (method 2): 0 the float64 kernel (one workgroup per frame; TF's ops compute in double; default), 1 the float32 throughput kernels with the op's filterbank / log floor (rounds 3-4: up to 0.5 off on noise-free tones, where the empty bands are pure round-off) */
+       TCR_TUNE_COUNT = 27 };
 int tcr_tune(int knob, int value);
 
 /* The library's internal streams (hipStream_t), one set per device and process.  HIP multiplexes streams onto a few hardware queues

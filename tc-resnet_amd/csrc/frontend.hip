@@ -290,6 +290,65 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontendArgs a) 
 }
 
 // [B][T][F] <-> [B][F][Tp] re-layouts for the "no_preprocessing" path.
+// ---------------------------------------------------------------------------------------------
+// Deploy-path MFCC in float64 (method 2: contrib_audio.audio_spectrogram + contrib_audio.mfcc, datasets/preprocessors.py:98-124,
+// 196-203).  TF's two C++ ops compute in double, and the path has NO log offset (log(max(x, 1e-12))): on clean tones the empty
+// bands hold nothing but the transform's round-off, which a float32 FFT puts five orders of magnitude above a float64 one -- the
+// float32 kernels were up to 0.5 off on the pure-tone fixture rows.  The reference runs this path one utterance at a time (freeze.py,
+// on-device comparison), so rate does not matter: one workgroup per frame, iterative radix-2 FFT on doubles in LDS with twiddles from
+// cos / sin in double, magnitude, the op's filterbank (the plan's slopes), log, DCT-II in double; float32 only on the way out.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frontend_deploy_f64_kernel(const FrontendArgs a, int nfft, int log_nfft) {
+    constexpr double kPi = 3.14159265358979323846;
+    __shared__ double s_re[1024], s_im[1024];
+    __shared__ double s_mag[513];
+    __shared__ double s_lm[64];
+    const int tid = threadIdx.x;
+    const float2* wud = reinterpret_cast<const float2*>(a.wud);
+    for (int g = blockIdx.x; g < a.total_frames; g += gridDim.x) {
+        const int n = g / a.n_frames, t = g - n * a.n_frames;
+        const float* src = a.wav + (size_t)n * a.n_samples + (size_t)t * a.hop;
+        for (int i = tid; i < nfft; i += 256) {
+            const double x = i < a.win ? (double)src[i] * (0.5 - 0.5 * cos(2.0 * kPi * (double)i / (double)a.win)) : 0.0;
+            const int j = (int)(__brev((unsigned)i) >> (32 - log_nfft));
+            s_re[j] = x;
+            s_im[j] = 0.0;
+        }
+        __syncthreads();
+        for (int half = 1; half < nfft; half <<= 1) {
+            for (int b = tid; b < nfft / 2; b += 256) {
+                const int pos = b & (half - 1), i0 = ((b - pos) << 1) + pos, i1 = i0 + half;
+                const double ang = -kPi * (double)pos / (double)half;
+                const double wr = cos(ang), wi = sin(ang);
+                const double xr = s_re[i1], xi = s_im[i1];
+                const double tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
+                const double ur = s_re[i0], ui = s_im[i0];
+                s_re[i1] = ur - tr; s_im[i1] = ui - ti;
+                s_re[i0] = ur + tr; s_im[i0] = ui + ti;
+            }
+            __syncthreads();
+        }
+        for (int k = tid; k <= nfft / 2; k += 256) s_mag[k] = sqrt(s_re[k] * s_re[k] + s_im[k] * s_im[k]);
+        __syncthreads();
+        if (tid < 64) {            // filter m: the up-slopes of segment m, then the down-slopes of segment m + 1 (ascending bins, as the op adds them)
+            double sum = 0.0;
+            for (int k = a.seg_start[tid]; k < a.seg_start[tid + 1]; ++k) sum += (double)wud[k].x * s_mag[k];
+            for (int k = a.seg_start[tid + 1]; k < a.seg_start[tid + 2]; ++k) sum += (double)wud[k].y * s_mag[k];
+            s_lm[tid] = log(sum > 1e-12 ? sum : 1e-12);
+        }
+        __syncthreads();
+        if (tid < a.n_coef) {
+            double v = 0.0;
+            for (int m = 0; m < 64; ++m) v += s_lm[m] * cos(kPi * (double)tid * ((double)m + 0.5) / 64.0);
+            float* row = a.out + ((size_t)n * a.n_coef + tid) * a.tp + kHalo + t;
+            row[0] = (float)(v * sqrt(2.0 / 64.0));
+            if (t == 0) { row[-4] = 0.f; row[-3] = 0.f; row[-2] = 0.f; row[-1] = 0.f; }
+            if (t == a.n_frames - 1) { row[1] = 0.f; row[2] = 0.f; row[3] = 0.f; row[4] = 0.f; }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void to_planar_kernel(const float* __restrict__ ntf, float* __restrict__ planar,
                                                         int batch, int t_len, int f_len) {
     const int tp = t_len + 2 * kHalo;
@@ -365,6 +424,12 @@ extern "C" int tcr_frontend_fwd_rounds(const tcr_frontend_cfg* cfg, const void* 
     const int grid = ceil_div(a.total_frames, 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int knob = tune_get(TCR_TUNE_FRONTEND);
+    if (cfg->method == 2 && tune_get(TCR_TUNE_DEPLOY_F32) == 0) {      // deploy path: float64 (the ops it restates compute in double)
+        int lg = 0;
+        while ((1 << lg) < cfg->nfft) ++lg;
+        hipLaunchKernelGGL(frontend_deploy_f64_kernel, dim3(min(a.total_frames, 16 * device_cus())), dim3(256), 0, s, a, cfg->nfft, lg);
+        return check_launch("frontend_deploy_f64_kernel");
+    }
     if (knob == 0 || knob == 5 || knob >= 10) {           // default: packed-FP32 kernels where their window specialisation applies
         if (tune_get(TCR_TUNE_FE_KERNEL) == 0) {          // three waves per SIMD (frontend_pk3.hip) for filterbanks its unrolled trips cover
             const int rc = launch_frontend_pk3(cfg->nfft / 2, a, frontend_mel_item_count(*cfg), s);

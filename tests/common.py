@@ -78,10 +78,13 @@ def check_frontend_edges(lib, tag):
     hold the same 1e-4 as the ordinary rows although log(mel + 1e-6) is steepest there; every kernel variant and the deploy path.
     Rows 4-5 are pure tones (a full-scale 1 kHz line; a 30 Hz line below the first filter): every other bin of the float64 spectrum is
     Hann leakage 100+ dB down, i.e. BELOW float32 round-off of the line (|X| ~ 320, eps |X| ~ 4e-5, power noise ~ 1e-9 against the 1e-6
-    log offset), so a float32 FFT's answer depends on its butterfly order: the float32 NumPy restatement itself is 4-8e-5 from the
-    float64 oracle on these rows (1.5e-5 on ordinary ones), the kernels 3-7e-4.  Bound: 1e-3.  The deploy path has NO offset
-    (log(max(x, 1e-12)), and TF's C++ op computes in double): its empty bands are pure round-off there -- recorded, bounded at 0.5,
-    a documented limitation of a float32 path on noise-free tones."""
+    log offset), so any float32 FFT's answer is its own round-off there: a complete float32 NumPy pipeline with pocketfft's
+    single-precision transform is 3-5e-4 from the float64 oracle on these rows (1.5e-5 on ordinary ones), the kernels 3-7e-4 -- the same
+    class (tests/test_sensitivity.py::test_pure_tone_rows_what_float32_can_hold, test_emu_parity.py::test_pure_tone_rows_are_where_a_
+    float32_fft_is).  Bound: 1e-3.  The deploy path has NO offset
+    (log(max(x, 1e-12)), and TF's C++ ops compute in double): its empty bands are pure round-off there -- the float32 kernels were up
+    to 0.5 off, so the deploy path runs in float64 since round 5 (frontend_deploy_f64_kernel: every row within 2e-5, i.e. float32
+    output rounding); the float32 kernels stay behind TCR_TUNE_DEPLOY_F32 with the old bound."""
     fx = load(f"frontend_edge_{tag}.npz")
     wav = to_dev(lib, fx["wav"])
     errs = {}
@@ -102,11 +105,38 @@ def check_frontend_edges(lib, tag):
         lib.tcr_tune(23, 0)
     fd = make_frontend(lib, fx["win"], fx["hop"], method="mfcc_deploy")
     gd = fd.reference_view(fd(wav))[..., 0].cpu().numpy()
-    errs["deploy"] = np.abs(gd - fx["mfcc_deploy"]).max(axis=(1, 2))
+    errs["deploy"] = np.abs(gd - fx["mfcc_deploy"]).max(axis=(1, 2))            # the float64 kernel (default)
+    try:
+        lib.tcr_tune(26, 1)                                 # the float32 throughput kernels on the deploy path (rounds 3-4)
+        g32 = fd.reference_view(fd(wav))[..., 0].cpu().numpy()
+        errs["deploy_f32"] = np.abs(g32 - fx["mfcc_deploy"]).max(axis=(1, 2))
+    finally:
+        lib.tcr_tune(26, 0)
     for k, e in errs.items():
         assert e[:4].max() < MFCC_TOL, f"edge rows {tag} / {k}: per-row max abs err {e}"
-        assert e[4:].max() < (0.5 if k == "deploy" else 1e-3), f"pure-tone rows {tag} / {k}: per-row max abs err {e}"
+        assert e[4:].max() < {"deploy": 2e-5, "deploy_f32": 0.5}.get(k, 1e-3), f"pure-tone rows {tag} / {k}: per-row max abs err {e}"
+    assert errs["deploy"].max() < 2e-5                      # float64 inside, float32 only on the way out: every row
     return errs
+
+
+def check_edge_rows_logits(lib, tag):
+    """The edge rows of the front-end fixtures (silence under background noise at three volumes, 1e-4 noise, two pure tones) through the
+    WHOLE eval path -- front-end kernel -> TCResNet8-1.0 kernel with the net fixture's weights and randomised BN statistics -- against
+    the oracle's logits on the oracle's float64 features: identical argmax on all six rows, logits within the ordinary tolerance on rows
+    0-3; rows 4-5 (pure tones: features up to 1e-3 off in bands that hold float32 round-off, see check_frontend_edges) within 5e-4
+    (measured 2e-4 / 2e-5)."""
+    fx = load(f"frontend_edge_{tag}.npz")
+    nfx = load(f"tcresnet8_1.0_{tag}.npz")
+    arch, p, s = fixture_params(nfx, "TCResNet8", 1.0)
+    ref = R.forward(arch, p, s, fx["mfcc"].astype(np.float64), is_training=False)["logits"]
+    fe = make_frontend(lib, fx["win"], fx["hop"])
+    net = make_net(lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+    got = net.forward_infer(fe(to_dev(lib, fx["wav"])))[0].cpu().numpy()
+    err = np.abs(got - ref).max(axis=1)
+    assert np.array_equal(got.argmax(1), ref.argmax(1)), (got.argmax(1), ref.argmax(1))
+    assert err[:4].max() < LOGIT_TOL, f"edge rows {tag}: logits per-row max abs err {err}"
+    assert err[4:].max() < 5e-4, f"pure-tone rows {tag}: logits per-row max abs err {err}"
+    return err
 
 
 def check_frontend_kernels_bitwise(lib, batch):
@@ -118,12 +148,14 @@ def check_frontend_kernels_bitwise(lib, batch):
              (480, 160, "log_mel_spectrogram", 40), (640, 320, "mfcc_deploy", 40), (480, 160, "mfcc_deploy", 40), (320, 160, "mfcc", 40)]
     for win, hop, method, nc in cases:
         fe = make_frontend(lib, win, hop, method=method, num_mfccs=nc)
-        new = fe(wav).clone()
         try:
+            lib.tcr_tune(26, 1)             # (deploy cases: the float32 kernels' filterbank / log-floor variant, not the float64 kernel)
+            new = fe(wav).clone()
             lib.tcr_tune(23, 1)
             old = fe(wav).clone()
         finally:
             lib.tcr_tune(23, 0)
+            lib.tcr_tune(26, 0)
         assert torch.equal(new, old), (win, hop, method, nc, float((new - old).abs().max()))
 
 
@@ -465,6 +497,35 @@ def check_dscnn_staged_equals_unstaged(lib, size, batch):
     assert len(seen) == 2 * (net.lib.tcr_dscnn_num_stages(net._h) - 1) and all(dt == torch.float64 for dt in seen)
     for a, b, what in zip(outs[0], outs[1], ("logits", "loss", "grads", "moving stats")):
         assert torch.equal(a, b), f"DS-CNN-{size}: staged {what} differ from the unstaged run"
+
+
+def check_dscnn_pointwise_wgrad_kernels(lib, size, batch):
+    """The DMA-staged pointwise filter gradient (TCR_TUNE_PW_WGRAD = 1: global_load_lds into two LDS buffers, three split-K wave groups)
+    against the register-staged default: the same products, another summation order (split over wave groups and chunk counts) --
+    every gradient tensor agrees to rounding, everything that does not pass through the kernel bitwise."""
+    from oracle import dscnn_ref as D
+    p, s = D.init_params(D.net_def(size), seed=4)
+    fe = make_frontend(lib, 640, 320, num_mfccs=10)
+    base = R.synth_waveforms(min(batch, 32), seed=8)
+    reps = max(batch // base.shape[0], 1)
+    feat = fe(to_dev(lib, np.tile(base, (reps, 1))))
+    labels = to_dev(lib, np.tile(R.synth_labels(base.shape[0]), (reps, 1)))
+    grads = []
+    try:
+        for knob in (0, 1):
+            lib.tcr_tune(25, knob)
+            net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
+            sd = dict(p); sd.update(s); net.load_state_dict(sd)
+            net.forward_train(feat, labels)
+            grads.append(net.backward().clone())
+    finally:
+        lib.tcr_tune(25, 0)
+    a, b = grads
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    scale = float(a.abs().max())
+    err = float((a - b).abs().max())
+    assert scale > 0 and err <= 3e-5 * scale, (err, scale)
+    assert not torch.equal(a, b)                # (the knob did select another kernel)
 
 
 def check_dscnn_lazy_equals_materialised(lib, size, batch, seed=6):

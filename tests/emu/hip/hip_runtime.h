@@ -323,6 +323,11 @@ static inline void __builtin_amdgcn_wave_barrier_emu() { emu::wave_barrier(); }
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+static inline unsigned __brev(unsigned v) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
 static inline int __builtin_amdgcn_readfirstlane_emu(int v) { return emu::shfl(v, 0); }
 #define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_emu(v)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4((a), (b), (c))

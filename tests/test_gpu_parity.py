@@ -104,6 +104,11 @@ def test_frontend_persistent_chunks_are_position_independent(hip_lib, win, hop):
     assert float((big[:64] - ref).abs().max()) < Cm.MFCC_TOL
 
 
+@pytest.mark.parametrize("tag", ["3010", "4020"])
+def test_edge_rows_logits(hip_lib, tag):
+    Cm.check_edge_rows_logits(hip_lib, tag)
+
+
 @pytest.mark.parametrize("batch", [5, 4099])
 def test_frontend_three_wave_kernel_is_bitwise_the_two_wave_kernel(hip_lib, batch):
     Cm.check_frontend_kernels_bitwise(hip_lib, batch)
@@ -477,6 +482,11 @@ def test_down_dgrad_order_is_bitwise(hip_lib):
 @pytest.mark.parametrize("size,batch", [("S", 96), ("M", 100), ("L", 1024)])
 def test_dscnn_staged_sync_bn_api(hip_lib, size, batch):
     Cm.check_dscnn_staged_equals_unstaged(hip_lib, size, batch)
+
+
+@pytest.mark.parametrize("size,batch", [("L", 37), ("M", 256)])
+def test_dscnn_pointwise_filter_gradient_kernels_agree(hip_lib, size, batch):
+    Cm.check_dscnn_pointwise_wgrad_kernels(hip_lib, size, batch)
 
 
 @pytest.mark.parametrize("size,batch", [("M", 67), ("L", 256), ("L", 4096)])

@@ -124,14 +124,18 @@ def test_same_padding_asymmetry_matters():
 
 def test_pure_tone_rows_what_float32_can_hold():
     """The pure-tone rows of the edge fixtures (rows 4, 5: a full-scale 1 kHz line, a 30 Hz line) are bounded at 1e-3 on the kernels
-    (tests/common.py::check_frontend_edges) where every other row holds 1e-4.  This pins down how much of that a float32 pipeline owes
-    to float32 itself: rounding the WINDOWED FRAMES to float32 and doing everything else in float64 already moves the MFCCs of those
-    rows by 2e-5 .. 7e-5 (all but one bin of their float64 spectrum is Hann leakage 100+ dB under the line, against a 1e-6 log offset),
-    and NumPy's own float32 real FFT -- or the kernels' algorithm, a half-length complex FFT of z = x[2m] + i x[2m+1] followed by the
-    real-FFT split, evaluated in float32 -- adds < 1e-5 to that.  So ~7e-5 is the floor of ANY float32 front-end on these rows; the kernels
-    measure 3e-4 .. 7e-4: their radix-16 x radix-16 FFT has a ~5x higher noise floor in the far leakage bins (~1e-6 per bin against
-    ~2e-7) than pocketfft's real transform.  Not a parity defect of the arithmetic (no reference vector exists for these rows), but the
-    reason the bound is 1e-3 and not 2e-4 -- recorded here so that the number can be re-derived."""
+    (tests/common.py::check_frontend_edges) where every other row holds 1e-4.  What a float32 pipeline owes to float32 itself there:
+      * rounding the WINDOWED FRAMES to float32 and doing everything else in float64 moves the MFCCs of those rows by 2e-5 .. 7e-5 (all
+        but one bin of their float64 spectrum is Hann leakage 100+ dB under the line, against a 1e-6 log offset);
+      * a float32 FFT of those frames -- pocketfft's single-precision real transform (scipy.fft on float32 input), or the kernels'
+        algorithm (half-length complex FFT of z = x[2m] + i x[2m+1] + the real-FFT split) in float32 -- lands at 2e-4 .. 6e-4: the
+        transform's own round-off in the far leakage bins is ~7e-7 per bin, three times the input rounding.
+    The kernels measure 3e-4 .. 7e-4 (tests/test_emu_parity.py::test_pure_tone_rows_are_where_a_float32_fft_is): the class of ANY
+    float32 FFT, TF's Eigen transform included -- not a defect of the radix-16 decomposition.  (Rounds 3-4 recorded "~7e-5 is the floor
+    of any float32 front-end; the kernels' FFT is 5-10x noisier": that comparison used numpy.fft on float32 input, which NumPy 2
+    evaluates in DOUBLE and rounds once at the end -- asserted below.)  Hence the bound 1e-3, and the float64 kernel on the deploy path,
+    which has no log offset to hide behind."""
+    import scipy.fft
     from tests import common as Cm
     for tag in ("4020", "3010"):
         fx = Cm.load(f"frontend_edge_{tag}.npz")
@@ -147,18 +151,22 @@ def test_pure_tone_rows_what_float32_can_hold():
             e = np.abs((np.log(power.astype(np.float64) @ M + 1e-6) @ D)[..., :cfg.num_mfccs] - ref)
             return e.reshape(ref.shape[0], -1).max(1)
 
-        e64 = finish(np.abs(np.fft.rfft(x.astype(np.float64), axis=-1)) ** 2)           # float32 frames, float64 everything else
-        X = np.fft.rfft(x, axis=-1)
-        assert X.dtype == np.complex64                                                  # (NumPy >= 2 transforms float32 in single precision)
-        e32 = finish(X.real ** 2 + X.imag ** 2)
+        X64 = np.fft.rfft(x.astype(np.float64), axis=-1)
+        e64 = finish(np.abs(X64) ** 2)                                                  # float32 frames, float64 everything else
+        Xnp = np.fft.rfft(x, axis=-1)                                                   # complex64 out, but computed in double:
+        assert Xnp.dtype == np.complex64 and np.abs(Xnp - X64)[4:, :, cfg.n_bins // 3:].max() < 1e-9        # (tone rows, far leakage bins)
+        X = scipy.fft.rfft(x, axis=-1)                                                  # a transform that IS single precision
+        assert X.dtype == np.complex64 and np.abs(X - X64)[4:, :, cfg.n_bins // 3:].max() > 1e-7
+        e32 = finish(X.real.astype(np.float64) ** 2 + X.imag.astype(np.float64) ** 2)
         z = (x[..., 0::2] + 1j * x[..., 1::2]).astype(np.complex64)                     # the kernels' algorithm in float32
-        Z = np.fft.fft(z, axis=-1)
+        Z = scipy.fft.fft(z, axis=-1)
+        assert Z.dtype == np.complex64
         n2 = cfg.nfft // 2
         k = np.arange(n2 + 1)
         zk, zn = Z[..., k % n2], np.conj(Z[..., (n2 - k) % n2])
         w = np.exp(-2j * np.pi * k / cfg.nfft).astype(np.complex64)
         xp = ((zk + zn) * np.float32(0.5) + w * ((zk - zn) * np.complex64(-0.5j))).astype(np.complex64)
-        esp = finish(xp.real ** 2 + xp.imag ** 2)
-        assert e64[:4].max() < 1e-6 and e32[:4].max() < 1e-6 and esp[:4].max() < 1e-6     # ordinary / low-amplitude rows: nothing to see
+        esp = finish(xp.real.astype(np.float64) ** 2 + xp.imag.astype(np.float64) ** 2)
+        assert e64[:4].max() < 1e-6 and e32[:4].max() < 1e-5 and esp[:4].max() < 1e-5     # ordinary / low-amplitude rows: nothing to see
         assert 1e-5 < e64[4:].max() < 1e-4                                                 # the tones: float32 frames alone cost 2e-5 .. 7e-5
-        assert e32[4:].max() < 1e-4 and esp[4:].max() < 1e-4                               # ... and a float32 FFT (either form) stays there
+        assert 1.5e-4 < e32[4:].max() < 1e-3 and 1.5e-4 < esp[4:].max() < 1e-3             # ... a float32 FFT of either form 2e-4 .. 6e-4
