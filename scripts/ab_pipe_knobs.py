@@ -33,7 +33,8 @@ def run(pipe, n=200, warm=60):
 
 
 WAYS = [int(v) for v in os.environ.get("WAYS", "2").split(",")]
-pipes = {w: InferencePipeline(fe, net, B, mode="alternate", ways=w) for w in WAYS}
+FE_ROUNDS = os.environ.get("FE_ROUNDS", "auto")
+pipes = {w: InferencePipeline(fe, net, B, mode="alternate", ways=w, fe_rounds=(FE_ROUNDS if FE_ROUNDS == "auto" else int(FE_ROUNDS))) for w in WAYS}
 res = {}
 for rnd in range(ROUNDS):
     for spec in SETS:

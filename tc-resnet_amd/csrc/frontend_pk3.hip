@@ -98,6 +98,8 @@ __global__ __launch_bounds__(256, 3) void frontend_pk3_kernel(const FrontendArgs
     __shared__ float s_lm[4 * NMEL * 16];
     __shared__ v2 s_wit[kMelItemBins * NIT];
     __shared__ int s_items[kItemsLds ? NIT : 1];
+    constexpr bool kBandsLds = true;                // the bands' item ranges from LDS (one ds_read_b32 per band and round instead of 2 - 4 registers)
+    __shared__ int s_band[kBandsLds ? NMEL : 1];
     __shared__ v2 s_wnd[QV * LPF];          // signed window [q][lane of the frame]: samples 2 (SUB (l + 16 q) + u), + 1
 
     const int tid = threadIdx.x;
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(256, 3) void frontend_pk3_kernel(const FrontendArgs
         for (int i = tid; i < kMelItemBins * NIT; i += 256) s_wit[i] = wit[i] * fold;
         if (kItemsLds)
             for (int i = tid; i < NIT; i += 256) s_items[i] = a.mel_items[i];
+        if (kBandsLds && tid < NMEL) s_band[tid] = a.mel_ifirst[tid] | (a.mel_ifirst[tid + 1] << 8) | (a.mel_ifirst[tid + 2] << 16);
         for (int i = tid; i < QV * LPF; i += 256) {
             const int q = i / LPF, lfi = i % LPF;
             s_wnd[i] = *reinterpret_cast<const v2*>(a.window_sgn + 2 * (SUB * ((lfi & 15) + 16 * q) + (lfi >> 4)));
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256, 3) void frontend_pk3_kernel(const FrontendArgs
     // idle (ten sample loads per round), the LDS pipe is not -- so that 3 waves per SIMD (<= 168 registers) hold without scratch.
     v2 tw[16], twr[8], twc[8];
     float sgn;
-    int item_d[kItemsLds ? 1 : TRIPS], band_i[NMEL / LPF];
+    int item_d[kItemsLds ? 1 : TRIPS], band_i[kBandsLds ? 1 : NMEL / LPF];
     {
         const int lf = tid % LPF, l = tid & 15, h = l >> 3;
         sgn = h ? -1.f : 1.f;
@@ -138,10 +141,12 @@ __global__ __launch_bounds__(256, 3) void frontend_pk3_kernel(const FrontendArgs
 #pragma unroll
             for (int tr = 0; tr < TRIPS; ++tr) item_d[kItemsLds ? 0 : tr] = a.mel_items[lf + LPF * tr];
         }
+        if (!kBandsLds) {
 #pragma unroll
-        for (int i = 0; i < NMEL / LPF; ++i) {
-            const int m = lf + LPF * i;
-            band_i[i] = a.mel_ifirst[m] | (a.mel_ifirst[m + 1] << 8) | (a.mel_ifirst[m + 2] << 16);
+            for (int i = 0; i < NMEL / LPF; ++i) {
+                const int m = lf + LPF * i;
+                band_i[kBandsLds ? 0 : i] = a.mel_ifirst[m] | (a.mel_ifirst[m + 1] << 8) | (a.mel_ifirst[m + 2] << 16);
+            }
         }
     }
     const v2 wm = tw_real[NC / 2];
@@ -308,7 +313,8 @@ __global__ __launch_bounds__(256, 3) void frontend_pk3_kernel(const FrontendArgs
 #pragma unroll
             for (int i = 0; i < NMEL / LPF; ++i) {
                 const int m = lf + LPF * i;
-                const int i0 = band_i[i] & 255, i1 = (band_i[i] >> 8) & 255, i2 = band_i[i] >> 16;
+                const int bi = kBandsLds ? s_band[m] : band_i[kBandsLds ? 0 : i];
+                const int i0 = bi & 255, i1 = (bi >> 8) & 255, i2 = bi >> 16;
                 constexpr int MAXC = NC == 512 ? 3 : 2;
                 float up[MAXC], dn[MAXC];
 #pragma unroll
