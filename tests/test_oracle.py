@@ -244,3 +244,17 @@ def test_dscnn_training_oracle_matches_autograd_and_fixture():
     k = "DSCNN/fc1/weights"
     assert np.allclose(p1[k], p[k] - 5e-4 * g[k] / (np.abs(g[k]) + 1e-8 / np.sqrt(1 - 0.999)), atol=1e-12)
     assert np.abs(p1[k] - fx["S:param1:" + k]).max() < 1e-12
+
+
+def test_top_n_accuracy_pinned_to_the_reference():
+    """tests/golden/metrics_topn.npz holds outputs of the REAL reference (metrics/funcs.py::topN_accuracy imported from /root/reference by
+    oracle/pin_metrics_from_reference.py -- the one module of the reference that runs without TensorFlow): the host mirror's top-N
+    accuracy (evaluate_audio.py's `top5_accuracy/<split>`) must reproduce them exactly, ties and worst cases included."""
+    import os
+    from tcresnet_amd.metrics import top_n_accuracy
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_topn.npz"))
+    for i in fx["cases"]:
+        y, sc = fx[f"y_true_{i}"], fx[f"scores_{i}"]
+        for n in (1, 3, 5, sc.shape[1]):
+            assert top_n_accuracy(y, sc, n) == float(fx[f"acc_{i}_{n}"]), (i, n)
+    assert float(fx["acc_3_5"]) == 0.0 and float(fx["acc_0_12"]) == 1.0
