@@ -238,7 +238,7 @@ __device__ __forceinline__ void fused_layer_t(const FusedArgs& a, const FusedLay
 // per layer): 17.5 M instead of 21.3 M VALU and 4.9 M instead of 11 M SALU instructions per launch, bitwise the same results.
 // (Tried with it and dropped: the taps fully unrolled into a software pipeline -- weight fragments two / three stages ahead in a
 // register ring, LDS operands one stage ahead, a scheduling barrier per stage: 131 / 133 us vs 125 us, SQ_WAIT_INST_ANY UP 11 %.)
-template <int NW, int K, int S, int CIN, int COUT, int TIN, bool HAS_RES>
+template <int NW, int K, int S, int CIN, int COUT, int TIN, bool HAS_RES, int NTJ = 2>
 __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
                                               float* lds, const int ng, const int wave, const int r_in, const int q_in) {
     // lane geometry re-derived from an opaque zero: the per-lane address arithmetic of ten layers must not be hoisted out of the group
@@ -251,31 +251,42 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
     constexpr int TPI = TIN + 2 * kHalo, TPO = TOUT + 2 * kHalo;
     constexpr int C4 = CIN / 4, NRT = (COUT + 15) / 16;
     constexpr int WSTEP = 4 * COUT, XSTEP = 4 * TPI;
+    constexpr int JP = 16 * NTJ;            // positions per job
     static_assert(CIN % 4 == 0, "channel quads");
+    static_assert(NTJ == 2 || NTJ == 4, "two or four 16-position tiles per job");
     float* yout = lds + a.buf_off[L.out_buf];
     const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
     const int out_sz = L.out_sz;
     const int res_sz = L.res_sz;
     const int npos = ng * TOUT;
-    const int ncp = (npos + 31) / 32;
+    const int ncp = (npos + JP - 1) / JP;
     const float* w = a.params + L.w_off;
     const float* scale = a.ss + L.ss_off;
     const float* shift = scale + L.c_pad;
-    // Which of a job's 32 positions a lane's two tile columns hold (the columns of the implicit GEMM are independent: any assignment
+    // Which of a job's positions a lane's tile columns hold (the columns of the implicit GEMM are independent: any assignment
     // gives the same sums).  One ds_read_b32 serves lanes (q, q + 1) x 16 columns against 32 banks: with stride 2 consecutive columns
     // are 2 floats apart and the odd row pitch puts row q + 1 on the other bank parity; with stride 1 the columns of a tile are every
-    // OTHER position (tile 0 the even, tile 1 the odd ones) for the same picture.  The host pads the per-utterance stride so that the
+    // OTHER position (tile 0 the even, tile 1 the odd ones of a run of 32) for the same picture.  The host pads the per-utterance stride so that the
     // pattern continues across the utterances of a group (net.cpp: fused_strides).  PMC, TCResNet8 at 49 frames: see OPTLOG.md.
+    // NTJ = 4 (round 5 experiment; the 16 / 24-channel layers at 25 frames): a weight fragment feeds four MFMAs instead of two -- those layers have
+    // 4 - 6 channel quads, i.e. 8 - 12 MFMAs between two dependent weight loads of a tap, and 14 jobs for 8 waves; with 64-position jobs a tap's
+    // loads sit behind 16 - 24 MFMAs and a layer is one round of <= 8 jobs.  Same sums (columns are independent), bitwise -- and no faster
+    // (phase stamps, scripts/fused_ts.py: block 0's first phase 37.5 -> 31.8 k cycles, its second 39.5 -> 43.4 k: the two workgroups of a CU
+    // share the matrix pipes, a shorter phase of one lengthens the other's).
     constexpr bool IL = S == 1;
     for (int job = wave; job < ncp * NRT; job += NW) {
         const int cp = job / NRT, m = job - cp * NRT;
-        const int c0 = IL ? cp * 32 + 2 * r : cp * 32 + r, c1 = IL ? c0 + 1 : c0 + 16;
-        const int p0 = min(c0, npos - 1), p1 = min(c1, npos - 1);
-        const int g0 = p0 / TOUT, g1 = p1 / TOUT;
-        const int t0 = p0 - g0 * TOUT, t1 = p1 - g1 * TOUT;
+        int cc[NTJ], gg[NTJ], tt[NTJ];
+        const float* xp[NTJ];
+#pragma unroll
+        for (int nt = 0; nt < NTJ; ++nt) {
+            cc[nt] = IL ? cp * JP + 32 * (nt >> 1) + 2 * r + (nt & 1) : cp * JP + 16 * nt + r;
+            const int p = min(cc[nt], npos - 1);
+            gg[nt] = p / TOUT;
+            tt[nt] = p - gg[nt] * TOUT;
+            xp[nt] = xin + gg[nt] * in_sz + q * TPI + tt[nt] * S + kHalo - PADLO;
+        }
         const float* wp = w + q * COUT + min(m * 16 + r, COUT - 1);
-        const float* x0 = xin + g0 * in_sz + q * TPI + t0 * S + kHalo - PADLO;
-        const float* x1 = xin + g1 * in_sz + q * TPI + t1 * S + kHalo - PADLO;
         float sc[4], sh[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -283,7 +294,9 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
             sc[reg] = scale[co];
             sh[reg] = shift[co];
         }
-        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[NTJ];
+#pragma unroll
+        for (int nt = 0; nt < NTJ; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // rolled taps, two half-tap weight sets refilled for the next tap (the round-2 loop)
         constexpr int H0 = C4 / 2, H1 = C4 - H0;
         float wa[H0 > 0 ? H0 : 1], wb[H1];
@@ -296,26 +309,28 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
             const int jn = TCR_WHATIF(2) ? 0 : min(j + 1, K - 1);
             const int jx = TCR_WHATIF(4) ? 0 : j;
             {
-                float b0[H0 > 0 ? H0 : 1], b1[H0 > 0 ? H0 : 1];
+                float b[NTJ][H0 > 0 ? H0 : 1];
 #pragma unroll
-                for (int c4 = 0; c4 < H0; ++c4) { b0[c4] = x0[c4 * XSTEP + jx]; b1[c4] = x1[c4 * XSTEP + jx]; }
+                for (int c4 = 0; c4 < H0; ++c4)
 #pragma unroll
-                for (int c4 = 0; c4 < H0; ++c4) {
-                    acc0 = TCR_MFMA(wa[c4], b0[c4], acc0);
-                    acc1 = TCR_MFMA(wa[c4], b1[c4], acc1);
-                }
+                    for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = xp[nt][c4 * XSTEP + jx];
+#pragma unroll
+                for (int c4 = 0; c4 < H0; ++c4)
+#pragma unroll
+                    for (int nt = 0; nt < NTJ; ++nt) acc[nt] = TCR_MFMA(wa[c4], b[nt][c4], acc[nt]);
 #pragma unroll
                 for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[(jn * C4 + c4) * WSTEP];
             }
             {
-                float b0[H1], b1[H1];
+                float b[NTJ][H1];
 #pragma unroll
-                for (int c4 = 0; c4 < H1; ++c4) { b0[c4] = x0[(H0 + c4) * XSTEP + jx]; b1[c4] = x1[(H0 + c4) * XSTEP + jx]; }
+                for (int c4 = 0; c4 < H1; ++c4)
 #pragma unroll
-                for (int c4 = 0; c4 < H1; ++c4) {
-                    acc0 = TCR_MFMA(wb[c4], b0[c4], acc0);
-                    acc1 = TCR_MFMA(wb[c4], b1[c4], acc1);
-                }
+                    for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = xp[nt][(H0 + c4) * XSTEP + jx];
+#pragma unroll
+                for (int c4 = 0; c4 < H1; ++c4)
+#pragma unroll
+                    for (int nt = 0; nt < NTJ; ++nt) acc[nt] = TCR_MFMA(wb[c4], b[nt][c4], acc[nt]);
 #pragma unroll
                 for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(jn * C4 + H0 + c4) * WSTEP];
             }
@@ -323,22 +338,21 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
         // ---- epilogue: folded BN (+ shortcut) (+ ReLU) -> LDS rows ----
         const int dump = a.buf_off[2] + a.group * a.buf_sz[2] + (q * 16 + r);
         const float lo = L.relu ? 0.f : -3.4e38f;
-        float rv[2][4];
+        float rv[NTJ][4];
         if (HAS_RES) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NTJ; ++nt)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int co = min(m * 16 + q * 4 + reg, COUT - 1);
-                    rv[nt][reg] = res[(nt == 0 ? g0 : g1) * res_sz + co * TPO + kHalo + (nt == 0 ? t0 : t1)];
+                    rv[nt][reg] = res[gg[nt] * res_sz + co * TPO + kHalo + tt[nt]];
                 }
         }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const bool pv = (nt == 0 ? c0 : c1) < npos;
-            const int g = nt == 0 ? g0 : g1, t = nt == 0 ? t0 : t1;
-            const f32x4 ac = nt == 0 ? acc0 : acc1;
-            const int base = g * out_sz + kHalo + t;
+        for (int nt = 0; nt < NTJ; ++nt) {
+            const bool pv = cc[nt] < npos;
+            const f32x4 ac = acc[nt];
+            const int base = gg[nt] * out_sz + kHalo + tt[nt];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int co = m * 16 + q * 4 + reg;
@@ -566,17 +580,17 @@ __device__ __forceinline__ void fused_head(const FusedArgs& a, float* lds, const
 #define TCR_WAVES_PER_SIMD_4 TCR_WAVES_PER_SIMD(4)     // two 8-wave workgroups per CU: <= 128 VGPRs
 // WD < 0: the round-2 layer (A/B arm, TCR_TUNE_NET_FUSED = 4).  HALO: some consumer convolves this layer's rows (K > 1) and so reads
 // their zero halo; the shortcut convs' outputs (only ever a residual term) and the last block output (only pooled) skip the zero pass.
-template <int NW, int K, int S, int CIN, int COUT, int TIN, int WD, bool HAS_RES, bool HALO = true>
+template <int NW, int K, int S, int CIN, int COUT, int TIN, int WD, bool HAS_RES, bool HALO = true, int NTJ = 2>
 __device__ __forceinline__ void fused_layer_sel(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
                                                 float* lds, const int ng, const int wave, const int r, const int q) {
     if constexpr (WD < 0) fused_layer_t<NW, K, S, CIN, COUT, TIN>(a, L, xin, in_sz, lds, ng, wave, r, q);
     else {
         if constexpr (HALO) fused_zero_halo<NW * 64, COUT, (TIN + S - 1) / S>(lds + a.buf_off[L.out_buf], L.out_sz, ng, (int)threadIdx.x);
-        fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES>(a, L, xin, in_sz, lds, ng, wave, r, q);
+        fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES, NTJ>(a, L, xin, in_sz, lds, ng, wave, r, q);
     }
 }
 
-template <int NW, int T0, int WD>
+template <int NW, int T0, int WD, int NTJ0 = 2>
 __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_kernel(const FusedArgs a) {
     constexpr int NT = NW * 64;
     constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2;
@@ -586,15 +600,25 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int row = a.in_c * a.in_tp;
-#if TCR_FUSED_WHATIF & 8
+#if TCR_FUSED_WHATIF & 2048
+    // phase timing (diagnostic side build, WRONG outputs): cycles between the barriers, written over the group's first probabilities
+    long long ts[14];
+    int nts = 0;
+#define TCR_TC8_BARRIER do { __syncthreads(); ts[nts++] = (long long)__builtin_readcyclecounter(); } while (0)
+#elif TCR_FUSED_WHATIF & 8
 #define TCR_TC8_BARRIER ((void)0)
 #else
 #define TCR_TC8_BARRIER __syncthreads()
 #endif
-#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9), (K_ != 1 && LI != 9)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, ng, wave, r, q)
+    // (tiles per job: two; NTJ0 = 4: four for block 0's layers -- 16 / 24 channels at T0 / 2 frames --, the TCR_TUNE_NET_FUSED = 5 arm)
+#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9), (K_ != 1 && LI != 9), ((LI >= 1 && LI <= 3 && NTJ0 == 4) ? 4 : 2)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, ng, wave, r, q)
     for (int grp = blockIdx.x; grp < (TCR_WHATIF(512) ? 0 : a.n_groups); grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
+#if TCR_FUSED_WHATIF & 2048
+        nts = 0;
+        ts[nts++] = (long long)__builtin_readcyclecounter();
+#endif
         if constexpr (WD < 0) fused_layer_sel<NW, 3, 1, 40, 16, T0, WD, false>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, ng, wave, r, q);
         else if (!TCR_WHATIF(64)) {
             fused_zero_halo<NT, 16, T0>(lds + a.buf_off[a.layer[0].out_buf], a.layer[0].out_sz, ng, tid);
@@ -621,6 +645,12 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
             if (a.nc == 12) fused_head_s<NT, 48, (T2 + 1) / 2, 12>(a, lds, n0, ng, tid);
             else fused_head<NT>(a, lds, n0, ng, tid);
         }
+#if TCR_FUSED_WHATIF & 2048
+        __syncthreads();
+        ts[nts++] = (long long)__builtin_readcyclecounter();
+        if (tid == 0)
+            for (int i = 0; i + 1 < nts && i < 12; ++i) a.probs[(size_t)n0 * a.nc + i] = (float)(ts[i + 1] - ts[i]);
+#endif
     }
 #undef TCR_TC8
 #undef TCR_TC8_BARRIER
@@ -901,7 +931,8 @@ int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, 
     const int tc8 = tune_get(TCR_TUNE_NET_FUSED) == 3 ? 0 : fused_tc8_frames(a);
     // TCR_TUNE_NET_FUSED: 0 branch-free epilogue (default); 4: the round-2 static-shape kernel (A/B arm)
     const bool r2 = tune_get(TCR_TUNE_NET_FUSED) == 4;
-#define TCR_FS(NW_, T_) if (tc8 == T_ && waves == NW_) kern = r2 ? net_fused_tc8_kernel<NW_, T_, -1> : net_fused_tc8_kernel<NW_, T_, 0>;
+    const bool j4 = tune_get(TCR_TUNE_NET_FUSED) == 5;         // 5: four 16-position tiles per job in block 0's layers (A/B arm, bitwise; measured 103.6 vs 103.2 us at 49 frames, 184.9 vs 181.2 at 98: no gain)
+#define TCR_FS(NW_, T_) if (tc8 == T_ && waves == NW_) kern = r2 ? net_fused_tc8_kernel<NW_, T_, -1> : (j4 ? net_fused_tc8_kernel<NW_, T_, 0, 4> : net_fused_tc8_kernel<NW_, T_, 0, 2>);
     TCR_FS(4, 49) TCR_FS(8, 49) TCR_FS(16, 49) TCR_FS(4, 98) TCR_FS(8, 98) TCR_FS(16, 98)
 #undef TCR_FS
     const int tc14 = (kern || tune_get(TCR_TUNE_NET_FUSED) == 3 || tune_get(TCR_TUNE_NET_FUSED) == 4) ? 0 : fused_tc14w_frames(a);

@@ -346,7 +346,9 @@ def test_every_kernel_path_agrees(hip_lib):
                             ("fused g=3", {4: 3}), ("fused g=4, 4 waves", {4: 4, 5: 404}), ("fused, features staged in LDS", {3: 2}),
                             ("fused g=8, 16 waves, ring 8", {4: 8, 5: 816}), ("fused, generic layer walk (no compile-time shapes)", {3: 3}),
                             ("fused, generic walk, 4 waves", {3: 3, 5: 404}),
-                            ("fused, utterance strides not padded to the bank pattern", {3: 7})):
+                            ("fused, utterance strides not padded to the bank pattern", {3: 7}),
+                            ("fused, four tiles per job in block 0's layers", {3: 5}),
+                            ("fused, four tiles per job in block 0, 3 utterances per group", {3: 5, 4: 3})):
             for k, v in knobs.items():
                 hip_lib.tcr_tune(k, v)
             results[name] = net.forward_infer(feat0)[0].clone()
