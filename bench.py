@@ -365,7 +365,8 @@ def main():
                 sync()
             out["latency_batch_1"] = {"value": round((time.perf_counter() - t0) / 200 * 1e6, 1), "unit": "us", "higher_is_better": False,
                                       "workload": "one utterance, waveform -> softmax, host call (tcr_forward_waveform) + device synchronisation per "
-                                                  "utterance; the two kernels' own serial latency dominates (persistent front-end set-up + one network group)"}
+                                                  "utterance: front-end ~9 us + small-batch network kernel ~21 us (weights DMA-copied into LDS a phase ahead; "
+                                                  "bitwise the throughput kernel) back to back, the rest is launch + synchronisation latency"}
         if "train" in legs:
             # ---------------- training step (configs[2]) ----------------
             out["train"] = train_leg(fe, net, tsteps, twarm)

@@ -428,7 +428,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_FE_STAGGER = 24, /* three-waves front-end: one-off start-up delay of (workgroup generation * 4 + wave) * value * 64 cycles that de-phases the twelve waves of a CU (0: none) */
        TCR_TUNE_PW_WGRAD = 25,   /* wide pointwise (DS-CNN 172 / 276 channels) filter gradient: 0 the register-staged kernel (two 4-wave workgroups per CU; default), 1 the DMA-staged kernel (global_load_lds into two LDS buffers, one 12-wave workgroup per CU, three split-K wave groups; measured 2 % slower) */
        TCR_TUNE_DEPLOY_F32 = 26, /* deploy-path MFCC (method 2): 0 the float64 kernel (one workgroup per frame; TF's ops compute in double; default), 1 the float32 throughput kernels with the op's filterbank / log floor (rounds 3-4: up to 0.5 off on noise-free tones, where the empty bands are pure round-off) */
-       TCR_TUNE_COUNT = 27 };
+       TCR_TUNE_NET_SMALL = 27,  /* eval network, TCResNet8-1.0 at 49 frames, batches of <= 64 utterances: 0 the small-batch kernel (one utterance per 8-wave workgroup, each phase's weights DMA-copied into LDS one phase ahead; default), 1 the throughput kernel at one utterance per group (rounds 2-4).  Bitwise the same outputs. */
+       TCR_TUNE_COUNT = 28 };
 int tcr_tune(int knob, int value);
 
 /* The library's internal streams (hipStream_t), one set per device and process.  HIP multiplexes streams onto a few hardware queues

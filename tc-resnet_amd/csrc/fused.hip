@@ -238,9 +238,10 @@ __device__ __forceinline__ void fused_layer_t(const FusedArgs& a, const FusedLay
 // per layer): 17.5 M instead of 21.3 M VALU and 4.9 M instead of 11 M SALU instructions per launch, bitwise the same results.
 // (Tried with it and dropped: the taps fully unrolled into a software pipeline -- weight fragments two / three stages ahead in a
 // register ring, LDS operands one stage ahead, a scheduling barrier per stage: 131 / 133 us vs 125 us, SQ_WAIT_INST_ANY UP 11 %.)
-template <int NW, int K, int S, int CIN, int COUT, int TIN, bool HAS_RES, int NTJ = 2>
+template <int NW, int K, int S, int CIN, int COUT, int TIN, bool HAS_RES, int NTJ = 2, bool WLDS = false>
 __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
-                                              float* lds, const int ng, const int wave, const int r_in, const int q_in) {
+                                              float* lds, const int ng, const int wave, const int r_in, const int q_in,
+                                              const int w_lds = 0) {     // WLDS: this layer's weights are staged in LDS at float offset w_lds (small-batch kernel)
     // lane geometry re-derived from an opaque zero: the per-lane address arithmetic of ten layers must not be hoisted out of the group
     // loop, where it would stay live through every other layer (the kernel runs at a 128-register budget)
     const int oz = opaque_zero();
@@ -253,14 +254,14 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
     constexpr int WSTEP = 4 * COUT, XSTEP = 4 * TPI;
     constexpr int JP = 16 * NTJ;            // positions per job
     static_assert(CIN % 4 == 0, "channel quads");
-    static_assert(NTJ == 2 || NTJ == 4, "two or four 16-position tiles per job");
+    static_assert(NTJ == 1 || NTJ == 2 || NTJ == 4, "one, two or four 16-position tiles per job");
     float* yout = lds + a.buf_off[L.out_buf];
     const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
     const int out_sz = L.out_sz;
     const int res_sz = L.res_sz;
     const int npos = ng * TOUT;
     const int ncp = (npos + JP - 1) / JP;
-    const float* w = a.params + L.w_off;
+    const float* w = WLDS ? lds + w_lds : a.params + L.w_off;
     const float* scale = a.ss + L.ss_off;
     const float* shift = scale + L.c_pad;
     // Which of a job's positions a lane's tile columns hold (the columns of the implicit GEMM are independent: any assignment
@@ -280,7 +281,7 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
         const float* xp[NTJ];
 #pragma unroll
         for (int nt = 0; nt < NTJ; ++nt) {
-            cc[nt] = IL ? cp * JP + 32 * (nt >> 1) + 2 * r + (nt & 1) : cp * JP + 16 * nt + r;
+            cc[nt] = (IL && NTJ > 1) ? cp * JP + 32 * (nt >> 1) + 2 * r + (nt & 1) : cp * JP + 16 * nt + r;
             const int p = min(cc[nt], npos - 1);
             gg[nt] = p / TOUT;
             tt[nt] = p - gg[nt] * TOUT;
@@ -304,7 +305,10 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
         for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[c4 * WSTEP];
 #pragma unroll
         for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(H0 + c4) * WSTEP];
-#pragma unroll 1
+        // (throughput kernels: rolled taps -- 128-register budget; small-batch kernel: unrolled, the LDS operand and weight reads of the
+        //  following taps move ahead of the MFMAs)
+        constexpr int kTapUnroll = WLDS ? K : 1;
+#pragma unroll kTapUnroll
         for (int j = 0; j < K; ++j) {
             const int jn = TCR_WHATIF(2) ? 0 : min(j + 1, K - 1);
             const int jx = TCR_WHATIF(4) ? 0 : j;
@@ -372,9 +376,10 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
 // 10 % of its MFMAs.  Here a job requests ALL its operands up front (per lane 10 channel quads x 3 taps = three consecutive
 // floats each, and the 30 weight fragments; a job is 16 positions so that this fits the register budget), then runs its 30 MFMAs:
 // one exposed latency per job.  Same accumulation order.
-template <int NW, int T0>
+template <int NW, int T0, bool WLDS = false>
 __device__ __forceinline__ void fused_conv0_s(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
-                                              float* lds, const int ng, const int wave, const int r_in, const int q_in) {
+                                              float* lds, const int ng, const int wave, const int r_in, const int q_in,
+                                              const int w_lds = 0) {
     const int oz = opaque_zero();
     const int r = r_in + oz, q = q_in + oz;
     constexpr int K = 3, CIN = 40, COUT = 16, C4 = CIN / 4;
@@ -384,7 +389,7 @@ __device__ __forceinline__ void fused_conv0_s(const FusedArgs& a, const FusedLay
     const int out_sz = L.out_sz;
     const int npos = ng * TOUT;
     const int nct = (npos + 15) / 16;
-    const float* w = a.params + L.w_off;
+    const float* w = WLDS ? lds + w_lds : a.params + L.w_off;
     const float* scale = a.ss + L.ss_off;
     const float* shift = scale + L.c_pad;
     for (int job = wave; job < nct; job += NW) {            // job = 16 positions x 16 channels (30 + 30 operand registers)
@@ -580,13 +585,14 @@ __device__ __forceinline__ void fused_head(const FusedArgs& a, float* lds, const
 #define TCR_WAVES_PER_SIMD_4 TCR_WAVES_PER_SIMD(4)     // two 8-wave workgroups per CU: <= 128 VGPRs
 // WD < 0: the round-2 layer (A/B arm, TCR_TUNE_NET_FUSED = 4).  HALO: some consumer convolves this layer's rows (K > 1) and so reads
 // their zero halo; the shortcut convs' outputs (only ever a residual term) and the last block output (only pooled) skip the zero pass.
-template <int NW, int K, int S, int CIN, int COUT, int TIN, int WD, bool HAS_RES, bool HALO = true, int NTJ = 2>
+template <int NW, int K, int S, int CIN, int COUT, int TIN, int WD, bool HAS_RES, bool HALO = true, int NTJ = 2, bool WLDS = false>
 __device__ __forceinline__ void fused_layer_sel(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
-                                                float* lds, const int ng, const int wave, const int r, const int q) {
+                                                float* lds, const int ng, const int wave, const int r, const int q,
+                                                const int w_lds = 0) {
     if constexpr (WD < 0) fused_layer_t<NW, K, S, CIN, COUT, TIN>(a, L, xin, in_sz, lds, ng, wave, r, q);
     else {
         if constexpr (HALO) fused_zero_halo<NW * 64, COUT, (TIN + S - 1) / S>(lds + a.buf_off[L.out_buf], L.out_sz, ng, (int)threadIdx.x);
-        fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES, NTJ>(a, L, xin, in_sz, lds, ng, wave, r, q);
+        fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES, NTJ, WLDS>(a, L, xin, in_sz, lds, ng, wave, r, q, w_lds);
     }
 }
 
@@ -654,6 +660,105 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
     }
 #undef TCR_TC8
 #undef TCR_TC8_BARRIER
+}
+
+// Small-batch (latency) form of the same network, TCResNet8-1.0 at 49 frames: ONE utterance per 8-wave workgroup, every phase's weights
+// copied into LDS by the DMA path (global_load_lds_dwordx4, coalesced, all in flight at once) one phase ahead, A fragments read from
+// LDS.  In the throughput kernel a job's nine taps are nine DEPENDENT weight loads from L2 (cold L1 at batch 1): ~4.5 us per layer,
+// 35 us for the walk; here a phase costs one L2 round trip, hidden behind the phase before it (two weight buffers: 83 KB + 61 KB, the
+// two largest consecutive phases).  One 16-position tile per job: more jobs for the eight waves, half the matrix work of a
+// two-tile job whose second tile would be empty at 13 / 7 frames.  Same accumulation order as the throughput kernels: bitwise their
+// results, so an utterance's outputs do not depend on the batch it arrives in.  (Round 4's `net_small_kernel` -- every weight fragment of
+// a job gathered into registers -- was slower than the throughput kernel: 108 dword gathers per lane and job.)
+template <int NW>
+__device__ __forceinline__ void small_stage_weights(const float* __restrict__ src, int n_floats, float* dst, int wave, int lane) {
+    for (int c0 = wave * 256; c0 < n_floats; c0 += NW * 256) {          // one DMA instruction: 64 lanes x 16 B = 256 floats
+        const int c = c0 + 4 * lane;
+        if (c < n_floats) glds16(src + c, dst + c0);
+    }
+}
+
+template <int NW, int T0>
+__global__ __launch_bounds__(NW * 64) void net_small_tc8_kernel(const FusedArgs a, const int wa_off, const int wb_off) {
+    constexpr int NT = NW * 64;
+    constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2, T3 = (T2 + 1) / 2;
+    float* lds = reinterpret_cast<float*>(dyn_lds());
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int row = a.in_c * a.in_tp;
+    float* WA = lds + wa_off;
+    float* WB = lds + wb_off;
+    constexpr int W0 = 3 * 40 * 16, WD0 = 16 * 24, W00 = 9 * 16 * 24, W01 = 9 * 24 * 24, WD1 = 24 * 32, W10 = 9 * 24 * 32, W11 = 9 * 32 * 32,
+                  WD2 = 32 * 48, W20 = 9 * 32 * 48, W21 = 9 * 48 * 48;
+#define TCR_SM_W(LI) (a.params + a.layer[LI].w_off)
+#define TCR_SM(LI, K_, S_, CI_, CO_, T_, WP_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, 0, (LI == 3 || LI == 6 || LI == 9), (K_ != 1 && LI != 9), 1, true>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, 1, wave, r, q, WP_)
+#if TCR_FUSED_WHATIF & 2048
+    long long ts[16];
+    int nts = 0;
+#define TCR_SM_TS() ts[nts++] = (long long)__builtin_readcyclecounter()
+#else
+#define TCR_SM_TS() ((void)0)
+#endif
+    for (int n0 = blockIdx.x; n0 < a.batch; n0 += gridDim.x) {
+        TCR_SM_TS();
+        small_stage_weights<NW>(TCR_SM_W(0), W0, WA, wave, lane);               // phase 0 -> A
+        small_stage_weights<NW>(TCR_SM_W(1), WD0, WB, wave, lane);              // phase 1 -> B
+        small_stage_weights<NW>(TCR_SM_W(2), W00, WB + WD0, wave, lane);
+        fused_zero_halo<NT, 16, T0>(lds + a.buf_off[a.layer[0].out_buf], a.layer[0].out_sz, 1, tid);
+        wait_dma();
+        __syncthreads();
+        TCR_SM_TS();
+        fused_conv0_s<NW, T0, true>(a, a.layer[0], a.feat + (size_t)n0 * row, row, lds, 1, wave, r, q, wa_off);
+        __syncthreads();
+        TCR_SM_TS();
+        small_stage_weights<NW>(TCR_SM_W(3), W01, WA, wave, lane);              // phase 2 -> A (conv0 is done with it)
+        TCR_SM(1, 1, 2, 16, 24, T0, wb_off);
+        TCR_SM(2, 9, 2, 16, 24, T0, wb_off + WD0);
+        wait_dma();
+        __syncthreads();
+        TCR_SM_TS();
+        small_stage_weights<NW>(TCR_SM_W(4), WD1, WB, wave, lane);              // phase 3 -> B
+        small_stage_weights<NW>(TCR_SM_W(5), W10, WB + WD1, wave, lane);
+        TCR_SM(3, 9, 1, 24, 24, T1, wa_off);
+        wait_dma();
+        __syncthreads();
+        TCR_SM_TS();
+        small_stage_weights<NW>(TCR_SM_W(6), W11, WA, wave, lane);              // phase 4 -> A
+        TCR_SM(4, 1, 2, 24, 32, T1, wb_off);
+        TCR_SM(5, 9, 2, 24, 32, T1, wb_off + WD1);
+        wait_dma();
+        __syncthreads();
+        TCR_SM_TS();
+        small_stage_weights<NW>(TCR_SM_W(7), WD2, WB, wave, lane);              // phase 5 -> B
+        small_stage_weights<NW>(TCR_SM_W(8), W20, WB + WD2, wave, lane);
+        TCR_SM(6, 9, 1, 32, 32, T2, wa_off);
+        wait_dma();
+        __syncthreads();
+        TCR_SM_TS();
+        small_stage_weights<NW>(TCR_SM_W(9), W21, WA, wave, lane);              // phase 6 -> A
+        TCR_SM(7, 1, 2, 32, 48, T2, wb_off);
+        TCR_SM(8, 9, 2, 32, 48, T2, wb_off + WD2);
+        wait_dma();
+        __syncthreads();
+        TCR_SM_TS();
+        TCR_SM(9, 9, 1, 48, 48, T3, wa_off);
+        __syncthreads();
+        TCR_SM_TS();
+        if (a.nc == 12) fused_head_s<NT, 48, T3, 12>(a, lds, n0, 1, tid);
+        else fused_head<NT>(a, lds, n0, 1, tid);
+#if TCR_FUSED_WHATIF & 2048
+        __syncthreads();
+        TCR_SM_TS();
+        if (tid == 0)
+            for (int i = 0; i + 1 < nts && i < 12; ++i) a.probs[(size_t)n0 * a.nc + i] = (float)(ts[i + 1] - ts[i]);
+        nts = 0;
+#endif
+    }
+#undef TCR_SM
+#undef TCR_SM_W
+#undef TCR_SM_TS
 }
 
 // TCResNet14-1.5 (channels 24 / 36 / 36 / 48 / 48 / 72 / 72; BASELINE.json configs[3]'s network) with compile-time layer shapes, T0 = 49 or 98
@@ -926,9 +1031,34 @@ __global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
     }
 }
 
+// one utterance per group, TCResNet8-1.0 at 49 frames, few utterances: the small-batch kernel (weights through LDS); 1: not taken
+static int launch_net_small(const FusedArgs& a0, hipStream_t s) {
+    constexpr int kWA = 9 * 48 * 48, kWB = 32 * 48 + 9 * 32 * 48;       // the two largest consecutive phases: conv2_1 | down2 + conv2_0
+    FusedArgs a = a0;
+    const int act = a.buf_off[2] + a.buf_sz[2];                         // group == 1
+    const int wa_off = (act + 64 + 63) / 64 * 64, wb_off = wa_off + kWA + 64;      // (+ pad: the layers' one-step operand lookahead)
+    const size_t lds = ((size_t)wb_off + kWB + 64) * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(net_small_tc8_kernel<8, 49>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((net_small_tc8_kernel<8, 49>), dim3(a.batch), dim3(512), lds, s, a, wa_off, wb_off);
+    return check_launch("net_small_tc8_kernel");
+}
+
 int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, int ring, hipStream_t s) {
     void (*kern)(const FusedArgs) = nullptr;
     const int tc8 = tune_get(TCR_TUNE_NET_FUSED) == 3 ? 0 : fused_tc8_frames(a);
+    if (tc8 == 49 && a.group == 1 && a.batch <= kSmallBatchMax && a.nc + 2 <= 16 && tune_get(TCR_TUNE_NET_FUSED) == 0 && tune_get(TCR_TUNE_NET_SMALL) == 0 &&
+        tune_get(TCR_TUNE_FUSED_WAVES) == 0) {
+        const int rc = launch_net_small(a, s);
+        if (rc != 1) return rc;
+    }
     // TCR_TUNE_NET_FUSED: 0 branch-free epilogue (default); 4: the round-2 static-shape kernel (A/B arm)
     const bool r2 = tune_get(TCR_TUNE_NET_FUSED) == 4;
     const bool j4 = tune_get(TCR_TUNE_NET_FUSED) == 5;         // 5: four 16-position tiles per job in block 0's layers (A/B arm, bitwise; measured 103.6 vs 103.2 us at 49 frames, 184.9 vs 181.2 at 98: no gain)

@@ -201,6 +201,7 @@ struct FusedArgs {
     FusedLayer layer[kFusedMaxLayers];
 };
 
+constexpr int kSmallBatchMax = 64;      // batches up to this many utterances take the small-batch (latency) kernel where it exists
 // returns 1 when the launch could not be configured (caller falls back to the per-layer kernels)
 int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, int ring, hipStream_t s);
 

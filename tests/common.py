@@ -119,6 +119,30 @@ def check_frontend_edges(lib, tag):
     return errs
 
 
+def check_small_batch_kernel(lib, batches=(1, 5, 64)):
+    """The small-batch network kernel (TCResNet8-1.0 at 49 frames, <= 64 utterances: one utterance per workgroup, weights DMA-copied
+    into LDS a phase ahead, one tile per job) against the throughput kernel at one utterance per group (TCR_TUNE_NET_SMALL = 1) and
+    against rows of a large batch: the same accumulation order, so logits, probabilities and ranges are bitwise equal."""
+    arch = R.make_tcresnet("TCResNet8", 1.0)
+    p, s = R.init_params(arch, 5)
+    R.randomize_bn(arch, p, s)
+    fe = make_frontend(lib, 640, 320)
+    net = make_net(lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+    wav = to_dev(lib, R.synth_waveforms(max(max(batches), 80), seed=21))
+    big = [t.clone() for t in net.forward_infer(fe(wav[:80].contiguous()), want_ranges=True)]
+    for b in batches:
+        feat = fe(wav[:b].contiguous())
+        new = [t.clone() for t in net.forward_infer(feat, want_ranges=True)]
+        try:
+            lib.tcr_tune(27, 1)
+            old = [t.clone() for t in net.forward_infer(feat, want_ranges=True)]
+        finally:
+            lib.tcr_tune(27, 0)
+        for x, y, z, what in zip(new, old, big, ("logits", "probs", "ranges")):
+            assert torch.equal(x, y), (b, what, float((x - y).abs().max()))
+            assert torch.equal(x, z[:b]), (b, what, "vs rows of a batch of 80")
+
+
 def check_edge_rows_logits(lib, tag):
     """The edge rows of the front-end fixtures (silence under background noise at three volumes, 1e-4 noise, two pure tones) through the
     WHOLE eval path -- front-end kernel -> TCResNet8-1.0 kernel with the net fixture's weights and randomised BN statistics -- against

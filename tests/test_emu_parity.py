@@ -20,6 +20,10 @@ def test_frontend_edge_rows(emu_lib, tag):
     Cm.check_frontend_edges(emu_lib, tag)
 
 
+def test_small_batch_network_kernel_is_bitwise_the_throughput_kernel(emu_lib):
+    Cm.check_small_batch_kernel(emu_lib, batches=(1, 3))
+
+
 @pytest.mark.parametrize("tag", ["3010", "4020"])
 def test_pure_tone_rows_are_where_a_float32_fft_is(emu_lib, tag):
     """The kernels' error on the pure-tone fixture rows against what a complete float32 NumPy pipeline with a single-precision FFT

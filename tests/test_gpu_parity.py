@@ -104,6 +104,10 @@ def test_frontend_persistent_chunks_are_position_independent(hip_lib, win, hop):
     assert float((big[:64] - ref).abs().max()) < Cm.MFCC_TOL
 
 
+def test_small_batch_network_kernel_is_bitwise_the_throughput_kernel(hip_lib):
+    Cm.check_small_batch_kernel(hip_lib)
+
+
 @pytest.mark.parametrize("tag", ["3010", "4020"])
 def test_edge_rows_logits(hip_lib, tag):
     Cm.check_edge_rows_logits(hip_lib, tag)
