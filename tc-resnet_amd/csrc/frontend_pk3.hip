@@ -322,13 +322,15 @@ __global__ __launch_bounds__(256, 3) void frontend_pk3_kernel(const FrontendArgs
                     up[cc] = UD[i0 + cc].x;                 // (i0, i1 <= NIT: inside the row; cells past the band's items are read and dropped)
                     dn[cc] = UD[i1 + cc].y;
                 }
+                // (nfft 1024: a segment has <= MAXC items -- the launcher sends other filterbanks to frontend_pk.hip --, so no loop behind
+                //  the unconditional reads; nfft 512: the reference filterbank has a few 3-item segments, the loops stay)
                 float mel = 0.f;
 #pragma unroll
                 for (int cc = 0; cc < MAXC; ++cc) mel += i0 + cc < i1 ? up[cc] : 0.f;
-                for (int it = i0 + MAXC; it < i1; ++it) mel += UD[it].x;
+                if (NC != 512) for (int it = i0 + MAXC; it < i1; ++it) mel += UD[it].x;
 #pragma unroll
                 for (int cc = 0; cc < MAXC; ++cc) mel += i1 + cc < i2 ? dn[cc] : 0.f;
-                for (int it = i1 + MAXC; it < i2; ++it) mel += UD[it].y;
+                if (NC != 512) for (int it = i1 + MAXC; it < i2; ++it) mel += UD[it].y;
                 LM[m * 16 + (c ^ ((m >> 1) & 15))] = fast_log(a.log_floor ? fmaxf(mel, 1e-12f) : mel + 1e-6f);
             }
         }
@@ -391,7 +393,8 @@ __global__ __launch_bounds__(256, 3) void frontend_pk3_kernel(const FrontendArgs
 }
 
 // returns 1 (nothing launched) when the configuration needs another kernel: unaligned frames, a window whose valid radix-16 inputs
-// differ from lane to lane, or a filterbank with more items than the unrolled trips take
+// differ from lane to lane, or a filterbank with more items than the unrolled trips take / with a segment of more items than the log
+// phase reads (n_items < 0: frontend_mel_item_count)
 int launch_frontend_pk3(int nc, const FrontendArgs& a0, int n_items, hipStream_t s) {
     const int sub = nc / 256;
     if (!a0.aligned || (a0.win & 1) || (a0.win / 2) % (16 * sub) != 0) return 1;

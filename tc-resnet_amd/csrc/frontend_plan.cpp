@@ -307,6 +307,7 @@ extern "C" int tcr_frontend_plan_init(const tcr_frontend_cfg* cfg, void* host_pl
 }
 
 int tcr::frontend_mel_item_count(const tcr_frontend_cfg& c) {
+    // (-1 as well when, at nfft 1024, a segment has more than the three items the three-waves kernel's log phase reads)
     struct Entry { tcr_frontend_cfg cfg; int n; };
     static std::mutex mu;
     static std::vector<Entry> cache;
@@ -317,7 +318,13 @@ int tcr::frontend_mel_item_count(const tcr_frontend_cfg& c) {
     if (c.nfft == 512 || c.nfft == 1024) {
         const FrontendPlanLayout L = frontend_plan_layout(c);
         std::vector<float> plan(L.words);
-        if (tcr_frontend_plan_init(&c, plan.data()) == TCR_OK) n = reinterpret_cast<const int32_t*>(plan.data() + L.mel_ifirst)[L.nseg];
+        if (tcr_frontend_plan_init(&c, plan.data()) == TCR_OK) {
+            const int32_t* ifirst = reinterpret_cast<const int32_t*>(plan.data() + L.mel_ifirst);
+            n = ifirst[L.nseg];
+            if (L.nc == 512)
+                for (int j = 0; j < L.nseg; ++j)
+                    if (ifirst[j + 1] - ifirst[j] > 3) n = -1;
+        }
     }
     if (cache.size() >= 64) cache.clear();
     cache.push_back(Entry{c, n});
