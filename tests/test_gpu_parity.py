@@ -104,6 +104,23 @@ def test_frontend_persistent_chunks_are_position_independent(hip_lib, win, hop):
     assert float((big[:64] - ref).abs().max()) < Cm.MFCC_TOL
 
 
+def test_frontend_kernels_agree_over_batch_sizes(hip_lib):
+    """Chunk / wave / round geometry of the three-waves front-end over awkward batch sizes (one round per chunk at the small ones,
+    partial last chunks, fewer chunks than workgroups): bitwise the two-waves kernel, both reference framings."""
+    wav_all = torch.from_numpy(R.synth_waveforms(64, seed=3)).to("cuda").repeat(16, 1)
+    for win, hop in ((640, 320), (480, 160)):
+        fe = Cm.make_frontend(hip_lib, win, hop)
+        for b in (1, 2, 3, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 129, 1000):
+            wav = wav_all[:b].contiguous()
+            new = fe(wav).clone()
+            try:
+                hip_lib.tcr_tune(23, 1)
+                old = fe(wav).clone()
+            finally:
+                hip_lib.tcr_tune(23, 0)
+            assert torch.equal(new, old), (win, hop, b)
+
+
 def test_small_batch_network_kernel_is_bitwise_the_throughput_kernel(hip_lib):
     Cm.check_small_batch_kernel(hip_lib)
 
