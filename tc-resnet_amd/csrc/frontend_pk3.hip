@@ -278,10 +278,15 @@ __global__ __launch_bounds__(256, 3) void frontend_pk3_kernel(const FrontendArgs
         wave_sync();
         // ---------------- sparse mel: one item (<= 8 bins of one segment) per lane and trip, one packed FMA per bin ----------------
         v2* UD = s_ud + (wave * FPWV + fw) * USZ;
+        int bi_pre[NMEL / LPF];                             // the bands' item ranges: requested with the trips' operands, used by the log phase
+        if (kBandsLds) {
+#pragma unroll
+            for (int i = 0; i < NMEL / LPF; ++i) bi_pre[i] = s_band[lf + LPF * i];
+        }
         {
             const float* P = Pw + fw * PLD;
-#pragma unroll 1
-            for (int tr = 0; tr < TRIPS; ++tr) {
+#pragma unroll
+            for (int tr = 0; tr < TRIPS; ++tr) {            // (unrolled: the trips' descriptor and operand reads overlap instead of TRIPS dependent LDS round trips in a row)
                 const int it = lf + LPF * tr;
                 int d;
                 if (kItemsLds) {
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256, 3) void frontend_pk3_kernel(const FrontendArgs
 #pragma unroll
             for (int i = 0; i < NMEL / LPF; ++i) {
                 const int m = lf + LPF * i;
-                const int bi = kBandsLds ? s_band[m] : band_i[kBandsLds ? 0 : i];
+                const int bi = kBandsLds ? bi_pre[i] : band_i[kBandsLds ? 0 : i];
                 const int i0 = bi & 255, i1 = (bi >> 8) & 255, i2 = bi >> 16;
                 constexpr int MAXC = NC == 512 ? 3 : 2;
                 float up[MAXC], dn[MAXC];
