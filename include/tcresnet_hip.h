@@ -429,7 +429,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_PW_WGRAD = 25,   /* wide pointwise (DS-CNN 172 / 276 channels) filter gradient: 0 the register-staged kernel (two 4-wave workgroups per CU; default), 1 the DMA-staged kernel (global_load_lds into two LDS buffers, one 12-wave workgroup per CU, three split-K wave groups; measured 2 % slower) */
        TCR_TUNE_DEPLOY_F32 = 26, /* deploy-path MFCC (method 2): 0 the float64 kernel (one workgroup per frame; TF's ops compute in double; default), 1 the float32 throughput kernels with the op's filterbank / log floor (rounds 3-4: up to 0.5 off on noise-free tones, where the empty bands are pure round-off) */
        TCR_TUNE_NET_SMALL = 27,  /* eval network, TCResNet8-1.0 at 49 frames, batches of <= 64 utterances: 0 the small-batch kernel (one utterance per 8-wave workgroup, each phase's weights DMA-copied into LDS one phase ahead; default), 1 the throughput kernel at one utterance per group (rounds 2-4).  Bitwise the same outputs. */
-       TCR_TUNE_COUNT = 28 };
+       TCR_TUNE_PW_POS = 28,     /* wide pointwise convs (DS-CNN-L, 276 channels; forward, data gradient): 0 the nine-tile kernel built for <= 128 registers = four waves per SIMD (default since round 5), 1 the unconstrained build of rounds 3-4 (92 VGPRs + 72 AGPRs, three waves per SIMD).  Bitwise the same results. */
+       TCR_TUNE_COUNT = 29 };
 int tcr_tune(int knob, int value);
 
 /* The library's internal streams (hipStream_t), one set per device and process.  HIP multiplexes streams onto a few hardware queues

@@ -135,17 +135,24 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
 #define TCR_PW_WHATIF 0
 #endif
 #define TCR_PWW(bit) ((TCR_PW_WHATIF & (bit)) != 0)
-template <int MT, int NT, int EPI, int MODE>
-__global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
+// NWN: wave columns per workgroup (2: four waves, 32 NT positions).  Round 5 measured NWN = 3 (six waves, 96 positions: a staged weight chunk
+// serves half again as many positions -- every workgroup walks ALL of W, 1.3 GB of L2 -> CU traffic per launch at 276 channels): DS-CNN-L
+// eval 4.48 vs 4.06 ms, training step 17.5 vs 15.7 -- slower, not instantiated.  MINW = 4 (default for the nine-tile instances since round 5):
+// the compiler keeps the 72 accumulator registers in VGPRs and fits 128 -- four waves per SIMD instead of three (92 VGPRs + 72 AGPRs):
+// DS-CNN-L eval 4.06 -> 3.93 ms, training step 15.72 -> 15.47 ms; TCR_TUNE_PW_POS = 1 selects the unconstrained build (bitwise the same).
+template <int MT, int NT, int EPI, int MODE, int NWN = 2, int MINW = 1>
+__global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv1x1Args a) {     // MINW = 4: <= 128 registers (four waves per SIMD)
+    constexpr int NTHR = 128 * NWN;
     constexpr int KC = 12;                  // input channels per chunk = 3 MFMA k-steps
     constexpr int MW = 32 * MT;             // output channels covered (2 wave rows)
-    constexpr int XN = 32 * NT;             // positions per workgroup (2 wave columns)
+    constexpr int XN = 16 * NT * NWN;       // positions per workgroup (NWN wave columns)
     constexpr int WLD = MW + 16;            // (32 MT + 16) % 64 in {16, 48} for MT = 6, 9
-    constexpr int XLD = XN + 16;            // (32 NT + 16) % 64 in {16, 48}
-    constexpr int RS = 256 / XN;            // x rows staged per pass (threads >= RS * XN idle in the x stage)
+    constexpr int XLD = XN + 16;            // (XN + 16) % 64 in {16, 48} for XN = 64, 96
+    constexpr int RS = NTHR / XN;           // x rows staged per pass (threads >= RS * XN idle in the x stage)
     constexpr int XPT = KC / RS;            // x dwords per thread and chunk
     constexpr int W4 = MW / 4;              // float4 per weight row
-    constexpr int WPT = (KC * W4 + 255) / 256;
+    constexpr int WPT = (KC * W4 + NTHR - 1) / NTHR;
+    static_assert(NTHR % XN == 0 && (XLD % 64 == 16 || XLD % 64 == 48), "x staging geometry / bank pattern");
     static_assert(KC % RS == 0, "x staging");
     __shared__ float s_w[2][KC * WLD];
     __shared__ float s_x[2][KC * XLD];
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
     // ---- staging roles ----
     const bool xuse = tid < RS * XN;
     const int xpos = tid % XN, xrow0 = XN == 64 ? wave : min(tid / XN, RS - 1);   // rows xrow0 + RS * j  (XN = 64: wave-uniform -> scalar loads of in_scale / in_shift)
+    static_assert(XN != 64 || NTHR == 256, "wave-uniform x rows");
     const float* xsrc;
     bool xvalid, xfirst, xlast;
     {
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
     bool wuse[WPT], wval[WPT];
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-        const int idx = tid + 256 * j;
+        const int idx = tid + NTHR * j;
         wuse[j] = idx < KC * W4;
         wrow[j] = min(idx / W4, KC - 1);
         wcol[j] = 4 * (idx % W4);
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
         first[nt] = t == 0; last[nt] = t == a.tout - 1;
     }
     float* s_sum = &s_w[0][0];              // [wn][which][MW] (the loop's last barrier is behind every LDS read of the tiles)
-    static_assert(2 * 2 * MW <= KC * WLD, "sums fit the first weight buffer");
+    static_assert(NWN * 2 * MW <= KC * WLD, "sums fit the first weight buffer");
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int co0 = (wm * MT + m) * 16;
@@ -361,9 +369,11 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const Conv1x1Args a) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * a.cout; i += 256) {
+    for (int i = tid; i < 2 * a.cout; i += NTHR) {
         const int which = i >= a.cout ? 1 : 0, c = i - which * a.cout;
-        a.sums.partial[((size_t)blockIdx.x * 2 + which) * a.cout + c] = s_sum[which * MW + c] + s_sum[(2 + which) * MW + c];
+        float v = s_sum[which * MW + c] + s_sum[(2 + which) * MW + c];
+        if (NWN > 2) v += s_sum[(4 + which) * MW + c];
+        a.sums.partial[((size_t)blockIdx.x * 2 + which) * a.cout + c] = v;
     }
 }
 
@@ -382,6 +392,8 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
         const int mt = tiles > 12 ? 9 : 6;
         // 2 column tiles per wave = 64 positions per workgroup (3 tiles: 236 VGPRs, 2 waves per SIMD, slower; 4: slower still)
         const dim3 lgrid(ceil_div(a.npos, 64));
+        const dim3 lblk(256);
+        const bool cap128 = tune_get(TCR_TUNE_PW_POS) != 1;     // nine-tile instances at <= 128 registers (four waves per SIMD)
         if (extras) {
             // training forms: (in-affine + forward sums) with the bias epilogue, or (backward sums) on the raw data gradient
             const bool fwd = epi == MF_AFFINE && a.in_scale && a.in_shift && a.sums.partial && !a.sums.raw;
@@ -389,18 +401,27 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
             const bool bfly = bwd && a.dy_out && a.fly.raw && a.fly.mean && a.fly.k1 && a.fly.k2 && a.fly.k3 && a.fly.self_scale && a.fly.self_shift && a.tpi == a.tpo;
             if (!fwd && !bwd) { set_error("conv1x1: unsupported combination of in-affine / epilogue sums"); return TCR_ERR_ARG; }
             if (a.dy_out && !bfly) { set_error("conv1x1: on-the-fly BN backward needs the data-gradient form with sums"); return TCR_ERR_ARG; }
-#define TCR_LT(MT_)                                                                                                     \
-    if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE, 1>), lgrid, dim3(256), 0, s, a);                \
-    else if (bfly) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 3>), lgrid, dim3(256), 0, s, a);             \
-    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 2>), lgrid, dim3(256), 0, s, a)
-            if (mt == 9) { TCR_LT(9); } else { TCR_LT(6); }
+#define TCR_LT(MT_, NWN_)                                                                                               \
+    if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE, 1, NWN_>), lgrid, lblk, 0, s, a);               \
+    else if (bfly) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 3, NWN_>), lgrid, lblk, 0, s, a);            \
+    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 2, NWN_>), lgrid, lblk, 0, s, a)
+            if (cap128 && mt == 9) {
+                if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_AFFINE, 1, 2, 4>), lgrid, lblk, 0, s, a);
+                else if (bfly) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 3, 2, 1>), lgrid, lblk, 0, s, a);     // (this form spills at 128)
+                else hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 2, 2, 4>), lgrid, lblk, 0, s, a);
+            }
+            else if (mt == 9) { TCR_LT(9, 2); } else { TCR_LT(6, 2); }
 #undef TCR_LT
             return check_launch("conv1x1_lds_kernel");
         }
-#define TCR_LL(MT_)                                                                                                     \
-    if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 0>), lgrid, dim3(256), 0, s, a);         \
-    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE, 0>), lgrid, dim3(256), 0, s, a)
-        if (mt == 9) { TCR_LL(9); } else { TCR_LL(6); }
+#define TCR_LL(MT_, NWN_)                                                                                               \
+    if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 0, NWN_>), lgrid, lblk, 0, s, a);        \
+    else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE, 0, NWN_>), lgrid, lblk, 0, s, a)
+        if (cap128 && mt == 9) {
+            if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 0, 2, 4>), lgrid, lblk, 0, s, a);
+            else hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_AFFINE, 0, 2, 4>), lgrid, lblk, 0, s, a);
+        }
+        else if (mt == 9) { TCR_LL(9, 2); } else { TCR_LL(6, 2); }
 #undef TCR_LL
         return check_launch("conv1x1_lds_kernel");
     }

@@ -552,6 +552,31 @@ def check_dscnn_pointwise_wgrad_kernels(lib, size, batch):
     assert not torch.equal(a, b)                # (the knob did select another kernel)
 
 
+def check_dscnn_pointwise_geometries(lib, size, batch):
+    """The wide pointwise conv kernel built for <= 128 registers (four waves per SIMD; default) against the unconstrained build of
+    rounds 3-4 (TCR_TUNE_PW_POS = 1): the same instructions in another register allocation -- eval logits and training gradients bitwise."""
+    from oracle import dscnn_ref as D
+    p, s = D.init_params(D.net_def(size), seed=4)
+    fe = make_frontend(lib, 640, 320, num_mfccs=10)
+    base = R.synth_waveforms(min(batch, 32), seed=8)
+    reps = max(batch // base.shape[0], 1)
+    feat = fe(to_dev(lib, np.tile(base, (reps, 1))))
+    labels = to_dev(lib, np.tile(R.synth_labels(base.shape[0]), (reps, 1)))
+    evals, grads = [], []
+    try:
+        for knob in (0, 1):
+            lib.tcr_tune(28, knob)
+            net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
+            sd = dict(p); sd.update(s); net.load_state_dict(sd)
+            evals.append(net.forward_infer(feat)[0].clone())
+            net.forward_train(feat, labels)
+            grads.append(net.backward().clone())
+    finally:
+        lib.tcr_tune(28, 0)
+    assert torch.equal(evals[0], evals[1]), float((evals[0] - evals[1]).abs().max())
+    assert torch.isfinite(grads[0]).all() and torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
+
+
 def check_dscnn_lazy_equals_materialised(lib, size, batch, seed=6):
     """DS-CNN training with the normalised activations never materialised (default for the 172 / 276-channel nets: BN + ReLU applied by
     the consumers to the raw conv outputs, statistics / backward sums from the conv and data-gradient epilogues) against the materialising

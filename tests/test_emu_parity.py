@@ -214,6 +214,10 @@ def test_dscnn_pointwise_filter_gradient_kernels_agree(emu_lib):
     Cm.check_dscnn_pointwise_wgrad_kernels(emu_lib, "M", 3)
 
 
+def test_dscnn_pointwise_kernel_geometries_agree(emu_lib):
+    Cm.check_dscnn_pointwise_geometries(emu_lib, "M", 3)
+
+
 def test_dscnn_lazy_training_path_equals_materialised(emu_lib):
     Cm.check_dscnn_lazy_equals_materialised(emu_lib, "M", 2)
 

@@ -508,6 +508,11 @@ def test_dscnn_staged_sync_bn_api(hip_lib, size, batch):
 
 
 @pytest.mark.parametrize("size,batch", [("L", 37), ("M", 256)])
+def test_dscnn_pointwise_kernel_geometries_agree(hip_lib, size, batch):
+    Cm.check_dscnn_pointwise_geometries(hip_lib, size, batch)
+
+
+@pytest.mark.parametrize("size,batch", [("L", 37), ("M", 256)])
 def test_dscnn_pointwise_filter_gradient_kernels_agree(hip_lib, size, batch):
     Cm.check_dscnn_pointwise_wgrad_kernels(hip_lib, size, batch)
 
