@@ -430,7 +430,11 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_DEPLOY_F32 = 26, /* deploy-path MFCC (method 2): 0 the float64 kernel (one workgroup per frame; TF's ops compute in double; default), 1 the float32 throughput kernels with the op's filterbank / log floor (rounds 3-4: up to 0.5 off on noise-free tones, where the empty bands are pure round-off) */
        TCR_TUNE_NET_SMALL = 27,  /* eval network, TCResNet8-1.0 at 49 frames, batches of <= 64 utterances: 0 the small-batch kernel (one utterance per 8-wave workgroup, each phase's weights DMA-copied into LDS one phase ahead; default), 1 the throughput kernel at one utterance per group (rounds 2-4).  Bitwise the same outputs. */
        TCR_TUNE_PW_POS = 28,     /* wide pointwise convs (DS-CNN-L, 276 channels; forward, data gradient): 0 the nine-tile kernel built for <= 128 registers = four waves per SIMD (default since round 5), 1 the unconstrained build of rounds 3-4 (92 VGPRs + 72 AGPRs, three waves per SIMD).  Bitwise the same results. */
-       TCR_TUNE_COUNT = 29 };
+       TCR_TUNE_BN_APPLY = 29,   /* BN-backward apply pass over large tensors (DS-CNN): 0 four float4 per thread and operand, per-channel coefficients staged in LDS (default since round 5), 1 the one-float4-per-thread kernel of rounds 2-4.  Bitwise the same dy. */
+       TCR_TUNE_DW_DGRAD = 30,   /* DS-CNN depthwise data gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (dz / raw / dx blocks of 16 planes as contiguous float4 through LDS, one lane per map row; default since round 5), 1 the zero-padded-image kernel of rounds 2-4.  Bitwise the same dx and backward sums. */
+       TCR_TUNE_DW_WGRAD = 31,   /* DS-CNN depthwise filter gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (a wave owns four channels, their x / dz planes as contiguous float4 through wave-private LDS; default since round 5), 1 the gather kernel of rounds 2-4 (another summation order: equal to rounding). */
+       TCR_TUNE_DW_FWD = 32,     /* DS-CNN depthwise conv (eval and training forward), stride-1 layers on 13 x 5 maps: 0 the row kernel (x / y blocks of 16 planes as contiguous float4 through LDS; default since round 5), 1 the zero-padded-image kernel of rounds 2-4.  Bitwise the same outputs and statistics. */
+       TCR_TUNE_COUNT = 33 };
 int tcr_tune(int knob, int value);
 
 /* The library's internal streams (hipStream_t), one set per device and process.  HIP multiplexes streams onto a few hardware queues

@@ -579,12 +579,84 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const BnBwdApplyArgs
     *reinterpret_cast<bn_f4*>(a.dy + i0) = o4;
 }
 
+// The same pass for the large tensors (DS-CNN-L: 4096 x 276 x 73 floats, ~1 GB through HBM per launch): kApplyU float4 per thread
+// and operand, all loads of a thread issued before anything waits on them (the one-float4 kernel above keeps 32 B per lane in flight
+// and ran at 2.8 TB/s; a float4 copy measures 6.3 TB/s on this chip); the six per-channel coefficients of the workgroup's channel
+// range are staged in LDS once (8 floats per channel) instead of 24 gathers per float4.  A float4 touches at most two channels (tp >= 4).
+// Same expression per element as bn_bwd_apply_kernel: bitwise the same dy.
+constexpr int kApplyU = 4;
+constexpr int kApplyMaxCh = 264;                // channels a workgroup's 1024 * kApplyU floats can touch at tp >= 16: 4096 / 16 + 2
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4x_kernel(const BnBwdApplyArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_k[kApplyMaxCh * 8];
+    const int per_utt = a.c * a.tp;
+    const int base4 = blockIdx.x * (256 * kApplyU);
+    const size_t u0 = (size_t)blockIdx.y * per_utt;
+    bn_f4 y4[kApplyU], d4[kApplyU];
+    int j0[kApplyU];
+#pragma unroll
+    for (int u = 0; u < kApplyU; ++u) {         // (past the utterance's end: the last float4 again, not stored)
+        j0[u] = min((base4 + u * 256 + (int)threadIdx.x) * 4, per_utt - 4);
+        y4[u] = *reinterpret_cast<const bn_f4*>(a.y + u0 + j0[u]);
+        d4[u] = (bn_f4){0.f, 0.f, 0.f, 0.f};
+        if (!a.bcast) d4[u] = *reinterpret_cast<const bn_f4*>(a.da + u0 + j0[u]);
+    }
+    const int c_lo = fast_div(min(base4 * 4, per_utt - 4), a.tp, a.inv_tp);
+    const int c_hi = min(fast_div(min((base4 + 256 * kApplyU) * 4, per_utt) - 1, a.tp, a.inv_tp) + 1, a.c - 1);
+    const bool has_self = a.self_scale != nullptr;
+    for (int i = threadIdx.x; i < (c_hi - c_lo + 1) * 8; i += 256) {
+        const int ch = c_lo + (i >> 3), k = i & 7;
+        float v = 0.f;
+        if (k == 0) v = a.k1[ch];
+        else if (k == 1) v = a.k2[ch];
+        else if (k == 2) v = a.k3[ch];
+        else if (k == 3) v = a.mean[ch];
+        else if (k == 4) v = has_self ? a.self_scale[ch] : 0.f;
+        else if (k == 5) v = has_self ? a.self_shift[ch] : 1.f;
+        s_k[i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kApplyU; ++u) {
+        if ((base4 + u * 256 + (int)threadIdx.x) * 4 >= per_utt) break;
+        const int c = fast_div(j0[u], a.tp, a.inv_tp);
+        const int cn = min(c + 1, a.c - 1);
+        const bn_f4 ka = *reinterpret_cast<const bn_f4*>(s_k + (c - c_lo) * 8), kb = *reinterpret_cast<const bn_f4*>(s_k + (c - c_lo) * 8 + 4);
+        const bn_f4 na = *reinterpret_cast<const bn_f4*>(s_k + (cn - c_lo) * 8), nb = *reinterpret_cast<const bn_f4*>(s_k + (cn - c_lo) * 8 + 4);
+        bn_f4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0[u] + e;
+            const bool nx = j >= (c + 1) * a.tp;
+            const int ce = nx ? c + 1 : c;
+            const int tt = j - ce * a.tp - kHalo;
+            const float k1 = nx ? na[0] : ka[0], k2 = nx ? na[1] : ka[1], k3 = nx ? na[2] : ka[2], mu = nx ? na[3] : ka[3];
+            const float ssc = nx ? nb[0] : kb[0], ssh = nx ? nb[1] : kb[1];
+            float v = 0.f;
+            if (tt >= 0 && tt < a.t) {
+                float dz = a.bcast ? a.da[(size_t)blockIdx.y * a.c + ce] : d4[u][e];
+                const float yv = y4[u][e];
+                if (has_self && !(fmaf(yv, ssc, ssh) > 0.f)) dz = 0.f;
+                v = k1 * (dz - k2 - (yv - mu) * k3);
+            }
+            o4[e] = v;
+        }
+        *reinterpret_cast<bn_f4*>(a.dy + u0 + j0[u]) = o4;
+    }
+}
+
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a0, hipStream_t s) {
     BnBwdApplyArgs a = a0;
     a.inv_tp = 1.0f / (float)a.tp;
     const int per_utt = a.c * a.tp;
     const int batch = (int)(a.total / per_utt);
     if (per_utt >= (1 << 22) || batch > 65535) { set_error("bn_bwd_apply: %d x %d exceeds the launch geometry", batch, per_utt); return TCR_ERR_ARG; }
+    // the wide kernel where an utterance fills at least two of its workgroups (DS-CNN: 20148 floats; TC-ResNet's 16-72 channels x 57 do not)
+    if (!a.accumulate && !a.m1 && !a.m2 && a.tp >= 16 && per_utt >= 2 * 1024 * kApplyU && tune_get(TCR_TUNE_BN_APPLY) != 1 &&
+        bn_vec4_ok(a.y, a.bcast ? nullptr : a.da, nullptr, nullptr, per_utt) && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) {
+        hipLaunchKernelGGL(bn_bwd_apply4x_kernel, dim3(ceil_div(per_utt / 4, 256 * kApplyU), batch), dim3(256), 0, s, a);
+        return check_launch("bn_bwd_apply4x_kernel");
+    }
     if (!a.accumulate && bn_vec4_ok(a.y, a.bcast ? nullptr : a.da, a.m1, a.m2, per_utt) && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) {
         hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(ceil_div(per_utt / 4, 256), batch), dim3(256), 0, s, a);
         return check_launch("bn_bwd_apply4_kernel");

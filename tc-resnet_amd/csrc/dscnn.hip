@@ -520,7 +520,112 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds2_kernel(const DsDwArg
     }
 }
 
+// The stride-1 layers on 13 x 5 maps, every byte through HBM as a contiguous float4 (see dscnn_dw_dgrad_rows_kernel): a workgroup owns 16
+// consecutive planes = one contiguous block of 16 x Pp floats of x and of y.  x is copied to LDS as it lies; lane (plane, h) computes the
+// W outputs of map row h from the three x rows around it (in-affine + ReLU where they leave LDS, zeros outside the map; the same fmaf
+// chain per output as the image kernels) into an LDS copy of the y block, which leaves as float4 (halo floats zero).  Epilogue sums from
+// the LDS copy by 16 lanes per plane in the image kernels' order: bitwise the same y and partial rows.
+template <int H, int W>
+__global__ __launch_bounds__(256) void dscnn_depthwise_rows_kernel(const DsDwArgs a) {
+    constexpr int NPL = 16, P = H * W;
+    static_assert(NPL * H <= 256, "one lane per (plane, map row)");
+    const int pp = a.ppo;                                       // (== ppi)
+    const int blk = NPL * pp, n4 = blk / 4;
+    float* s_x = reinterpret_cast<float*>(dyn_lds());
+    float* s_y = s_x + blk;
+    const int tid = threadIdx.x;
+    const size_t g0 = (size_t)blockIdx.x * blk;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + g0);
+    const bool two = tid + 256 < n4;
+    const f32x4 z0 = x4[tid], z1 = x4[two ? tid + 256 : tid];
+    const int row0 = blockIdx.x * NPL;
+    const int n0 = row0 / a.c, c0 = row0 - n0 * a.c;
+    const int pl3 = tid / H, h = tid - pl3 * H;                 // the compute phase's (plane, map row)
+    const bool act3 = pl3 < NPL;
+    int c3 = c0 + (act3 ? pl3 : 0);
+    if (c3 >= a.c) c3 -= a.c;
+    float wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = a.w[(size_t)k * a.c + c3];
+    const bool aff = a.in_scale != nullptr;
+    const float isc = aff ? a.in_scale[c3] : 1.0f, isf = aff ? a.in_shift[c3] : 0.f;
+    const float sc = a.scale ? a.scale[c3] : 1.0f, sh = a.shift[c3];
+    reinterpret_cast<f32x4*>(s_x)[tid] = z0;
+    if (two) reinterpret_cast<f32x4*>(s_x)[tid + 256] = z1;
+    if (tid < NPL * 2 * kHalo) {
+        const int pl = tid / (2 * kHalo), k = tid - pl * (2 * kHalo);
+        s_y[pl * pp + (k < kHalo ? k : P + k)] = 0.f;
+    }
+    __syncthreads();
+    if (act3) {
+        float in[3][W + 2];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {                        // x row h + rr - 1 (tap row di = rr)
+            const int hh = h + rr - 1;
+            const bool hv = hh >= 0 && hh < H;
+            const float* src = s_x + pl3 * pp + kHalo + (hv ? hh : h) * W;
+            in[rr][0] = 0.f; in[rr][W + 1] = 0.f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                float v = src[w];
+                if (aff) v = fmaxf(fmaf(v, isc, isf), 0.f);
+                in[rr][w + 1] = hv ? v : 0.f;
+            }
+        }
+        float* dst = s_y + pl3 * pp + kHalo + h * W;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) sacc = fmaf(wt[di * 3 + dj], in[di][w + dj], sacc);          // x[h + di - 1][w + dj - 1]
+            float o = fmaf(sacc, sc, sh);
+            if (a.relu) o = fmaxf(o, 0.f);
+            dst[w] = o;
+        }
+    }
+    __syncthreads();
+    f32x4* y4 = reinterpret_cast<f32x4*>(a.y + g0);
+    y4[tid] = reinterpret_cast<const f32x4*>(s_y)[tid];
+    if (two) y4[tid + 256] = reinterpret_cast<const f32x4*>(s_y)[tid + 256];
+    if (a.sums.partial) {
+        const int plane = tid >> 4, t16 = tid & 15;
+        int c = c0 + plane, n = n0;
+        if (c >= a.c) { c -= a.c; ++n; }
+        const float* sy = s_y + plane * pp + kHalo;
+        float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < (P + 15) / 16; ++i) {
+            const int pos = t16 + 16 * i;
+            if (pos < P) {
+                const float o = sy[pos];
+                q1 += o;
+                q2 = fmaf(o, o, q2);
+            }
+        }
+        q1 = row16_sum(q1);
+        q2 = row16_sum(q2);
+        if (t16 == 0) {
+            a.sums.partial[((size_t)n * 2 + 0) * a.c + c] = q1;
+            a.sums.partial[((size_t)n * 2 + 1) * a.c + c] = q2;
+        }
+    }
+}
+
+static bool dscnn_depthwise_rows_covers(const DsDwArgs& d, int batch) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int64_t planes = (int64_t)batch * d.c;
+    return d.sh == 1 && d.sw == 1 && d.pad_t == 1 && d.pad_l == 1 && d.h_in == 13 && d.w_in == 5 && d.oh == 13 && d.ow == 5 && d.ppi == d.ppo &&
+           d.ppo == 13 * 5 + 2 * kHalo && planes % 16 == 0 && planes / 16 < (int64_t)1 << 27 && d.c >= 16 && al(d.x) && al(d.y) &&
+           tune_get(TCR_TUNE_DW_FWD) != 1;
+}
+
 static int launch_dscnn_depthwise(const DsDwArgs& d, int batch, hipStream_t s) {
+    if (dscnn_depthwise_rows_covers(d, batch)) {
+        hipLaunchKernelGGL((dscnn_depthwise_rows_kernel<13, 5>), dim3((unsigned)((int64_t)batch * d.c / 16)), dim3(256), (size_t)2 * 16 * d.ppo * sizeof(float), s, d);
+        return check_launch("dscnn_depthwise_rows_kernel");
+    }
     const int rows = batch * d.c;
     const int img_r = (d.oh - 1) * d.sh + 3, img_c = (d.ow - 1) * d.sw + 3;
     const size_t lds = (size_t)16 * img_r * img_c * sizeof(float);

@@ -146,12 +146,122 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_lds_kernel(const DsDwBwdAr
     }
 }
 
+// Stride-1 layers of the 13 x 5 maps (four of DS-CNN's five depthwise units), every byte through HBM as a contiguous float4: a workgroup
+// owns 16 consecutive planes = ONE contiguous block of 16 x Pp floats of dz, of the raw output (EpiSums) and of dx.  dz and raw are copied
+// to LDS as they lie (292 float4, no index arithmetic); lane (plane, h) then computes the W outputs of map row h from the three dz rows
+// around it (15 LDS reads for 5 outputs; the image kernel above reads 9 per output and spends ~30 VALU instructions per staged element
+// on divisions and predicates) and writes them to an LDS copy of the dx block, which leaves as float4.  The backward sums are taken from
+// the LDS copies by 16 lanes per plane in the order of the image kernel (positions t16, t16 + 16, ...; row16_sum): bitwise the same
+// partial rows, and the same fmaf chain per output (out-of-map taps multiply a zero).
+template <int H, int W>
+__global__ __launch_bounds__(256) void dscnn_dw_dgrad_rows_kernel(const DsDwBwdArgs a) {
+    constexpr int NPL = 16, P = H * W;
+    static_assert(NPL * H <= 256, "one lane per (plane, map row)");
+    const int pp = a.ppo;                                       // (== ppi)
+    const int blk = NPL * pp, n4 = blk / 4;
+    float* s_dz = reinterpret_cast<float*>(dyn_lds());
+    float* s_raw = s_dz + blk;
+    float* s_dx = s_raw + blk;
+    const int tid = threadIdx.x;
+    const bool sums = a.sums.partial != nullptr;
+    const size_t g0 = (size_t)blockIdx.x * blk;
+    const f32x4* dz4 = reinterpret_cast<const f32x4*>(a.dz + g0);
+    const f32x4* rw4 = reinterpret_cast<const f32x4*>(sums ? a.sums.raw + g0 : a.dz + g0);
+    const bool two = tid + 256 < n4;
+    const f32x4 z0 = dz4[tid], z1 = dz4[two ? tid + 256 : tid];
+    f32x4 r0 = z0, r1 = z1;
+    if (sums) { r0 = rw4[tid]; r1 = rw4[two ? tid + 256 : tid]; }
+    // channel of the workgroup's first plane (wave-uniform), then per lane
+    const int row0 = blockIdx.x * NPL;
+    const int n0 = row0 / a.c, c0 = row0 - n0 * a.c;
+    const int pl3 = tid / H, h = tid - pl3 * H;                 // the compute phase's (plane, map row)
+    const bool act3 = pl3 < NPL;
+    int c3 = c0 + (act3 ? pl3 : 0);
+    if (c3 >= a.c) c3 -= a.c;
+    float wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = a.w[(size_t)k * a.c + c3];
+    reinterpret_cast<f32x4*>(s_dz)[tid] = z0;
+    if (two) reinterpret_cast<f32x4*>(s_dz)[tid + 256] = z1;
+    if (sums) {
+        reinterpret_cast<f32x4*>(s_raw)[tid] = r0;
+        if (two) reinterpret_cast<f32x4*>(s_raw)[tid + 256] = r1;
+    }
+    if (tid < NPL * 2 * kHalo) {                                // the halo floats of the dx block leave as zeros
+        const int pl = tid / (2 * kHalo), k = tid - pl * (2 * kHalo);
+        s_dx[pl * pp + (k < kHalo ? k : P + k)] = 0.f;
+    }
+    __syncthreads();
+    if (act3) {
+        float in[3][W + 2];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {                        // rr: map row h + 1 - rr (tap row di = rr)
+            const int hh = h + 1 - rr;
+            const bool hv = hh >= 0 && hh < H;
+            const float* src = s_dz + pl3 * pp + kHalo + (hv ? hh : h) * W;
+            in[rr][0] = 0.f; in[rr][W + 1] = 0.f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { const float v = src[w]; in[rr][w + 1] = hv ? v : 0.f; }
+        }
+        float* dst = s_dx + pl3 * pp + kHalo + h * W;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) sacc = fmaf(wt[di * 3 + dj], in[di][w + 2 - dj], sacc);      // dz[h + 1 - di][w + 1 - dj]
+            dst[w] = sacc;
+        }
+    }
+    __syncthreads();
+    f32x4* dx4 = reinterpret_cast<f32x4*>(a.dx + g0);
+    dx4[tid] = reinterpret_cast<const f32x4*>(s_dx)[tid];
+    if (two) dx4[tid + 256] = reinterpret_cast<const f32x4*>(s_dx)[tid + 256];
+    if (sums) {
+        const int plane = tid >> 4, t16 = tid & 15;
+        int c = c0 + plane, n = n0;
+        if (c >= a.c) { c -= a.c; ++n; }
+        const float mu = a.sums.mean[c], is = a.sums.invstd[c], ssc = a.sums.self_scale[c], ssh = a.sums.self_shift[c];
+        const float* sx = s_dx + plane * pp + kHalo;
+        const float* sr = s_raw + plane * pp + kHalo;
+        float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < (P + 15) / 16; ++i) {
+            const int pos = t16 + 16 * i;
+            if (pos < P) {
+                const float rw = sr[pos];
+                const float dzv = fmaf(rw, ssc, ssh) > 0.f ? sx[pos] : 0.f;
+                q1 += dzv;
+                q2 = fmaf(dzv, (rw - mu) * is, q2);
+            }
+        }
+        q1 = row16_sum(q1);
+        q2 = row16_sum(q2);
+        if (t16 == 0) {
+            a.sums.partial[((size_t)n * 2 + 0) * a.c + c] = q1;
+            a.sums.partial[((size_t)n * 2 + 1) * a.c + c] = q2;
+        }
+    }
+}
+
+static bool dscnn_dw_dgrad_rows_covers(const DsDwBwdArgs& a) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return a.sh == 1 && a.sw == 1 && a.pad_t == 1 && a.pad_l == 1 && a.h_in == 13 && a.w_in == 5 && a.oh == 13 && a.ow == 5 && a.ppi == a.ppo &&
+           a.ppo == 13 * 5 + 2 * kHalo && a.planes % 16 == 0 && a.planes / 16 < (int64_t)1 << 27 && a.c >= 16 && !a.fly.da &&
+           al(a.dz) && al(a.dx) && (!a.sums.partial || al(a.sums.raw)) && tune_get(TCR_TUNE_DW_DGRAD) != 1;
+}
+
 bool dscnn_dw_dgrad_lds_covers(int h_in, int w_in, int pad_t, int pad_l) {
     return (size_t)16 * (h_in + 2) * (w_in + 2) * sizeof(float) <= 64 * 1024 && pad_t <= 2 && pad_l <= 2;
 }
 
 int launch_dscnn_dw_dgrad(const DsDwBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)16 * (a.h_in + 2) * (a.w_in + 2) * sizeof(float);
+    if (dscnn_dw_dgrad_rows_covers(a)) {
+        hipLaunchKernelGGL((dscnn_dw_dgrad_rows_kernel<13, 5>), dim3((unsigned)(a.planes / 16)), dim3(256), (size_t)3 * 16 * a.ppo * sizeof(float), s, a);
+        return check_launch("dscnn_dw_dgrad_rows_kernel");
+    }
     if (dscnn_dw_dgrad_lds_covers(a.h_in, a.w_in, a.pad_t, a.pad_l)) {
         const dim3 lgrid((unsigned)ceil_div64(a.planes, 16));
         if (a.sh == 1 && a.sw == 1) hipLaunchKernelGGL((dscnn_dw_dgrad_lds_kernel<1, 1>), lgrid, dim3(256), lds, s, a);
@@ -217,6 +327,98 @@ __global__ __launch_bounds__(256) void dscnn_dw_wgrad_kernel(const DsDwWgradArgs
     }
 }
 
+// The stride-1 units on 13 x 5 maps (four of five): a WAVE owns four consecutive channels -- per utterance their x planes and their dz
+// planes are two contiguous blocks of 4 x Pp floats, fetched as 73 float4 each (two coalesced loads per lane and block, the next
+// utterance's in flight while this one is multiplied) into wave-private LDS; lane (plane, h) then takes map row h of dz against the three
+// x rows around it: 20 LDS reads and 45 fmaf per lane and utterance.  (The kernel above issues nine predicated gathers per element and
+// ran at 2.1 TB/s.)  The 13 row lanes of a plane meet in LDS in a fixed order; chunk slabs as above.
+template <int H, int W>
+__global__ __launch_bounds__(256) void dscnn_dw_wgrad_rows_kernel(const DsDwWgradArgs a) {
+    constexpr int NPL = 4, P = H * W, PP = P + 2 * kHalo, BLK = NPL * PP, N4 = BLK / 4;
+    static_assert(NPL * H <= 64 && BLK % 4 == 0 && N4 > 64 && N4 <= 128 && 64 * 9 <= 2 * BLK, "wave geometry");
+    __shared__ __attribute__((aligned(16))) float s_w[4][2 * BLK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.y * 4 + wave) * NPL;
+    if (c0 >= a.c) return;                                      // (no workgroup barrier below)
+    float* sx = s_w[wave];
+    float* sd = sx + BLK;
+    const int n0 = blockIdx.x * a.utt_per_block;
+    const int cnt = min(a.utt_per_block, a.batch - n0);
+    const int pl = lane / H, h = lane - pl * H;
+    const bool act = pl < NPL;
+    const int c = c0 + (act ? pl : 0);
+    const bool aff = a.x_scale != nullptr;
+    const float xsc = aff ? a.x_scale[c] : 1.0f, xsf = aff ? a.x_shift[c] : 0.f;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    const bool two = lane + 64 < N4;
+    const int l2 = two ? lane + 64 : lane;
+    f32x4 x0, x1, d0, d1;
+    {
+        const size_t off = ((size_t)n0 * a.c + c0) * PP;
+        const f32x4* xb = reinterpret_cast<const f32x4*>(a.x + off);
+        const f32x4* db = reinterpret_cast<const f32x4*>(a.dz + off);
+        x0 = xb[lane]; x1 = xb[l2]; d0 = db[lane]; d1 = db[l2];
+    }
+    for (int i = 0; i < cnt; ++i) {
+        wave_sync();                                            // (the previous utterance's reads are done)
+        reinterpret_cast<f32x4*>(sx)[lane] = x0;
+        reinterpret_cast<f32x4*>(sd)[lane] = d0;
+        if (two) { reinterpret_cast<f32x4*>(sx)[lane + 64] = x1; reinterpret_cast<f32x4*>(sd)[lane + 64] = d1; }
+        wave_sync();
+        if (i + 1 < cnt) {
+            const size_t off = ((size_t)(n0 + i + 1) * a.c + c0) * PP;
+            const f32x4* xb = reinterpret_cast<const f32x4*>(a.x + off);
+            const f32x4* db = reinterpret_cast<const f32x4*>(a.dz + off);
+            x0 = xb[lane]; x1 = xb[l2]; d0 = db[lane]; d1 = db[l2];
+        }
+        if (act) {
+            float xin[3][W + 2], g[W];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {                    // x row h + rr - 1 (tap row di = rr), zero outside the map
+                const int hh = h + rr - 1;
+                const bool hv = hh >= 0 && hh < H;
+                const float* src = sx + pl * PP + kHalo + (hv ? hh : h) * W;
+                xin[rr][0] = 0.f; xin[rr][W + 1] = 0.f;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    float v = src[w];
+                    if (aff) v = fmaxf(fmaf(v, xsc, xsf), 0.f);
+                    xin[rr][w + 1] = hv ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w) g[w] = sd[pl * PP + kHalo + h * W + w];
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                    for (int w = 0; w < W; ++w) acc[di * 3 + dj] = fmaf(xin[di][w + dj], g[w], acc[di * 3 + dj]);   // x[h + di - 1][w + dj - 1] dz[h][w]
+        }
+    }
+    wave_sync();
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sx[lane * 9 + k] = acc[k];
+    }
+    wave_sync();
+    if (lane < NPL * 9) {
+        const int p2 = lane / 9, k = lane - p2 * 9;
+        float v = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) v += sx[(p2 * H + hh) * 9 + k];
+        a.partial[((size_t)blockIdx.x * 9 + k) * a.c + c0 + p2] = v;
+    }
+}
+
+static bool dscnn_dw_wgrad_rows_covers(const DsDwWgradArgs& a) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return a.sh == 1 && a.sw == 1 && a.pad_t == 1 && a.pad_l == 1 && a.h_in == 13 && a.w_in == 5 && a.oh == 13 && a.ow == 5 && a.ppi == a.ppo &&
+           a.ppo == 13 * 5 + 2 * kHalo && a.c % 4 == 0 && !a.fly.da && al(a.x) && al(a.dz) && tune_get(TCR_TUNE_DW_WGRAD) != 1;
+}
+
 static int dw_wgrad_chunks(int batch) {
     int n = ceil_div(batch, 32);
     if (n > 128) n = 128;
@@ -227,9 +429,15 @@ size_t dscnn_dw_wgrad_partial_floats(int batch, int c) { return (size_t)dw_wgrad
 
 int launch_dscnn_dw_wgrad(DsDwWgradArgs a, float* dw, hipStream_t s) {
     a.utt_per_block = ceil_div(a.batch, dw_wgrad_chunks(a.batch));
-    const dim3 grid(ceil_div(a.batch, a.utt_per_block), ceil_div(a.c, 4));
-    hipLaunchKernelGGL(dscnn_dw_wgrad_kernel, grid, dim3(256), 0, s, a);
-    TCR_TRY(check_launch("dscnn_dw_wgrad_kernel"));
+    dim3 grid(ceil_div(a.batch, a.utt_per_block), ceil_div(a.c, 4));
+    if (dscnn_dw_wgrad_rows_covers(a)) {
+        grid.y = ceil_div(a.c, 16);
+        hipLaunchKernelGGL((dscnn_dw_wgrad_rows_kernel<13, 5>), grid, dim3(256), 0, s, a);
+        TCR_TRY(check_launch("dscnn_dw_wgrad_rows_kernel"));
+    } else {
+        hipLaunchKernelGGL(dscnn_dw_wgrad_kernel, grid, dim3(256), 0, s, a);
+        TCR_TRY(check_launch("dscnn_dw_wgrad_kernel"));
+    }
     // dw[tap][c] = sum_chunk partial[chunk][tap][c]: the reduction kernel of mfma.hip with k = 9 taps, Cin = 1, Cout = C
     return launch_wgrad_reduce(a.partial, dw, (int)grid.x, 9, 1, a.c, 1, a.c, a.c, 0, s);
 }

@@ -523,10 +523,11 @@ def check_dscnn_staged_equals_unstaged(lib, size, batch):
         assert torch.equal(a, b), f"DS-CNN-{size}: staged {what} differ from the unstaged run"
 
 
-def check_dscnn_pointwise_wgrad_kernels(lib, size, batch):
+def check_dscnn_pointwise_wgrad_kernels(lib, size, batch, knob_id=25):
     """The DMA-staged pointwise filter gradient (TCR_TUNE_PW_WGRAD = 1: global_load_lds into two LDS buffers, three split-K wave groups)
     against the register-staged default: the same products, another summation order (split over wave groups and chunk counts) --
-    every gradient tensor agrees to rounding, everything that does not pass through the kernel bitwise."""
+    every gradient tensor agrees to rounding, everything that does not pass through the kernel bitwise.
+    knob_id 31 (TCR_TUNE_DW_WGRAD): the depthwise filter gradient by the row kernel (default) against the gather kernel, likewise."""
     from oracle import dscnn_ref as D
     p, s = D.init_params(D.net_def(size), seed=4)
     fe = make_frontend(lib, 640, 320, num_mfccs=10)
@@ -537,13 +538,13 @@ def check_dscnn_pointwise_wgrad_kernels(lib, size, batch):
     grads = []
     try:
         for knob in (0, 1):
-            lib.tcr_tune(25, knob)
+            lib.tcr_tune(knob_id, knob)
             net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
             sd = dict(p); sd.update(s); net.load_state_dict(sd)
             net.forward_train(feat, labels)
             grads.append(net.backward().clone())
     finally:
-        lib.tcr_tune(25, 0)
+        lib.tcr_tune(knob_id, 0)
     a, b = grads
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     scale = float(a.abs().max())
@@ -552,9 +553,13 @@ def check_dscnn_pointwise_wgrad_kernels(lib, size, batch):
     assert not torch.equal(a, b)                # (the knob did select another kernel)
 
 
-def check_dscnn_pointwise_geometries(lib, size, batch):
+def check_dscnn_pointwise_geometries(lib, size, batch, knob_id=28):
     """The wide pointwise conv kernel built for <= 128 registers (four waves per SIMD; default) against the unconstrained build of
-    rounds 3-4 (TCR_TUNE_PW_POS = 1): the same instructions in another register allocation -- eval logits and training gradients bitwise."""
+    rounds 3-4 (TCR_TUNE_PW_POS = 1): the same instructions in another register allocation -- eval logits and training gradients bitwise.
+    knob_id 29 (TCR_TUNE_BN_APPLY): the BN-backward apply pass with four float4 per thread and its coefficients in LDS (default) against
+    the one-float4-per-thread kernel -- the same expression per element, gradients bitwise.  knob_id 30 (TCR_TUNE_DW_DGRAD): the depthwise
+    data gradient of the stride-1 units by the row kernel (default) against the padded-image kernel -- same fmaf chain per output, same
+    order of the backward sums, gradients bitwise.  knob_id 32 (TCR_TUNE_DW_FWD): the forward depthwise conv likewise (eval logits too)."""
     from oracle import dscnn_ref as D
     p, s = D.init_params(D.net_def(size), seed=4)
     fe = make_frontend(lib, 640, 320, num_mfccs=10)
@@ -565,14 +570,14 @@ def check_dscnn_pointwise_geometries(lib, size, batch):
     evals, grads = [], []
     try:
         for knob in (0, 1):
-            lib.tcr_tune(28, knob)
+            lib.tcr_tune(knob_id, knob)
             net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
             sd = dict(p); sd.update(s); net.load_state_dict(sd)
             evals.append(net.forward_infer(feat)[0].clone())
             net.forward_train(feat, labels)
             grads.append(net.backward().clone())
     finally:
-        lib.tcr_tune(28, 0)
+        lib.tcr_tune(knob_id, 0)
     assert torch.equal(evals[0], evals[1]), float((evals[0] - evals[1]).abs().max())
     assert torch.isfinite(grads[0]).all() and torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
 

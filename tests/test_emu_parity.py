@@ -218,6 +218,22 @@ def test_dscnn_pointwise_kernel_geometries_agree(emu_lib):
     Cm.check_dscnn_pointwise_geometries(emu_lib, "M", 3)
 
 
+def test_dscnn_bn_backward_apply_kernels_agree(emu_lib):
+    Cm.check_dscnn_pointwise_geometries(emu_lib, "M", 3, knob_id=29)
+
+
+def test_dscnn_depthwise_forward_kernels_agree(emu_lib):
+    Cm.check_dscnn_pointwise_geometries(emu_lib, "M", 4, knob_id=32)        # (whole blocks of 16 planes: 4 x 172)
+
+
+def test_dscnn_depthwise_filter_gradient_kernels_agree(emu_lib):
+    Cm.check_dscnn_pointwise_wgrad_kernels(emu_lib, "M", 3, knob_id=31)
+
+
+def test_dscnn_depthwise_data_gradient_kernels_agree(emu_lib):
+    Cm.check_dscnn_pointwise_geometries(emu_lib, "M", 4, knob_id=30)        # (the row kernel takes whole blocks of 16 planes: 4 x 172)
+
+
 def test_dscnn_lazy_training_path_equals_materialised(emu_lib):
     Cm.check_dscnn_lazy_equals_materialised(emu_lib, "M", 2)
 
