@@ -613,6 +613,108 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_rows_kernel(const DsDwArg
     }
 }
 
+// The stride-2 layer (25 x 10 -> 13 x 5, TF SAME: one zero row above, one zero column right), same scheme: the x block of 16 planes
+// (16 x 258 floats, contiguous) through LDS, lane (plane, oh) computes output row oh from x rows 2 oh - 1 .. 2 oh + 1 (8-byte LDS reads),
+// the y block leaves as float4.  Bitwise the image kernel's outputs and statistics.
+template <int HI, int WI, int HO, int WO>
+__global__ __launch_bounds__(256) void dscnn_depthwise_rows_s2_kernel(const DsDwArgs a) {
+    constexpr int NPL = 16, PI = HI * WI, PO = HO * WO, PPI = PI + 2 * kHalo, PPO = PO + 2 * kHalo;
+    static_assert(NPL * HO <= 256 && WI % 2 == 0 && (PPI % 2) == 0 && (NPL * PPI) % 4 == 0 && (NPL * PPO) % 4 == 0 && WI == 2 * WO && HI == 2 * HO - 1, "geometry");
+    constexpr int NX4 = NPL * PPI / 4, NY4 = NPL * PPO / 4;
+    float* s_x = reinterpret_cast<float*>(dyn_lds());
+    float* s_y = s_x + NPL * PPI;
+    const int tid = threadIdx.x;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + (size_t)blockIdx.x * (NPL * PPI));
+    constexpr int XPT = (NX4 + 255) / 256;
+    f32x4 xv[XPT];
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) xv[j] = x4[min(tid + 256 * j, NX4 - 1)];
+    const int row0 = blockIdx.x * NPL;
+    const int n0 = row0 / a.c, c0 = row0 - n0 * a.c;
+    const int pl3 = tid / HO, oh = tid - pl3 * HO;
+    const bool act3 = pl3 < NPL;
+    int c3 = c0 + (act3 ? pl3 : 0);
+    if (c3 >= a.c) c3 -= a.c;
+    float wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = a.w[(size_t)k * a.c + c3];
+    const bool aff = a.in_scale != nullptr;
+    const float isc = aff ? a.in_scale[c3] : 1.0f, isf = aff ? a.in_shift[c3] : 0.f;
+    const float sc = a.scale ? a.scale[c3] : 1.0f, sh = a.shift[c3];
+#pragma unroll
+    for (int j = 0; j < XPT; ++j)
+        if (tid + 256 * j < NX4) reinterpret_cast<f32x4*>(s_x)[tid + 256 * j] = xv[j];
+    if (tid < NPL * 2 * kHalo) {
+        const int pl = tid / (2 * kHalo), k = tid - pl * (2 * kHalo);
+        s_y[pl * PPO + (k < kHalo ? k : PO + k)] = 0.f;
+    }
+    __syncthreads();
+    if (act3) {
+        float in[3][WI + 1];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {                        // x row 2 oh + rr - 1 (tap row di = rr)
+            const int hh = 2 * oh + rr - 1;
+            const bool hv = hh >= 0 && hh < HI;
+            const float2* src = reinterpret_cast<const float2*>(s_x + pl3 * PPI + kHalo + (hv ? hh : 0) * WI);
+            in[rr][WI] = 0.f;                                   // (the zero column right of the map)
+#pragma unroll
+            for (int w2 = 0; w2 < WI / 2; ++w2) {
+                const float2 t = src[w2];
+                float v0 = t.x, v1 = t.y;
+                if (aff) { v0 = fmaxf(fmaf(v0, isc, isf), 0.f); v1 = fmaxf(fmaf(v1, isc, isf), 0.f); }
+                in[rr][2 * w2] = hv ? v0 : 0.f;
+                in[rr][2 * w2 + 1] = hv ? v1 : 0.f;
+            }
+        }
+        float* dst = s_y + pl3 * PPO + kHalo + oh * WO;
+#pragma unroll
+        for (int w = 0; w < WO; ++w) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) sacc = fmaf(wt[di * 3 + dj], in[di][2 * w + dj], sacc);      // x[2 oh + di - 1][2 ow + dj]
+            float o = fmaf(sacc, sc, sh);
+            if (a.relu) o = fmaxf(o, 0.f);
+            dst[w] = o;
+        }
+    }
+    __syncthreads();
+    f32x4* y4 = reinterpret_cast<f32x4*>(a.y + (size_t)blockIdx.x * (NPL * PPO));
+    y4[tid] = reinterpret_cast<const f32x4*>(s_y)[tid];
+    if (tid + 256 < NY4) y4[tid + 256] = reinterpret_cast<const f32x4*>(s_y)[tid + 256];
+    if (a.sums.partial) {
+        const int plane = tid >> 4, t16 = tid & 15;
+        int c = c0 + plane, n = n0;
+        if (c >= a.c) { c -= a.c; ++n; }
+        const float* sy = s_y + plane * PPO + kHalo;
+        float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < (PO + 15) / 16; ++i) {
+            const int pos = t16 + 16 * i;
+            if (pos < PO) {
+                const float o = sy[pos];
+                q1 += o;
+                q2 = fmaf(o, o, q2);
+            }
+        }
+        q1 = row16_sum(q1);
+        q2 = row16_sum(q2);
+        if (t16 == 0) {
+            a.sums.partial[((size_t)n * 2 + 0) * a.c + c] = q1;
+            a.sums.partial[((size_t)n * 2 + 1) * a.c + c] = q2;
+        }
+    }
+}
+
+static bool dscnn_depthwise_rows_s2_covers(const DsDwArgs& d, int batch) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int64_t planes = (int64_t)batch * d.c;
+    return d.sh == 2 && d.sw == 2 && d.pad_t == 1 && d.pad_l == 0 && d.h_in == 25 && d.w_in == 10 && d.oh == 13 && d.ow == 5 &&
+           d.ppi == 25 * 10 + 2 * kHalo && d.ppo == 13 * 5 + 2 * kHalo && planes % 16 == 0 && planes / 16 < (int64_t)1 << 27 && d.c >= 16 &&
+           al(d.x) && al(d.y) && tune_get(TCR_TUNE_DW_FWD) != 1;
+}
+
 static bool dscnn_depthwise_rows_covers(const DsDwArgs& d, int batch) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int64_t planes = (int64_t)batch * d.c;
@@ -625,6 +727,11 @@ static int launch_dscnn_depthwise(const DsDwArgs& d, int batch, hipStream_t s) {
     if (dscnn_depthwise_rows_covers(d, batch)) {
         hipLaunchKernelGGL((dscnn_depthwise_rows_kernel<13, 5>), dim3((unsigned)((int64_t)batch * d.c / 16)), dim3(256), (size_t)2 * 16 * d.ppo * sizeof(float), s, d);
         return check_launch("dscnn_depthwise_rows_kernel");
+    }
+    if (dscnn_depthwise_rows_s2_covers(d, batch)) {
+        hipLaunchKernelGGL((dscnn_depthwise_rows_s2_kernel<25, 10, 13, 5>), dim3((unsigned)((int64_t)batch * d.c / 16)), dim3(256),
+                           (size_t)16 * (d.ppi + d.ppo) * sizeof(float), s, d);
+        return check_launch("dscnn_depthwise_rows_s2_kernel");
     }
     const int rows = batch * d.c;
     const int img_r = (d.oh - 1) * d.sh + 3, img_c = (d.ow - 1) * d.sw + 3;

@@ -245,6 +245,112 @@ __global__ __launch_bounds__(256) void dscnn_dw_dgrad_rows_kernel(const DsDwBwdA
     }
 }
 
+// The stride-2 unit (dx on the 25 x 10 map from dz on 13 x 5; TF SAME: pad_t 1, pad_l 0), same scheme with 8 planes per workgroup: the dz
+// block (8 x 73 floats) and the raw block of the unit below (8 x 258) through LDS, lane (plane, h) computes the ten dx of map row h from
+// the one or two dz rows that reach it (taps with (h + 1 - di) even; columns (w - dj) even: the taps that meet a zero of the upsampled
+// image in the kernel above are left out -- fmaf(w, 0, s) = s), the dx block leaves as float4; sums in the image kernel's order.
+template <int HI, int WI, int HO, int WO>
+__global__ __launch_bounds__(256) void dscnn_dw_dgrad_rows_s2_kernel(const DsDwBwdArgs a) {
+    constexpr int NPL = 8, PI = HI * WI, PO = HO * WO, PPI = PI + 2 * kHalo, PPO = PO + 2 * kHalo;
+    static_assert(NPL * HI <= 256 && (NPL * PPI) % 4 == 0 && (NPL * PPO) % 4 == 0 && WI == 2 * WO && HI == 2 * HO - 1 && NPL * 16 <= 256, "geometry");
+    constexpr int NX4 = NPL * PPI / 4, NZ4 = NPL * PPO / 4, XPT = (NX4 + 255) / 256;
+    static_assert(NZ4 <= 256, "one dz float4 per thread");
+    float* s_dz = reinterpret_cast<float*>(dyn_lds());
+    float* s_raw = s_dz + NPL * PPO;
+    float* s_dx = s_raw + NPL * PPI;
+    const int tid = threadIdx.x;
+    const bool sums = a.sums.partial != nullptr;
+    const size_t gi = (size_t)blockIdx.x * (NPL * PPI), go = (size_t)blockIdx.x * (NPL * PPO);
+    const f32x4 z0 = reinterpret_cast<const f32x4*>(a.dz + go)[min(tid, NZ4 - 1)];
+    f32x4 rv[XPT];
+    if (sums) {
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) rv[j] = reinterpret_cast<const f32x4*>(a.sums.raw + gi)[min(tid + 256 * j, NX4 - 1)];
+    }
+    const int row0 = blockIdx.x * NPL;
+    const int n0 = row0 / a.c, c0 = row0 - n0 * a.c;
+    const int pl3 = tid / HI, h = tid - pl3 * HI;
+    const bool act3 = pl3 < NPL;
+    int c3 = c0 + (act3 ? pl3 : 0);
+    if (c3 >= a.c) c3 -= a.c;
+    float wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = a.w[(size_t)k * a.c + c3];
+    if (tid < NZ4) reinterpret_cast<f32x4*>(s_dz)[tid] = z0;
+    if (sums) {
+#pragma unroll
+        for (int j = 0; j < XPT; ++j)
+            if (tid + 256 * j < NX4) reinterpret_cast<f32x4*>(s_raw)[tid + 256 * j] = rv[j];
+    }
+    if (tid < NPL * 2 * kHalo) {
+        const int pl = tid / (2 * kHalo), k = tid - pl * (2 * kHalo);
+        s_dx[pl * PPI + (k < kHalo ? k : PI + k)] = 0.f;
+    }
+    __syncthreads();
+    if (act3) {
+        float g[3][WO];
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const int hh = h + 1 - di;
+            const int oh = hh >> 1;
+            const bool hv = hh >= 0 && (hh & 1) == 0 && oh < HO;
+            const float* src = s_dz + pl3 * PPO + kHalo + (hv ? oh : 0) * WO;
+#pragma unroll
+            for (int w = 0; w < WO; ++w) { const float v = src[w]; g[di][w] = hv ? v : 0.f; }
+        }
+        float* dst = s_dx + pl3 * PPI + kHalo + h * WI;
+#pragma unroll
+        for (int w = 0; w < WI; ++w) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int ww = w - dj;                      // (compile-time)
+                    if (ww >= 0 && (ww & 1) == 0 && ww / 2 < WO) sacc = fmaf(wt[di * 3 + dj], g[di][ww / 2], sacc);
+                }
+            dst[w] = sacc;
+        }
+    }
+    __syncthreads();
+    f32x4* dx4 = reinterpret_cast<f32x4*>(a.dx + gi);
+#pragma unroll
+    for (int j = 0; j < XPT; ++j)
+        if (tid + 256 * j < NX4) dx4[tid + 256 * j] = reinterpret_cast<const f32x4*>(s_dx)[tid + 256 * j];
+    if (sums && tid < NPL * 16) {
+        const int plane = tid >> 4, t16 = tid & 15;
+        int c = c0 + plane, n = n0;
+        if (c >= a.c) { c -= a.c; ++n; }
+        const float mu = a.sums.mean[c], is = a.sums.invstd[c], ssc = a.sums.self_scale[c], ssh = a.sums.self_shift[c];
+        const float* sx = s_dx + plane * PPI + kHalo;
+        const float* sr = s_raw + plane * PPI + kHalo;
+        float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < (PI + 15) / 16; ++i) {
+            const int pos = t16 + 16 * i;
+            if (pos < PI) {
+                const float rw = sr[pos];
+                const float dzv = fmaf(rw, ssc, ssh) > 0.f ? sx[pos] : 0.f;
+                q1 += dzv;
+                q2 = fmaf(dzv, (rw - mu) * is, q2);
+            }
+        }
+        q1 = row16_sum(q1);
+        q2 = row16_sum(q2);
+        if (t16 == 0) {
+            a.sums.partial[((size_t)n * 2 + 0) * a.c + c] = q1;
+            a.sums.partial[((size_t)n * 2 + 1) * a.c + c] = q2;
+        }
+    }
+}
+
+static bool dscnn_dw_dgrad_rows_s2_covers(const DsDwBwdArgs& a) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return a.sh == 2 && a.sw == 2 && a.pad_t == 1 && a.pad_l == 0 && a.h_in == 25 && a.w_in == 10 && a.oh == 13 && a.ow == 5 &&
+           a.ppi == 25 * 10 + 2 * kHalo && a.ppo == 13 * 5 + 2 * kHalo && a.planes % 8 == 0 && a.planes / 8 < (int64_t)1 << 27 && a.c >= 8 && !a.fly.da &&
+           al(a.dz) && al(a.dx) && (!a.sums.partial || al(a.sums.raw)) && tune_get(TCR_TUNE_DW_DGRAD) != 1;
+}
+
 static bool dscnn_dw_dgrad_rows_covers(const DsDwBwdArgs& a) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return a.sh == 1 && a.sw == 1 && a.pad_t == 1 && a.pad_l == 1 && a.h_in == 13 && a.w_in == 5 && a.oh == 13 && a.ow == 5 && a.ppi == a.ppo &&
@@ -261,6 +367,10 @@ int launch_dscnn_dw_dgrad(const DsDwBwdArgs& a, hipStream_t s) {
     if (dscnn_dw_dgrad_rows_covers(a)) {
         hipLaunchKernelGGL((dscnn_dw_dgrad_rows_kernel<13, 5>), dim3((unsigned)(a.planes / 16)), dim3(256), (size_t)3 * 16 * a.ppo * sizeof(float), s, a);
         return check_launch("dscnn_dw_dgrad_rows_kernel");
+    }
+    if (dscnn_dw_dgrad_rows_s2_covers(a)) {
+        hipLaunchKernelGGL((dscnn_dw_dgrad_rows_s2_kernel<25, 10, 13, 5>), dim3((unsigned)(a.planes / 8)), dim3(256), (size_t)8 * (a.ppo + 2 * a.ppi) * sizeof(float), s, a);
+        return check_launch("dscnn_dw_dgrad_rows_s2_kernel");
     }
     if (dscnn_dw_dgrad_lds_covers(a.h_in, a.w_in, a.pad_t, a.pad_l)) {
         const dim3 lgrid((unsigned)ceil_div64(a.planes, 16));
@@ -413,6 +523,97 @@ __global__ __launch_bounds__(256) void dscnn_dw_wgrad_rows_kernel(const DsDwWgra
     }
 }
 
+// The stride-2 unit (x on 25 x 10, dz on 13 x 5; pad_t 1, pad_l 0), same scheme: per utterance the wave's four x planes are 258 float4,
+// its four dz planes 73; lane (plane, oh) takes dz row oh against x rows 2 oh - 1 .. 2 oh + 1.
+template <int HI, int WI, int HO, int WO>
+__global__ __launch_bounds__(256) void dscnn_dw_wgrad_rows_s2_kernel(const DsDwWgradArgs a) {
+    constexpr int NPL = 4, PI = HI * WI, PO = HO * WO, PPI = PI + 2 * kHalo, PPO = PO + 2 * kHalo;
+    constexpr int NX4 = NPL * PPI / 4, NZ4 = NPL * PPO / 4, XPT = (NX4 + 63) / 64, ZPT = (NZ4 + 63) / 64;
+    static_assert(NPL * HO <= 64 && (NPL * PPI) % 4 == 0 && (NPL * PPO) % 4 == 0 && WI == 2 * WO && HI == 2 * HO - 1 && (PPI % 2) == 0 && 64 * 9 <= NPL * PPI, "wave geometry");
+    __shared__ __attribute__((aligned(16))) float s_w[4][NPL * (PPI + PPO)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.y * 4 + wave) * NPL;
+    if (c0 >= a.c) return;                                      // (no workgroup barrier below)
+    float* sx = s_w[wave];
+    float* sd = sx + NPL * PPI;
+    const int n0 = blockIdx.x * a.utt_per_block;
+    const int cnt = min(a.utt_per_block, a.batch - n0);
+    const int pl = lane / HO, oh = lane - pl * HO;
+    const bool act = pl < NPL;
+    const int c = c0 + (act ? pl : 0);
+    const bool aff = a.x_scale != nullptr;
+    const float xsc = aff ? a.x_scale[c] : 1.0f, xsf = aff ? a.x_shift[c] : 0.f;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    f32x4 xv[XPT], dv[ZPT];
+    auto fetch = [&](int n) {
+        const f32x4* xb = reinterpret_cast<const f32x4*>(a.x + ((size_t)n * a.c + c0) * PPI);
+        const f32x4* db = reinterpret_cast<const f32x4*>(a.dz + ((size_t)n * a.c + c0) * PPO);
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) xv[j] = xb[min(lane + 64 * j, NX4 - 1)];
+#pragma unroll
+        for (int j = 0; j < ZPT; ++j) dv[j] = db[min(lane + 64 * j, NZ4 - 1)];
+    };
+    fetch(n0);
+    for (int i = 0; i < cnt; ++i) {
+        wave_sync();                                            // (the previous utterance's reads are done)
+#pragma unroll
+        for (int j = 0; j < XPT; ++j)
+            if (lane + 64 * j < NX4) reinterpret_cast<f32x4*>(sx)[lane + 64 * j] = xv[j];
+#pragma unroll
+        for (int j = 0; j < ZPT; ++j)
+            if (lane + 64 * j < NZ4) reinterpret_cast<f32x4*>(sd)[lane + 64 * j] = dv[j];
+        wave_sync();
+        if (i + 1 < cnt) fetch(n0 + i + 1);
+        if (act) {
+            float xin[3][WI + 1], g[WO];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {                    // x row 2 oh + rr - 1 (tap row di = rr), zero outside the map
+                const int hh = 2 * oh + rr - 1;
+                const bool hv = hh >= 0 && hh < HI;
+                const float2* src = reinterpret_cast<const float2*>(sx + pl * PPI + kHalo + (hv ? hh : 0) * WI);
+                xin[rr][WI] = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WI / 2; ++w2) {
+                    const float2 t = src[w2];
+                    float v0 = t.x, v1 = t.y;
+                    if (aff) { v0 = fmaxf(fmaf(v0, xsc, xsf), 0.f); v1 = fmaxf(fmaf(v1, xsc, xsf), 0.f); }
+                    xin[rr][2 * w2] = hv ? v0 : 0.f;
+                    xin[rr][2 * w2 + 1] = hv ? v1 : 0.f;
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < WO; ++w) g[w] = sd[pl * PPO + kHalo + oh * WO + w];
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                    for (int w = 0; w < WO; ++w) acc[di * 3 + dj] = fmaf(xin[di][2 * w + dj], g[w], acc[di * 3 + dj]);   // x[2 oh + di - 1][2 ow + dj] dz[oh][ow]
+        }
+    }
+    wave_sync();
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sx[lane * 9 + k] = acc[k];
+    }
+    wave_sync();
+    if (lane < NPL * 9) {
+        const int p2 = lane / 9, k = lane - p2 * 9;
+        float v = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < HO; ++hh) v += sx[(p2 * HO + hh) * 9 + k];
+        a.partial[((size_t)blockIdx.x * 9 + k) * a.c + c0 + p2] = v;
+    }
+}
+
+static bool dscnn_dw_wgrad_rows_s2_covers(const DsDwWgradArgs& a) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return a.sh == 2 && a.sw == 2 && a.pad_t == 1 && a.pad_l == 0 && a.h_in == 25 && a.w_in == 10 && a.oh == 13 && a.ow == 5 &&
+           a.ppi == 25 * 10 + 2 * kHalo && a.ppo == 13 * 5 + 2 * kHalo && a.c % 4 == 0 && !a.fly.da && al(a.x) && al(a.dz) && tune_get(TCR_TUNE_DW_WGRAD) != 1;
+}
+
 static bool dscnn_dw_wgrad_rows_covers(const DsDwWgradArgs& a) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return a.sh == 1 && a.sw == 1 && a.pad_t == 1 && a.pad_l == 1 && a.h_in == 13 && a.w_in == 5 && a.oh == 13 && a.ow == 5 && a.ppi == a.ppo &&
@@ -434,6 +635,10 @@ int launch_dscnn_dw_wgrad(DsDwWgradArgs a, float* dw, hipStream_t s) {
         grid.y = ceil_div(a.c, 16);
         hipLaunchKernelGGL((dscnn_dw_wgrad_rows_kernel<13, 5>), grid, dim3(256), 0, s, a);
         TCR_TRY(check_launch("dscnn_dw_wgrad_rows_kernel"));
+    } else if (dscnn_dw_wgrad_rows_s2_covers(a)) {
+        grid.y = ceil_div(a.c, 16);
+        hipLaunchKernelGGL((dscnn_dw_wgrad_rows_s2_kernel<25, 10, 13, 5>), grid, dim3(256), 0, s, a);
+        TCR_TRY(check_launch("dscnn_dw_wgrad_rows_s2_kernel"));
     } else {
         hipLaunchKernelGGL(dscnn_dw_wgrad_kernel, grid, dim3(256), 0, s, a);
         TCR_TRY(check_launch("dscnn_dw_wgrad_kernel"));
