@@ -426,7 +426,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_LAZY_STAGE = 22, /* lazy backward: 0 the group's rows staged with 16-byte loads (default), 1 a dword gather per interior element (bitwise the same) */
        TCR_TUNE_FE_KERNEL = 23,  /* packed-FP32 front-end: 0 the three-waves-per-SIMD kernel (frontend_pk3.hip: wave-local LDS regions, <= 168 registers; default), 1 the two-waves kernel of rounds 2-4 (frontend_pk.hip; also what filterbanks with more work items than the unrolled trips fall back to). Bitwise the same features. */
        TCR_TUNE_FE_STAGGER = 24, /* three-waves front-end: one-off start-up delay of (workgroup generation * 4 + wave) * value * 64 cycles that de-phases the twelve waves of a CU (0: none) */
-       TCR_TUNE_PW_WGRAD = 25,   /* wide pointwise (DS-CNN 172 / 276 channels) filter gradient: 0 the register-staged kernel (two 4-wave workgroups per CU; default), 1 the DMA-staged kernel (global_load_lds into two LDS buffers, one 12-wave workgroup per CU, three split-K wave groups; measured 2 % slower) */
+       TCR_TUNE_PW_WGRAD = 25,   /* wide pointwise (DS-CNN 172 / 276 channels) filter gradient: 0 the register-staged kernel (two 4-wave workgroups per CU; on 13 x 5 maps its unrolled form with fixed staging roles, round 5; default), 1 the DMA-staged kernel (global_load_lds into two LDS buffers, one 12-wave workgroup per CU, three split-K wave groups; measured 2 % slower), 2 the register-staged kernel's run-time-shape form on every map (rounds 4-5; bitwise the default) */
        TCR_TUNE_DEPLOY_F32 = 26, /* deploy-path MFCC (method 2): 0 the float64 kernel (one workgroup per frame; TF's ops compute in double; default), 1 the float32 throughput kernels with the op's filterbank / log floor (rounds 3-4: up to 0.5 off on noise-free tones, where the empty bands are pure round-off) */
        TCR_TUNE_NET_SMALL = 27,  /* eval network, TCResNet8-1.0 at 49 frames, batches of <= 64 utterances: 0 the small-batch kernel (one utterance per 8-wave workgroup, each phase's weights DMA-copied into LDS one phase ahead; default), 1 the throughput kernel at one utterance per group (rounds 2-4).  Bitwise the same outputs. */
        TCR_TUNE_PW_POS = 28,     /* wide pointwise convs (DS-CNN-L, 276 channels; forward, data gradient): 0 the nine-tile kernel built for <= 128 registers = four waves per SIMD (default since round 5), 1 the unconstrained build of rounds 3-4 (92 VGPRs + 72 AGPRs, three waves per SIMD).  Bitwise the same results. */

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """DS-CNN-L / M training step with one tuning knob at 0 (default) and at 1, alternating in one process.
-usage: ab_dscnn_knob.py KNOB [KNOB ...]   (e.g. 29 = TCR_TUNE_BN_APPLY, 30 = TCR_TUNE_DW_DGRAD); the last line sets all listed knobs to 1."""
+usage: ab_dscnn_knob.py KNOB[=VALUE] [KNOB[=VALUE] ...]   (e.g. 29 = TCR_TUNE_BN_APPLY, 30 = TCR_TUNE_DW_DGRAD, 15=4; VALUE defaults to 1);
+the last arm sets all listed knobs."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +9,9 @@ import torch
 import tcresnet_amd as T
 from bench import synth_batch
 
-knobs = [int(x) for x in sys.argv[1:]] or [29, 30]
+spec = [(int(x.split("=")[0]), int(x.split("=")[1]) if "=" in x else 1) for x in sys.argv[1:]] or [(29, 1), (30, 1)]
+knobs = [k for k, _ in spec]
+val = dict(spec)
 dev = torch.device("cuda")
 lib = T._lib.get()
 B = 4096
@@ -33,7 +36,7 @@ for size in os.environ.get("AB_SIZES", "L,M").split(","):
     arms = [()] + [(k,) for k in knobs] + ([tuple(knobs)] if len(knobs) > 1 else [])
     for rnd in range(2):
         for arm in arms:
-            for k in knobs: lib.tcr_tune(k, 1 if k in arm else 0)
+            for k in knobs: lib.tcr_tune(k, val[k] if k in arm else 0)
             ds = T.DSCNN(size, fe.n_frames, 10, 12, device=dev); ds.init_xavier(0)
             def step():
                 st[0] += 1

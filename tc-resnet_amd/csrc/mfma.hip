@@ -1405,6 +1405,110 @@ __global__ __launch_bounds__(256) void pw_wgrad_lds_kernel(const PwWgradArgs a) 
             }
 }
 
+// The same kernel for a compile-time map size (DS-CNN: P = 65 positions, rows of 73 floats), round 5.  The run-time kernel above spends 4.1
+// VALU instructions per MFMA -- six address adds and six register moves per 4-position step (a rolled loop with a one-step lookahead), the
+// x-affine's compare / select in every step, and per staged float4 a pointer select, a clamp and a branch pair around the LDS store --
+// and on this chip the VALU and matrix instructions of a SIMD's waves share its issue: the kernel's time fits MFMA cycles + 4 x VALU
+// instructions, not their maximum.  Here the 17 steps are unrolled (LDS reads at immediate offsets, no moves, the tail mask in the last
+// step only) and the staging roles are fixed per thread: float4 i < NI of a thread belong to the x block, the rest to the dz block (each
+// block owns NI x 256 float4 of LDS; a thread's clamped duplicates of a block's last float4 are stored where that float4 goes anyway),
+// so a staged float4 costs its load and its store.  Same MFMA order per accumulator: bitwise the kernel above.
+template <int P, bool XAFF>
+__global__ __launch_bounds__(256) void pw_wgrad_lds_p_kernel(const PwWgradArgs a) {
+    constexpr int BT = 96, PP = P + 2 * kHalo, KS = (P + 3) / 4;
+    constexpr int B4 = BT * PP / 4, NI = (B4 + 255) / 256, SLOT = NI * 256;         // float4 per block / per thread and block / LDS float4 per block
+    static_assert((BT * PP) % 4 == 0 && KS * 4 <= P + kHalo, "rows end on a float4; the last step reads into the halo only");
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4* xs4 = reinterpret_cast<f4*>(dyn_lds());
+    f4* ds4 = xs4 + SLOT;
+    const float* xs = reinterpret_cast<const float*>(xs4);
+    const float* ds = reinterpret_cast<const float*>(ds4);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nb = a.nby * a.nbz;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int chunk = (jj / nb) * 8 + xcd, blk = jj % nb;       // (XCD-aware map: see pw_wgrad_lds_kernel)
+    if (chunk >= a.nchunk) return;
+    const int ci0 = (blk % a.nby) * BT, co0 = (blk / a.nby) * BT;
+    const int xrows = min(BT, a.cin - ci0), drows = min(BT, a.cout - co0);
+    const int xv = xrows * PP / 4, dv = drows * PP / 4;         // (host checks divisibility)
+#pragma unroll
+    for (int i = 0; i < 2 * NI; ++i) xs4[tid + 256 * i] = (f4){0.f, 0.f, 0.f, 0.f};     // rows past the channel count stay zero
+    const int wm = (wave >> 1) * 3, wn = (wave & 1) * 3;
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int ao[3], bo[3];
+    float xsc[3], xsf[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        ao[m] = ((wm + m) * 16 + r) * PP + kHalo + q;
+        bo[m] = ((wn + m) * 16 + r) * PP + kHalo + q;
+        const int ci = ci0 + (wm + m) * 16 + r;
+        xsc[m] = (XAFF && ci < a.cin) ? a.x_scale[ci] : 0.f;    // (rows past Cin: relu(0 * 0 + 0) = 0)
+        xsf[m] = (XAFF && ci < a.cin) ? a.x_shift[ci] : 0.f;
+    }
+    int xo[NI], dof[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { xo[i] = min(tid + 256 * i, xv - 1); dof[i] = min(tid + 256 * i, dv - 1); }
+    const int n_begin = chunk * a.utt_per_block;
+    const int n_end = min(n_begin + a.utt_per_block, a.batch);
+    f4 px[NI], pd[NI];
+    auto prefetch = [&](int n) {
+        const f4* xg4 = reinterpret_cast<const f4*>(a.x + ((size_t)n * a.cin + ci0) * PP);
+        const f4* dg4 = reinterpret_cast<const f4*>(a.dz + ((size_t)n * a.cout + co0) * PP);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { px[i] = xg4[xo[i]]; pd[i] = dg4[dof[i]]; }
+    };
+    if (n_begin < n_end) prefetch(n_begin);
+    for (int n = n_begin; n < n_end; ++n) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { xs4[xo[i]] = px[i]; ds4[dof[i]] = pd[i]; }
+        __syncthreads();
+        if (n + 1 < n_end) prefetch(n + 1);
+        float af[3], bf[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { af[m] = xs[ao[m]]; bf[m] = ds[bo[m]]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float an[3], bn[3];
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { an[m] = xs[ao[m] + 4 * (ks + 1)]; bn[m] = ds[bo[m] + 4 * (ks + 1)]; }
+            }
+            if (XAFF) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    af[m] = fmaxf(fmaf(af[m], xsc[m], xsf[m]), 0.f);
+                    if (4 * ks + 3 >= P) af[m] = 4 * ks + q < P ? af[m] : 0.f;     // (the last step's lanes past the map)
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 3; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nn], acc[m][nn], 0, 0, 0);
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { af[m] = an[m]; bf[m] = bn[m]; }
+            }
+        }
+    }
+    float* dst = a.partial + (size_t)chunk * a.cin_pad * a.cout_pad;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 3; ++nn)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ci = ci0 + (wm + m) * 16 + q * 4 + reg, co = co0 + (wn + nn) * 16 + r;
+                if (ci < a.cin_pad && co < a.cout_pad) dst[(size_t)ci * a.cout_pad + co] = acc[m][nn][reg];
+            }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The same filter gradient with the operand blocks copied global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers,
 // no ds_write pass) into TWO buffers: while the twelve waves of a workgroup multiply utterance n out of one buffer, utterance n + 1
@@ -1592,6 +1696,22 @@ static int launch_pw_wgrad_lds(const float* x, const float* dy, float* dw, float
     }
     a.nchunk = ceil_div(batch, a.utt_per_block); a.nby = ceil_div(cin, 96); a.nbz = ceil_div(cout, 96);
     const dim3 grid(ceil_div(a.nchunk, 8) * 8 * a.nby * a.nbz);
+    if (tout == 65 && tpi == 65 + 2 * kHalo && tune_get(TCR_TUNE_PW_WGRAD) != 2) {      // DS-CNN's 13 x 5 maps: the unrolled kernel
+        const size_t ldsp = (size_t)2 * 7 * 256 * 16;
+        static bool configured_p = false;
+        if (!configured_p) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_lds_p_kernel<65, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_lds_p_kernel<65, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp) != hipSuccess) {
+                set_error("pw_wgrad_lds_p_kernel: cannot reserve %zu bytes of LDS", ldsp);
+                return TCR_ERR_HIP;
+            }
+            configured_p = true;
+        }
+        if (x_scale) hipLaunchKernelGGL((pw_wgrad_lds_p_kernel<65, true>), grid, dim3(256), ldsp, s, a);
+        else hipLaunchKernelGGL((pw_wgrad_lds_p_kernel<65, false>), grid, dim3(256), ldsp, s, a);
+        TCR_TRY(check_launch("pw_wgrad_lds_p_kernel"));
+        return launch_wgrad_reduce(scratch, dw, a.nchunk, 1, cin, cout, a.cin_pad, a.cout_pad, cout, 0, s);
+    }
     hipLaunchKernelGGL(pw_wgrad_lds_kernel, grid, dim3(256), lds, s, a);
     TCR_TRY(check_launch("pw_wgrad_lds_kernel"));
     return launch_wgrad_reduce(scratch, dw, a.nchunk, 1, cin, cout, a.cin_pad, a.cout_pad, cout, 0, s);

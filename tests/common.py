@@ -553,13 +553,14 @@ def check_dscnn_pointwise_wgrad_kernels(lib, size, batch, knob_id=25):
     assert not torch.equal(a, b)                # (the knob did select another kernel)
 
 
-def check_dscnn_pointwise_geometries(lib, size, batch, knob_id=28):
+def check_dscnn_pointwise_geometries(lib, size, batch, knob_id=28, alt=1):
     """The wide pointwise conv kernel built for <= 128 registers (four waves per SIMD; default) against the unconstrained build of
     rounds 3-4 (TCR_TUNE_PW_POS = 1): the same instructions in another register allocation -- eval logits and training gradients bitwise.
     knob_id 29 (TCR_TUNE_BN_APPLY): the BN-backward apply pass with four float4 per thread and its coefficients in LDS (default) against
     the one-float4-per-thread kernel -- the same expression per element, gradients bitwise.  knob_id 30 (TCR_TUNE_DW_DGRAD): the depthwise
     data gradient of the stride-1 units by the row kernel (default) against the padded-image kernel -- same fmaf chain per output, same
-    order of the backward sums, gradients bitwise.  knob_id 32 (TCR_TUNE_DW_FWD): the forward depthwise conv likewise (eval logits too)."""
+    order of the backward sums, gradients bitwise.  knob_id 32 (TCR_TUNE_DW_FWD): the forward depthwise conv likewise (eval logits too).
+    knob_id 25, alt 2 (TCR_TUNE_PW_WGRAD): the pointwise filter gradient's unrolled kernel (default) against its run-time-shape form."""
     from oracle import dscnn_ref as D
     p, s = D.init_params(D.net_def(size), seed=4)
     fe = make_frontend(lib, 640, 320, num_mfccs=10)
@@ -569,7 +570,7 @@ def check_dscnn_pointwise_geometries(lib, size, batch, knob_id=28):
     labels = to_dev(lib, np.tile(R.synth_labels(base.shape[0]), (reps, 1)))
     evals, grads = [], []
     try:
-        for knob in (0, 1):
+        for knob in (0, alt):
             lib.tcr_tune(knob_id, knob)
             net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
             sd = dict(p); sd.update(s); net.load_state_dict(sd)

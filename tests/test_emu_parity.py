@@ -222,6 +222,10 @@ def test_dscnn_bn_backward_apply_kernels_agree(emu_lib):
     Cm.check_dscnn_pointwise_geometries(emu_lib, "M", 3, knob_id=29)
 
 
+def test_dscnn_pointwise_filter_gradient_unrolled_kernel_is_bitwise(emu_lib):
+    Cm.check_dscnn_pointwise_geometries(emu_lib, "M", 3, knob_id=25, alt=2)
+
+
 def test_dscnn_depthwise_forward_kernels_agree(emu_lib):
     Cm.check_dscnn_pointwise_geometries(emu_lib, "M", 4, knob_id=32)        # (whole blocks of 16 planes: 4 x 172)
 

@@ -517,6 +517,11 @@ def test_dscnn_bn_backward_apply_kernels_agree(hip_lib, size, batch):
     Cm.check_dscnn_pointwise_geometries(hip_lib, size, batch, knob_id=29)
 
 
+@pytest.mark.parametrize("size,batch", [("L", 37), ("M", 256)])
+def test_dscnn_pointwise_filter_gradient_unrolled_kernel_is_bitwise(hip_lib, size, batch):
+    Cm.check_dscnn_pointwise_geometries(hip_lib, size, batch, knob_id=25, alt=2)
+
+
 @pytest.mark.parametrize("size,batch", [("L", 36), ("M", 256)])         # (the row kernel takes whole blocks of 16 planes)
 def test_dscnn_depthwise_forward_kernels_agree(hip_lib, size, batch):
     Cm.check_dscnn_pointwise_geometries(hip_lib, size, batch, knob_id=32)
