@@ -429,7 +429,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_PW_WGRAD = 25,   /* wide pointwise (DS-CNN 172 / 276 channels) filter gradient: 0 the register-staged kernel (two 4-wave workgroups per CU; on 13 x 5 maps its unrolled form with fixed staging roles, round 5; default), 1 the DMA-staged kernel (global_load_lds into two LDS buffers, one 12-wave workgroup per CU, three split-K wave groups; measured 2 % slower), 2 the register-staged kernel's run-time-shape form on every map (rounds 4-5; bitwise the default) */
        TCR_TUNE_DEPLOY_F32 = 26, /* deploy-path MFCC (method 2): 0 the float64 kernel (one workgroup per frame; TF's ops compute in double; default), 1 the float32 throughput kernels with the op's filterbank / log floor (rounds 3-4: up to 0.5 off on noise-free tones, where the empty bands are pure round-off) */
        TCR_TUNE_NET_SMALL = 27,  /* eval network, TCResNet8-1.0 at 49 frames, batches of <= 64 utterances: 0 the small-batch kernel (one utterance per 8-wave workgroup, each phase's weights DMA-copied into LDS one phase ahead; default), 1 the throughput kernel at one utterance per group (rounds 2-4).  Bitwise the same outputs. */
-       TCR_TUNE_PW_POS = 28,     /* wide pointwise convs (DS-CNN-L, 276 channels; forward, data gradient): 0 the nine-tile kernel built for <= 128 registers = four waves per SIMD (default since round 5), 1 the unconstrained build of rounds 3-4 (92 VGPRs + 72 AGPRs, three waves per SIMD).  Bitwise the same results. */
+       TCR_TUNE_PW_POS = 28,     /* wide pointwise convs (DS-CNN-L, 276 channels; forward, data gradient): 0 the nine-tile kernel built for <= 128 registers = four waves per SIMD, its weight chunks copied global -> LDS by the DMA path and its LDS fragment reads one step ahead of the MFMAs (default since round 5), 1 the unconstrained build of rounds 3-4 (92 VGPRs + 72 AGPRs, three waves per SIMD, register-staged weights), 2 the <= 128-register build with register-staged weights.  Bitwise the same results. */
        TCR_TUNE_BN_APPLY = 29,   /* BN-backward apply pass over large tensors (DS-CNN): 0 four float4 per thread and operand, per-channel coefficients staged in LDS (default since round 5), 1 the one-float4-per-thread kernel of rounds 2-4.  Bitwise the same dy. */
        TCR_TUNE_DW_DGRAD = 30,   /* DS-CNN depthwise data gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (dz / raw / dx blocks of 16 planes as contiguous float4 through LDS, one lane per map row; default since round 5), 1 the zero-padded-image kernel of rounds 2-4.  Bitwise the same dx and backward sums. */
        TCR_TUNE_DW_WGRAD = 31,   /* DS-CNN depthwise filter gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (a wave owns four channels, their x / dz planes as contiguous float4 through wave-private LDS; default since round 5), 1 the gather kernel of rounds 2-4 (another summation order: equal to rounding). */

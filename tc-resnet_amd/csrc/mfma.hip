@@ -140,7 +140,14 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
 // eval 4.48 vs 4.06 ms, training step 17.5 vs 15.7 -- slower, not instantiated.  MINW = 4 (default for the nine-tile instances since round 5):
 // the compiler keeps the 72 accumulator registers in VGPRs and fits 128 -- four waves per SIMD instead of three (92 VGPRs + 72 AGPRs):
 // DS-CNN-L eval 4.06 -> 3.93 ms, training step 15.72 -> 15.47 ms; TCR_TUNE_PW_POS = 1 selects the unconstrained build (bitwise the same).
-template <int MT, int NT, int EPI, int MODE, int NWN = 2, int MINW = 1>
+// WDMA (round 5, the default of the nine-tile instances): the weight chunk goes global -> LDS by the DMA path (global_load_lds_dwordx4: an
+// instruction writes 64 x 16 contiguous bytes of LDS from per-lane global addresses; the chunk's LDS image [12][304] is 14.25 such
+// kilobytes, four instructions per wave, their per-lane source offsets fixed for the whole kernel) -- no staging registers, no LDS store
+// pass, no per-load predicates or address arithmetic (the register path spends ~100 VALU instructions per chunk and wave beside its 54
+// MFMAs, and on this chip they add to the matrix time); the 16 registers it frees hold the NEXT 4-position step's fragments, so the LDS
+// reads of a step are in flight behind the previous step's MFMAs (the <= 128-register build otherwise reads, waits, multiplies).
+// Columns past Cout carry other weights instead of zeros: their output rows are never stored.
+template <int MT, int NT, int EPI, int MODE, int NWN = 2, int MINW = 1, bool WDMA = false>
 __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv1x1Args a) {     // MINW = 4: <= 128 registers (four waves per SIMD)
     constexpr int NTHR = 128 * NWN;
     constexpr int KC = 12;                  // input channels per chunk = 3 MFMA k-steps
@@ -154,7 +161,11 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
     constexpr int WPT = (KC * W4 + NTHR - 1) / NTHR;
     static_assert(NTHR % XN == 0 && (XLD % 64 == 16 || XLD % 64 == 48), "x staging geometry / bank pattern");
     static_assert(KC % RS == 0, "x staging");
-    __shared__ float s_w[2][KC * WLD];
+    constexpr int WIMG = KC * WLD;                              // floats of a weight chunk's LDS image
+    constexpr int ND = (WIMG + 255) / 256;                      // WDMA: 1 KB copies per chunk
+    constexpr int WBUF = WDMA ? ND * 256 : WIMG;                // (the last copy's tail lands in the buffer's own padding)
+    constexpr int DPW = (ND + NTHR / 64 - 1) / (NTHR / 64);     // copies per wave and chunk
+    __shared__ __attribute__((aligned(16))) float s_w[2][WBUF];
     __shared__ float s_x[2][KC * XLD];
 
     const int tid = threadIdx.x;
@@ -186,6 +197,26 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
         wcol[j] = 4 * (idx % W4);
         wval[j] = wcol[j] < a.cout;                         // (Cout % 4 == 0: launcher)
     }
+    // WDMA: copy i = wave + (NTHR / 64) j of a chunk writes image floats [256 i, 256 i + 256); this lane's four start at f
+    unsigned dsrc[DPW];                                         // byte offset of the lane's source float4 from the chunk's first weight row
+    auto dma_src = [&](int j, int rows) -> unsigned {           // rows: weight rows the chunk really has (clamped past them)
+        const int f = (wave + (NTHR / 64) * j) * 256 + lane * 4;
+        const int row = min(f / WLD, rows - 1), col = min(f % WLD, a.cout - 4);
+        return (unsigned)(row * a.cout + col) * 4u;
+    };
+    if (WDMA) {
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) dsrc[j] = dma_src(j, KC);
+    }
+    auto dma_chunk = [&](int c0, int buf) {
+        const char* wsrc = reinterpret_cast<const char*>(a.w + (size_t)c0 * a.cout);
+        const bool part = c0 + KC > a.cin;                      // (the last chunk of a Cin that is not a multiple of 12)
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int i = wave + (NTHR / 64) * j;
+            if (i < ND) glds16(wsrc + (part ? dma_src(j, a.cin - c0) : dsrc[j]), &s_w[buf][i * 256]);
+        }
+    };
     float xr[XPT], xsc[XPT], xsf[XPT];
     float yr[XPT], fk1[XPT], fk2[XPT], fk3[XPT], fmu[XPT];     // MODE 3 (xsc / xsf hold the unit's own scale / shift there)
     int xrw[XPT];
@@ -203,6 +234,7 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
                 xrw[j] = row;
             }
         }
+        if (WDMA) return;
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
             const float* src = a.w + (size_t)min(c0 + wrow[j], a.cin - 1) * a.cout + min(wcol[j], a.cout - 4);
@@ -229,6 +261,7 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
                 s_x[buf][(xrow0 + RS * j) * XLD + xpos] = v;
             }
         }
+        if (WDMA) return;
 #pragma unroll
         for (int j = 0; j < WPT; ++j)
             if (wuse[j]) *reinterpret_cast<f32x4*>(&s_w[buf][wrow[j] * WLD + wcol[j]]) = wr[j];
@@ -241,17 +274,49 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = (a.cin + KC - 1) / KC;
+    if (WDMA) dma_chunk(0, 0);
     load_chunk(0);
     store_chunk(0);
+    if (WDMA) wait_dma();
     __syncthreads();
     const int aoff = q * WLD + wm * (16 * MT) + r, boff = q * XLD + wn * (16 * NT) + r;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const bool more = ch + 1 < nchunks;
+        if (WDMA && more) dma_chunk((ch + 1) * KC, buf ^ 1);
         if (more && !TCR_PWW(1)) load_chunk((ch + 1) * KC);
         const int steps = min(KC / 4, (a.cin - ch * KC) >> 2);      // (last chunk of a Cin that is not a multiple of 12)
         const float* sw = s_w[buf] + aoff;
         const float* sx = s_x[buf] + boff;
+        if (WDMA) {             // fragments one step ahead of the MFMAs that use them
+            float af[MT], bf[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = sw[m * 16];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = sx[nt * 16];
+#pragma unroll
+            for (int ks = 0; ks < KC / 4; ++ks) {
+                if (ks < steps) {
+                    float an[MT], bn[NT];
+                    if (ks + 1 < KC / 4) {      // (a step past `steps` reads stale rows of the buffer and is not multiplied)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) an[m] = sw[(ks + 1) * 4 * WLD + m * 16];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bn[nt] = sx[(ks + 1) * 4 * XLD + nt * 16];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+                    if (ks + 1 < KC / 4) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) af[m] = an[m];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bf[nt] = bn[nt];
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {
             if (ks < steps) {
@@ -269,7 +334,9 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
                     }
             }
         }
+        }
         if (more && !TCR_PWW(2)) store_chunk(buf ^ 1);
+        if (WDMA) wait_dma();
         if (!TCR_PWW(4)) __syncthreads();
     }
 
@@ -394,6 +461,7 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
         const dim3 lgrid(ceil_div(a.npos, 64));
         const dim3 lblk(256);
         const bool cap128 = tune_get(TCR_TUNE_PW_POS) != 1;     // nine-tile instances at <= 128 registers (four waves per SIMD)
+        const bool wdma = tune_get(TCR_TUNE_PW_POS) == 0 && a.cout % 4 == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;     // ... with the weight chunks by DMA
         if (extras) {
             // training forms: (in-affine + forward sums) with the bias epilogue, or (backward sums) on the raw data gradient
             const bool fwd = epi == MF_AFFINE && a.in_scale && a.in_shift && a.sums.partial && !a.sums.raw;
@@ -405,7 +473,11 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
     if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE, 1, NWN_>), lgrid, lblk, 0, s, a);               \
     else if (bfly) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 3, NWN_>), lgrid, lblk, 0, s, a);            \
     else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 2, NWN_>), lgrid, lblk, 0, s, a)
-            if (cap128 && mt == 9) {
+            if (wdma && mt == 9 && !bfly) {
+                if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_AFFINE, 1, 2, 4, true>), lgrid, lblk, 0, s, a);
+                else hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 2, 2, 4, true>), lgrid, lblk, 0, s, a);
+            }
+            else if (cap128 && mt == 9) {
                 if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_AFFINE, 1, 2, 4>), lgrid, lblk, 0, s, a);
                 else if (bfly) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 3, 2, 1>), lgrid, lblk, 0, s, a);     // (this form spills at 128)
                 else hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 2, 2, 4>), lgrid, lblk, 0, s, a);
@@ -417,7 +489,11 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
 #define TCR_LL(MT_, NWN_)                                                                                               \
     if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_RAW, 0, NWN_>), lgrid, lblk, 0, s, a);        \
     else hipLaunchKernelGGL((conv1x1_lds_kernel<MT_, 2, MF_AFFINE, 0, NWN_>), lgrid, lblk, 0, s, a)
-        if (cap128 && mt == 9) {
+        if (wdma && mt == 9) {
+            if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 0, 2, 4, true>), lgrid, lblk, 0, s, a);
+            else hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_AFFINE, 0, 2, 4, true>), lgrid, lblk, 0, s, a);
+        }
+        else if (cap128 && mt == 9) {
             if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 0, 2, 4>), lgrid, lblk, 0, s, a);
             else hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_AFFINE, 0, 2, 4>), lgrid, lblk, 0, s, a);
         }
