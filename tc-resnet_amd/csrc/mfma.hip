@@ -273,6 +273,25 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // WDMA: the epilogue's per-channel constants (AFFINE: scale / shift; backward sums: mean, invstd, the mask's scale / shift) are fetched
+    // here, parked in a few registers through the chunk loop and laid out in the x buffers after it: the epilogue reads them with 16-byte
+    // LDS loads (the register-path epilogue gathers them from global memory per output element: 41 us of a 460 us launch, what-if 32)
+    constexpr int NA = MODE >= 2 ? 4 : 2;
+    constexpr bool TAB = WDMA && (EPI == MF_AFFINE || MODE >= 2);
+    constexpr int TPT = (NA * MW + NTHR - 1) / NTHR;
+    static_assert(!WDMA || (NA * MW <= 2 * KC * XLD && NWN == 2), "the table fits the x buffers; two wave columns");
+    float tabr[TPT];
+    if (TAB) {
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+            const int i = min(tid + NTHR * j, NA * MW - 1);
+            const int which = i / MW, c = min(i - which * MW, a.cout - 1);
+            float v;
+            if (MODE >= 2) v = which == 0 ? a.sums.mean[c] : which == 1 ? a.sums.invstd[c] : which == 2 ? a.sums.self_scale[c] : a.sums.self_shift[c];
+            else v = which == 0 ? (a.scale ? a.scale[c] : 1.0f) : a.shift[c];
+            tabr[j] = v;
+        }
+    }
     const int nchunks = (a.cin + KC - 1) / KC;
     if (WDMA) dma_chunk(0, 0);
     load_chunk(0);
@@ -283,7 +302,7 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const bool more = ch + 1 < nchunks;
-        if (WDMA && more) dma_chunk((ch + 1) * KC, buf ^ 1);
+        if (WDMA && more && !TCR_PWW(1)) dma_chunk((ch + 1) * KC, buf ^ 1);
         if (more && !TCR_PWW(1)) load_chunk((ch + 1) * KC);
         const int steps = min(KC / 4, (a.cin - ch * KC) >> 2);      // (last chunk of a Cin that is not a multiple of 12)
         const float* sw = s_w[buf] + aoff;
@@ -307,7 +326,10 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt) {
+                            if (TCR_PWW(8)) { acc[m][nt][0] += af[m] + bf[nt]; continue; }
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+                        }
                     if (ks + 1 < KC / 4) {
 #pragma unroll
                         for (int m = 0; m < MT; ++m) af[m] = an[m];
@@ -342,6 +364,108 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
 
     // (lean addressing: see conv_mfma_store)
     const float inv_tout = 1.0f / (float)a.tout;
+    if (WDMA) {
+        // Lean epilogue: constants from the LDS table, the common case (whole tile inside the tensor, whole 16-channel tile below Cout) without
+        // per-store predicates, halo zeroing after the stores and only for the lanes that sit on an utterance edge.  Same arithmetic per
+        // element and the same order of the sums as the register-path epilogue below: bitwise.
+        float* s_tab = &s_x[0][0];                              // [NA][MW]  (the loop's last barrier is behind every read of the x buffers)
+        if (TAB) {
+#pragma unroll
+            for (int j = 0; j < TPT; ++j)
+                if (tid + NTHR * j < NA * MW) s_tab[tid + NTHR * j] = tabr[j];
+            __syncthreads();
+        }
+        size_t yo[NT];
+        bool pv[NT], first[NT], last[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int p = pos0 + (wn * NT + nt) * 16 + r;
+            pv[nt] = p < a.npos;
+            const int pc = min(p, a.npos - 1);
+            const int n = a.npos < (1 << 23) ? fast_div(pc, a.tout, inv_tout) : pc / a.tout, t = pc - n * a.tout;
+            yo[nt] = (size_t)n * a.cout * a.tpo + kHalo + t;
+            first[nt] = t == 0; last[nt] = t == a.tout - 1;
+        }
+        const bool full = pos0 + XN <= a.npos;
+        float* s_sum = &s_w[0][0];
+        auto tile = [&](int m, auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const int co0 = (wm * MT + m) * 16;
+            f32x4 t0 = {1.f, 1.f, 1.f, 1.f}, t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1, t3 = t1;
+            if (TAB) {
+                t0 = *reinterpret_cast<const f32x4*>(s_tab + co0 + q * 4);
+                t1 = *reinterpret_cast<const f32x4*>(s_tab + MW + co0 + q * 4);
+                if (MODE >= 2) {
+                    t2 = *reinterpret_cast<const f32x4*>(s_tab + 2 * MW + co0 + q * 4);
+                    t3 = *reinterpret_cast<const f32x4*>(s_tab + 3 * MW + co0 + q * 4);
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = co0 + q * 4 + reg;
+                const bool cok = FAST || co < a.cout;
+                const int cc = FAST ? co : min(co, a.cout - 1);
+                float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bool ok = FAST || (cok && pv[nt]);
+                    float v = acc[m][nt][reg];
+                    if (EPI == MF_AFFINE) {
+                        v = fmaf(v, t0[reg], t1[reg]);
+                        if (a.relu) v = fmaxf(v, 0.f);
+                    }
+                    const size_t off = yo[nt] + (size_t)(cc * a.tpo);
+                    if (ok) a.y[off] = v;
+                    if (MODE == 1) {
+                        const float yv = ok ? v : 0.f;
+                        q1 += yv;
+                        q2 = fmaf(yv, yv, q2);
+                    } else if (MODE >= 2) {
+                        const float rawv = a.sums.raw[off];     // (clamped address: always valid)
+                        const float dz = (ok && fmaf(rawv, t2[reg], t3[reg]) > 0.f) ? v : 0.f;
+                        q1 += dz;
+                        q2 = fmaf(dz, (rawv - t0[reg]) * t1[reg], q2);
+                    }
+                }
+                if (MODE >= 1) {
+                    q1 = row16_sum(q1);
+                    q2 = row16_sum(q2);
+                    if (r == 0 && cok) { s_sum[(wn * 2 + 0) * MW + co] = q1; s_sum[(wn * 2 + 1) * MW + co] = q2; }
+                }
+            }
+        };
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co0 = (wm * MT + m) * 16;
+            if (co0 >= a.cout) break;
+            if (full && co0 + 16 <= a.cout) tile(m, std::true_type());
+            else tile(m, std::false_type());
+        }
+        if (EPI == MF_AFFINE) {         // zero halo of the rows this tile starts / ends (the lanes on an utterance's first / last position)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (pv[nt] && (first[nt] || last[nt])) {
+                    for (int cq = wm * MT * 16 + q * 4; cq < min((wm + 1) * MT * 16, a.cout); cq += 16)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            if (cq + reg >= a.cout) continue;
+                            float* o = a.y + yo[nt] + (size_t)((cq + reg) * a.tpo);
+                            if (first[nt]) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
+                            if (last[nt]) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+                        }
+                }
+            }
+        }
+        if (MODE >= 1) {
+            __syncthreads();
+            for (int i = tid; i < 2 * a.cout; i += NTHR) {
+                const int which = i >= a.cout ? 1 : 0, c = i - which * a.cout;
+                const float v = s_sum[which * MW + c] + s_sum[(2 + which) * MW + c];
+                a.sums.partial[((size_t)blockIdx.x * 2 + which) * a.cout + c] = v;
+            }
+        }
+        return;
+    }
     if (MODE == 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -359,14 +483,14 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
                     const int co = co0 + q * 4 + reg;
                     if (co >= a.cout) continue;
                     float v = acc[m][nt][reg];
-                    if (EPI == MF_AFFINE) {
+                    if (EPI == MF_AFFINE && !TCR_PWW(32)) {
                         v = fmaf(v, a.scale ? a.scale[co] : 1.0f, a.shift[co]);
                         if (a.relu) v = fmaxf(v, 0.f);
                     }
                     float* o = yb + co * a.tpo;
                     if (TCR_PWW(16) && v != 12345.f) continue;
                     o[0] = v;
-                    if (EPI == MF_AFFINE) {
+                    if (EPI == MF_AFFINE && !TCR_PWW(64)) {
                         if (first) { o[-4] = 0.f; o[-3] = 0.f; o[-2] = 0.f; o[-1] = 0.f; }
                         if (last) { o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
                     }
