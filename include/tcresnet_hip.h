@@ -433,7 +433,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_BN_APPLY = 29,   /* BN-backward apply pass over large tensors (DS-CNN): 0 four float4 per thread and operand, per-channel coefficients staged in LDS (default since round 5), 1 the one-float4-per-thread kernel of rounds 2-4.  Bitwise the same dy. */
        TCR_TUNE_DW_DGRAD = 30,   /* DS-CNN depthwise data gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (dz / raw / dx blocks of 16 planes as contiguous float4 through LDS, one lane per map row; default since round 5), 1 the zero-padded-image kernel of rounds 2-4.  Bitwise the same dx and backward sums. */
        TCR_TUNE_DW_WGRAD = 31,   /* DS-CNN depthwise filter gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (a wave owns four channels, their x / dz planes as contiguous float4 through wave-private LDS; default since round 5), 1 the gather kernel of rounds 2-4 (another summation order: equal to rounding). */
-       TCR_TUNE_DW_FWD = 32,     /* DS-CNN depthwise conv (eval and training forward), stride-1 layers on 13 x 5 maps: 0 the row kernel (x / y blocks of 16 planes as contiguous float4 through LDS; default since round 5), 1 the zero-padded-image kernel of rounds 2-4.  Bitwise the same outputs and statistics. */
+       TCR_TUNE_DW_FWD = 32,     /* DS-CNN depthwise conv (eval and training forward), stride-1 layers on 13 x 5 maps: 0 the row kernels (x / y blocks of 16 planes as contiguous float4 through LDS; also the global pooling's block-copy kernel and the row-per-lane stencil of the fused conv_1 + depthwise eval kernel; default since round 5), 1 the zero-padded-image kernels of rounds 2-4.  Bitwise the same outputs and statistics. */
        TCR_TUNE_COUNT = 33 };
 int tcr_tune(int knob, int value);
 

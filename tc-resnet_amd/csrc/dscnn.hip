@@ -197,6 +197,7 @@ struct DsDwArgs {
     const float* in_scale = nullptr;
     const float* in_shift = nullptr;
     EpiSums sums;
+    int rows_stencil = 0;   // dscnn_conv1_dw_kernel: the row-per-lane stencil (set by its launcher from TCR_TUNE_DW_FWD)
 };
 
 __global__ __launch_bounds__(256) void dscnn_depthwise_kernel(const DsDwArgs a) {
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(256) void dscnn_conv1_dw_kernel(const DsConv1Args a
     const int cot0 = blockIdx.y * MT;
     const int P1 = a.oh * a.ow, P2 = d.oh * d.ow;
     const int isz = ir * ic;
+    const bool rows5 = d.ow == 5 && d.sw == 2 && d.sh == 2 && ic == 11 && d.rows_stencil;
     for (int j = threadIdx.x; j < CH * isz; j += 256) planes[j] = 0.f;
     for (int j = threadIdx.x; j < 9 * CH; j += 256) {
         const int k = j / CH, cl = j - k * CH;
@@ -406,6 +408,38 @@ __global__ __launch_bounds__(256) void dscnn_conv1_dw_kernel(const DsConv1Args a
         }
     __syncthreads();
     // ---- depthwise 3x3 (+ folded BN + ReLU) ----
+    if (rows5) {
+        // 5-wide stride-2 output rows (every DS-CNN size): one lane per (channel, output row) -- the three padded plane rows it needs (11
+        // floats each) and the channel's nine taps are read once for five outputs: ~20 instead of ~60 VALU instructions and 8.4 instead
+        // of 18 LDS reads per output (the element loop below pays two divisions and 18 reads for each).  Same fmaf chain per output.
+        constexpr int OW = 5, RW = 2 * (OW - 1) + 3;
+        const float inv_oh = 1.0f / (float)d.oh;
+        for (int task = threadIdx.x; task < CH * d.oh; task += 256) {
+            const int cl = fast_div(task, d.oh, inv_oh), oh = task - cl * d.oh;
+            const int c = cot0 * 16 + cl;
+            if (c >= d.c) break;                                // (channels ascend with task)
+            float wt[9], in[3][RW];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wt[k] = s_dw[k * CH + cl];
+            const float* p0 = planes + cl * isz + oh * 2 * ic;
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int j = 0; j < RW; ++j) in[di][j] = p0[di * ic + j];
+            const float sc = d.scale[c], sf = d.shift[c];
+            float* yo = d.y + ((size_t)n * d.c + c) * d.ppo + kHalo + oh * OW;
+#pragma unroll
+            for (int w = 0; w < OW; ++w) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int di = 0; di < 3; ++di)
+#pragma unroll
+                    for (int dj = 0; dj < 3; ++dj) sacc = fmaf(wt[di * 3 + dj], in[di][2 * w + dj], sacc);
+                yo[w] = fmaxf(fmaf(sacc, sc, sf), 0.f);
+            }
+        }
+        return;
+    }
     const float inv_p2 = 1.0f / (float)P2, inv_ow2 = 1.0f / (float)d.ow;
     for (int idx = threadIdx.x; idx < CH * P2; idx += 256) {
         const int cl = fast_div(idx, P2, inv_p2), pos = idx - cl * P2;
@@ -431,7 +465,9 @@ static int launch_dscnn_conv1_dw(const DsConv1Args& a, const DsDwArgs& d, int ba
         d.pad_t + a.oh > ir || d.pad_l + a.ow > ic || batch > 65535 * 16) return 1;
     // 32 channels per workgroup (38 KB of LDS, 4 workgroups per CU): 4.15 ms; 48 channels: 4.28 ms; 16: 4.41 ms (DS-CNN-L eval)
     const dim3 grid(batch, ceil_div(ceil_div(a.cout, 16), 2));
-    hipLaunchKernelGGL((dscnn_conv1_dw_kernel<2>), grid, dim3(256), lds, s, a, d, ir, ic);
+    DsDwArgs d2 = d;
+    d2.rows_stencil = tune_get(TCR_TUNE_DW_FWD) != 1 ? 1 : 0;
+    hipLaunchKernelGGL((dscnn_conv1_dw_kernel<2>), grid, dim3(256), lds, s, a, d2, ir, ic);
     return check_launch("dscnn_conv1_dw_kernel");
 }
 
@@ -775,6 +811,42 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict
     if (t16 == 0 && row < rows) pooled[row * (1 + 2 * kHalo) + kHalo] = s / (float)p;
 }
 
+// The same pooling with the workgroup's 16 planes fetched as ONE contiguous block of float4 (16 x Pp floats) through LDS; every 16-lane group
+// then adds its plane in the order of the kernel above: bitwise.  (Rows x Pp a multiple of 4, whole blocks of 16 planes: the launcher checks.)
+__global__ __launch_bounds__(256) void plane_mean_block_kernel(const float* __restrict__ x, float* __restrict__ pooled, int p, int pp,
+                                                               const float* __restrict__ in_scale, const float* __restrict__ in_shift, int c) {
+    float* s_x = reinterpret_cast<float*>(dyn_lds());
+    const int tid = threadIdx.x;
+    const int n4 = 16 * pp / 4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + (size_t)blockIdx.x * 16 * pp);
+    for (int i = tid; i < n4; i += 256) reinterpret_cast<f32x4*>(s_x)[i] = x4[i];
+    __syncthreads();
+    const int t16 = tid & 15, plane = tid >> 4;
+    const int64_t row = (int64_t)blockIdx.x * 16 + plane;
+    const float* xr = s_x + plane * pp + kHalo;
+    float s = 0.f;
+    if (in_scale) {
+        const int ch = (int)(row % c);
+        const float sc = in_scale[ch], sf = in_shift[ch];
+        for (int i = t16; i < p; i += 16) s += fmaxf(fmaf(xr[i], sc, sf), 0.f);
+    } else {
+        for (int i = t16; i < p; i += 16) s += xr[i];
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (t16 == 0) pooled[row * (1 + 2 * kHalo) + kHalo] = s / (float)p;
+}
+
+static int launch_plane_mean(const float* x, float* pooled, int64_t rows, int p, int pp, const float* in_scale, const float* in_shift, int c, hipStream_t s) {
+    if (rows % 16 == 0 && (16 * pp) % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (size_t)16 * pp * sizeof(float) <= 64 * 1024 &&
+        tune_get(TCR_TUNE_DW_FWD) != 1) {
+        hipLaunchKernelGGL(plane_mean_block_kernel, dim3((unsigned)(rows / 16)), dim3(256), (size_t)16 * pp * sizeof(float), s, x, pooled, p, pp, in_scale, in_shift, c);
+        return check_launch("plane_mean_block_kernel");
+    }
+    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, x, pooled, rows, p, pp, in_scale, in_shift, c);
+    return check_launch("plane_mean_kernel");
+}
+
 struct DsLayer {
     std::string scope;
     bool separable;
@@ -967,9 +1039,7 @@ extern "C" int tcr_dscnn_forward_infer(const tcr_dscnn* net, const float* params
     const DsLayer& last = net->layers.back();
     const int P = last.oh * last.ow;
     const int64_t rows = (int64_t)batch * last.cout;
-    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, (const float*)buf[cur], buf[cur ^ 1], rows, P,
-                       tcr_padded_len(P));
-    TCR_TRY(check_launch("plane_mean_kernel"));
+    TCR_TRY(launch_plane_mean(buf[cur], buf[cur ^ 1], rows, P, tcr_padded_len(P), nullptr, nullptr, 1, s));
     HeadArgs h;
     std::memset(&h, 0, sizeof(h));
     h.feat = buf[cur ^ 1]; h.wfc = params + net->fcw_off; h.wfc2 = nullptr; h.bias = params + net->fcb_off;
@@ -1188,9 +1258,7 @@ static int ds_forward_train_stages(const tcr_dscnn* net, const float* params, fl
     const DsLayer& last = net->layers.back();
     const int P = last.oh * last.ow;
     const int64_t rows = (int64_t)batch * last.cout;
-    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, x, base + w.pooled, rows, P, tcr_padded_len(P),
-                       pool_scale, pool_scale ? pool_scale + cp : (const float*)nullptr, last.cout);
-    TCR_TRY(check_launch("plane_mean_kernel"));
+    TCR_TRY(launch_plane_mean(x, base + w.pooled, rows, P, tcr_padded_len(P), pool_scale, pool_scale ? pool_scale + cp : (const float*)nullptr, last.cout, s));
     HeadArgs h;
     std::memset(&h, 0, sizeof(h));
     h.feat = base + w.pooled; h.wfc = params + net->fcw_off; h.wfc2 = nullptr; h.bias = params + net->fcb_off;
