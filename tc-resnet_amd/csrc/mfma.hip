@@ -601,6 +601,10 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
                 if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_AFFINE, 1, 2, 4, true>), lgrid, lblk, 0, s, a);
                 else hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 2, 2, 4, true>), lgrid, lblk, 0, s, a);
             }
+            else if (wdma && mt == 6 && !bfly) {        // (DS-CNN-M, 172 channels)
+                if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<6, 2, MF_AFFINE, 1, 2, 4, true>), lgrid, lblk, 0, s, a);
+                else hipLaunchKernelGGL((conv1x1_lds_kernel<6, 2, MF_RAW, 2, 2, 4, true>), lgrid, lblk, 0, s, a);
+            }
             else if (cap128 && mt == 9) {
                 if (fwd) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_AFFINE, 1, 2, 4>), lgrid, lblk, 0, s, a);
                 else if (bfly) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 3, 2, 1>), lgrid, lblk, 0, s, a);     // (this form spills at 128)
@@ -616,6 +620,10 @@ int launch_conv1x1(const Conv1x1Args& a, int epi, hipStream_t s) {
         if (wdma && mt == 9) {
             if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 0, 2, 4, true>), lgrid, lblk, 0, s, a);
             else hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_AFFINE, 0, 2, 4, true>), lgrid, lblk, 0, s, a);
+        }
+        else if (wdma && mt == 6) {
+            if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<6, 2, MF_RAW, 0, 2, 4, true>), lgrid, lblk, 0, s, a);
+            else hipLaunchKernelGGL((conv1x1_lds_kernel<6, 2, MF_AFFINE, 0, 2, 4, true>), lgrid, lblk, 0, s, a);
         }
         else if (cap128 && mt == 9) {
             if (epi == MF_RAW) hipLaunchKernelGGL((conv1x1_lds_kernel<9, 2, MF_RAW, 0, 2, 4>), lgrid, lblk, 0, s, a);
