@@ -393,8 +393,16 @@ def main():
                 net2.forward_infer(feat2)
 
             s2 = floor(50, args.steps)
-            dt2 = timed(fwd2, s2, floor(20, args.warmup), dist_on)
+            dt2_seq = timed(fwd2, s2, floor(20, args.warmup), dist_on)
+            dt2, sched2 = dt2_seq, "one stream"
+            if pipelined:           # the headline's schedule (whole batches alternating between three streams)
+                from tcresnet_amd.pipeline import InferencePipeline
+                pipe2 = InferencePipeline(fe2, net2, B, mode="alternate", ways=int(os.environ.get("TCR_BENCH_WAYS", "3")))
+                dt2 = timed(lambda: pipe2.submit(wav), s2, floor(20, args.warmup), dist_on)
+                sched2 = "whole batches alternating between three streams (InferencePipeline 'alternate')"
+                del pipe2
             out["forward_3010"] = {"value": round(world * B * s2 / dt2, 1), "unit": "utterances/s", "ms_per_step": round(dt2 / s2 * 1e3, 4), "steps": s2,
+                                   "schedule": sched2, "sequential": {"ms_per_step": round(dt2_seq / s2 * 1e3, 4), "steps": s2},
                                    "workload": "same, 98x40 MFCC (30/10 ms, FFT 512)"}
 
         if legs & {"dscnn_forward", "dscnn_train"}:
