@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void dscnn_depthwise_lds_kernel(const DsDwArgs
 // [48][(oh-1)*sh + 3][(ow-1)*sw + 3], and the 3x3 stencil reads them back -- conv_1's output never reaches HBM.
 // (Requires conv_1's map to fit 256 positions: 25 x 10 for every DS-CNN size.)
 template <int MT>
-__global__ __launch_bounds__(256) void dscnn_conv1_dw_kernel(const DsConv1Args a, const DsDwArgs d, const int ir, const int ic) {
+__global__ __launch_bounds__(256) void dscnn_conv1_dw_kernel(const DsConv1Args a, const DsDwArgs d, const int ir, const int ic, const int fs_off, const int fs_sz) {
     constexpr int CH = 16 * MT;
     float* planes = reinterpret_cast<float*>(dyn_lds());        // [CH][ir][ic]
     float* s_dw = planes + CH * ir * ic;                        // [9][CH] depthwise taps
@@ -357,6 +357,67 @@ __global__ __launch_bounds__(256) void dscnn_conv1_dw_kernel(const DsConv1Args a
         h0[nt] = oh * a.sh - a.pad_t;
         pdst[nt] = (oh + d.pad_t) * ic + ow + d.pad_l;          // this position inside a padded plane
     }
+    if (fs_off > 0) {
+        // Round 5: both operands from LDS.  The utterance's feature map goes into a zero-padded image s_f[w_in + 3][(oh - 1) sh + kh]
+        // (row = coefficient + pad_l, column = frame + pad_t) and the workgroup's weight slice into s_wt[kh * 4][48] (pitch 48: the four
+        // tap columns of a fragment on two bank halves), so kernel row i of a lane's fragments is a fixed LDS address + i: ten unrolled
+        // steps of 2 + 4 ds_reads at immediate offsets and 8 MFMAs.  (The loop below gathers 6 operands per step from global memory
+        // with a 64-bit address, two range tests and a select each: ~480 of the kernel's ~1200 VALU instructions per wave, on a chip
+        // where they add to the matrix time.)  Same products in the same order: bitwise.
+        constexpr int KH = 10, WP = 48;
+        float* s_f = planes + fs_off;
+        float* s_wt = s_f + fs_sz;
+        const int fpitch = (a.oh - 1) * a.sh + KH;
+        const float inv_fp = 1.0f / (float)fpitch;
+        const float* fu = a.feat + (size_t)n * a.w_in * a.tp_in + kHalo;
+        for (int idx = threadIdx.x; idx < fs_sz; idx += 256) {
+            const int row = fast_div(idx, fpitch, inv_fp), col = idx - row * fpitch;
+            const int w = row - a.pad_l, h = col - a.pad_t;
+            const bool in = w >= 0 && w < a.w_in && h >= 0 && h < a.h_in;
+            const float v = fu[in ? w * a.tp_in + h : 0];
+            s_f[idx] = in ? v : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < KH * 4 * CH; idx += 256) {
+            const int tap = idx / CH, cl = idx - tap * CH;
+            const int co = cot0 * 16 + cl;
+            const float v = a.w[(size_t)tap * a.cout + min(co, a.cout - 1)];
+            s_wt[tap * WP + cl] = co < a.cout ? v : 0.f;
+        }
+        __syncthreads();                                        // (also: planes zeroed, taps staged)
+        int fo[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int rem = min(wave * 64 + nt * 16 + r, P1 - 1);
+            const int oh = fast_div(rem, a.ow, inv_ow1), ow = rem - oh * a.ow;
+            fo[nt] = (ow * a.sw + q) * fpitch + oh * a.sh;
+        }
+        const float* wa = s_wt + q * WP + r;
+        float af[MT], bf[4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = wa[m * 16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bf[nt] = s_f[fo[nt]];
+#pragma unroll
+        for (int i = 0; i < KH; ++i) {
+            float an[MT], bn[4];
+            if (i + 1 < KH) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) an[m] = wa[(i + 1) * 4 * WP + m * 16];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bn[nt] = s_f[fo[nt] + i + 1];
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+            if (i + 1 < KH) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = an[m];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bf[nt] = bn[nt];
+            }
+        }
+    } else {
     const float* wp[MT];
     bool cok[MT];
 #pragma unroll
@@ -394,6 +455,7 @@ __global__ __launch_bounds__(256) void dscnn_conv1_dw_kernel(const DsConv1Args a
         for (int nt = 0; nt < 4; ++nt) bf[nt] = bn[nt];
     }
     __syncthreads();                                            // planes zeroed, taps staged
+    }
     // ---- conv_1 epilogue (folded BN + ReLU) into the padded planes ----
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -457,6 +519,168 @@ __global__ __launch_bounds__(256) void dscnn_conv1_dw_kernel(const DsConv1Args a
     }
 }
 
+// The same fusion with a workgroup walking SEVERAL utterances (round 5): the depthwise taps, the workgroup's conv_1 weight slice, both
+// layers' folded scale / shift and the planes' zero border are set up ONCE; per utterance the 2.3 KB feature map is the only thing fetched
+// (into registers while the previous utterance's MFMAs run, then into the zero-padded LDS image), conv_1 runs out of LDS (ten unrolled
+// steps), its epilogue overwrites the plane interiors and the stencil runs one lane per (channel, output row).  The one-utterance kernel
+// above pays the weight / tap / scale staging and three exposed global round trips per 80 MFMAs of a wave.  Shapes: kh = 10, 5-wide
+// stride-2 depthwise rows (every DS-CNN size); same products and sums in the same order: bitwise.
+template <int MT>
+__global__ __launch_bounds__(256) void dscnn_conv1_dw_loop_kernel(const DsConv1Args a, const DsDwArgs d, const int ir, const int ic, const int fs_off,
+                                                                  const int fs_sz, const int upw, const int batch) {
+    constexpr int CH = 16 * MT, KH = 10, WP = 48, OW = 5, RW = 2 * (OW - 1) + 3, FPT = 4;
+    float* planes = reinterpret_cast<float*>(dyn_lds());        // [CH][ir][ic]
+    float* s_dw = planes + CH * ir * ic;                        // [9][CH]
+    float* s_f = planes + fs_off;                               // [w_in + 3][fpitch]
+    float* s_wt = s_f + fs_sz;                                  // [KH * 4][WP]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int cot0 = blockIdx.y * MT;
+    const int P1 = a.oh * a.ow;
+    const int isz = ir * ic;
+    const int n_begin = blockIdx.x * upw, n_end = min(n_begin + upw, batch);
+    for (int j = tid; j < CH * isz; j += 256) planes[j] = 0.f;
+    for (int j = tid; j < 9 * CH; j += 256) {
+        const int k = j / CH, cl = j - k * CH;
+        s_dw[j] = d.w[(size_t)k * d.c + min(cot0 * 16 + cl, d.c - 1)];
+    }
+    for (int idx = tid; idx < KH * 4 * CH; idx += 256) {
+        const int tap = idx / CH, cl = idx - tap * CH;
+        const int co = cot0 * 16 + cl;
+        const float v = a.w[(size_t)tap * a.cout + min(co, a.cout - 1)];
+        s_wt[tap * WP + cl] = co < a.cout ? v : 0.f;
+    }
+    // feature image roles of this thread (fixed for the kernel): element idx = tid + 256 k of s_f
+    const int fpitch = (a.oh - 1) * a.sh + KH;
+    const float inv_fp = 1.0f / (float)fpitch;
+    int fsrc[FPT];
+    bool fin[FPT];
+#pragma unroll
+    for (int k = 0; k < FPT; ++k) {
+        const int idx = min(tid + 256 * k, fs_sz - 1);
+        const int row = fast_div(idx, fpitch, inv_fp), col = idx - row * fpitch;
+        const int w = row - a.pad_l, h = col - a.pad_t;
+        fin[k] = w >= 0 && w < a.w_in && h >= 0 && h < a.h_in;
+        fsrc[k] = fin[k] ? w * a.tp_in + kHalo + h : 0;
+    }
+    float fr[FPT];
+    auto fetch = [&](int n) {
+        const float* fu = a.feat + (size_t)n * a.w_in * a.tp_in;
+#pragma unroll
+        for (int k = 0; k < FPT; ++k) fr[k] = fu[fsrc[k]];
+    };
+    // conv_1 fragments / epilogue roles
+    const float inv_ow1 = 1.0f / (float)a.ow;
+    int fo[4], pdst[4];
+    bool pv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int rem_raw = wave * 64 + nt * 16 + r;
+        pv[nt] = rem_raw < P1;
+        const int rem = min(rem_raw, P1 - 1);
+        const int oh = fast_div(rem, a.ow, inv_ow1), ow = rem - oh * a.ow;
+        fo[nt] = (ow * a.sw + q) * fpitch + oh * a.sh;
+        pdst[nt] = (oh + d.pad_t) * ic + ow + d.pad_l;
+    }
+    float esc[MT][4], esf[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cc = min(cot0 * 16 + m * 16 + q * 4 + reg, a.cout - 1);
+            esc[m][reg] = a.scale[cc]; esf[m][reg] = a.shift[cc];
+        }
+    // stencil roles: tasks tid and tid + 256 of CH * d.oh (channel, output row) pairs
+    const float inv_oh = 1.0f / (float)d.oh;
+    int tcl[2], toh[2], tc[2];
+    bool tok[2];
+    float tsc[2], tsf[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int task = tid + 256 * k;
+        tcl[k] = min(fast_div(task, d.oh, inv_oh), CH - 1);
+        toh[k] = task - fast_div(task, d.oh, inv_oh) * d.oh;
+        tc[k] = cot0 * 16 + tcl[k];
+        tok[k] = task < CH * d.oh && tc[k] < d.c;
+        const int cc = min(tc[k], d.c - 1);
+        tsc[k] = d.scale[cc]; tsf[k] = d.shift[cc];
+    }
+    const float* wa = s_wt + q * WP + r;
+    if (n_begin < n_end) fetch(n_begin);
+    for (int n = n_begin; n < n_end; ++n) {
+#pragma unroll
+        for (int k = 0; k < FPT; ++k)
+            if (tid + 256 * k < fs_sz) s_f[tid + 256 * k] = fin[k] ? fr[k] : 0.f;
+        __syncthreads();                                        // feature image (first trip: planes, taps, weights too); the previous stencil is done
+        if (n + 1 < n_end) fetch(n + 1);
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float af[MT], bf[4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = wa[m * 16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bf[nt] = s_f[fo[nt]];
+#pragma unroll
+        for (int i = 0; i < KH; ++i) {
+            float an[MT], bn[4];
+            if (i + 1 < KH) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) an[m] = wa[(i + 1) * 4 * WP + m * 16];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bn[nt] = s_f[fo[nt] + i + 1];
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nt], acc[m][nt], 0, 0, 0);
+            if (i + 1 < KH) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = an[m];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bf[nt] = bn[nt];
+            }
+        }
+        // conv_1 epilogue (folded BN + ReLU) into the padded planes
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cl = m * 16 + q * 4 + reg;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    if (pv[nt]) planes[cl * isz + pdst[nt]] = fmaxf(fmaf(acc[m][nt][reg], esc[m][reg], esf[m][reg]), 0.f);
+            }
+        __syncthreads();
+        // depthwise 3x3 stride 2 (+ folded BN + ReLU), one lane per (channel, output row)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!tok[k]) continue;
+            float wt[9], in[3][RW];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wt[t] = s_dw[t * CH + tcl[k]];
+            const float* p0 = planes + tcl[k] * isz + toh[k] * 2 * ic;
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int j = 0; j < RW; ++j) in[di][j] = p0[di * ic + j];
+            float* yo = d.y + ((size_t)n * d.c + tc[k]) * d.ppo + kHalo + toh[k] * OW;
+#pragma unroll
+            for (int w = 0; w < OW; ++w) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int di = 0; di < 3; ++di)
+#pragma unroll
+                    for (int dj = 0; dj < 3; ++dj) sacc = fmaf(wt[di * 3 + dj], in[di][2 * w + dj], sacc);
+                yo[w] = fmaxf(fmaf(sacc, tsc[k], tsf[k]), 0.f);
+            }
+        }
+    }
+}
+
 // returns 1 (nothing launched) when the shapes do not fit the fused kernel
 static int launch_dscnn_conv1_dw(const DsConv1Args& a, const DsDwArgs& d, int batch, hipStream_t s) {
     const int ir = (d.oh - 1) * d.sh + 3, ic = (d.ow - 1) * d.sw + 3;
@@ -467,7 +691,22 @@ static int launch_dscnn_conv1_dw(const DsConv1Args& a, const DsDwArgs& d, int ba
     const dim3 grid(batch, ceil_div(ceil_div(a.cout, 16), 2));
     DsDwArgs d2 = d;
     d2.rows_stencil = tune_get(TCR_TUNE_DW_FWD) != 1 ? 1 : 0;
-    hipLaunchKernelGGL((dscnn_conv1_dw_kernel<2>), grid, dim3(256), lds, s, a, d2, ir, ic);
+    // both conv_1 operands from LDS (kh = 10 kernels: every DS-CNN size): feature image + weight slice behind the planes and the depthwise taps
+    int fs_off = 0, fs_sz = 0;
+    size_t lds_all = lds;
+    if (d2.rows_stencil && a.kh == 10 && a.oh * a.ow <= 256) {
+        fs_sz = (a.w_in + 3) * ((a.oh - 1) * a.sh + 10);
+        fs_off = 32 * ir * ic + 9 * 32;
+        lds_all = ((size_t)fs_off + fs_sz + 40 * 48) * sizeof(float);
+        if (lds_all > 64 * 1024) { fs_off = 0; fs_sz = 0; lds_all = lds; }
+    }
+    if (fs_off > 0 && d.ow == 5 && d.sw == 2 && d.sh == 2 && ic == 11 && fs_sz <= 4 * 256 && 32 * d.oh <= 512) {
+        const int upw = 8;              // utterances per workgroup (4096 / 8 x 9 channel groups = 4608 workgroups)
+        const dim3 lgrid(ceil_div(batch, upw), grid.y);
+        hipLaunchKernelGGL((dscnn_conv1_dw_loop_kernel<2>), lgrid, dim3(256), lds_all, s, a, d2, ir, ic, fs_off, fs_sz, upw, batch);
+        return check_launch("dscnn_conv1_dw_loop_kernel");
+    }
+    hipLaunchKernelGGL((dscnn_conv1_dw_kernel<2>), grid, dim3(256), lds_all, s, a, d2, ir, ic, fs_off, fs_sz);
     return check_launch("dscnn_conv1_dw_kernel");
 }
 

@@ -153,7 +153,7 @@ extern "C" const char* tcr_kernel_name(int index) {
         "dscnn_depthwise_kernel", "dscnn_dw_dgrad_kernel", "dscnn_dw_wgrad_kernel", "dscnn_conv1_wgrad_kernel", "train_phase_kernel", "train_bwd_phase_kernel", "conv2d_mfma_kernel", "conv2d_wgrad_kernel", "pool2d_fwd_kernel",
         "pool2d_bwd_kernel", "eltwise2d_kernel", "head2d_kernel", "chan_sum2d_kernel", "features_to_plane_kernel",
         "net_fused_tc8_kernel", "net_fused_tc14w_kernel", "train_phase_s_kernel", "bwd_lazy_kernel", "conv_wgrad_mfma4_kernel", "conv_wgrad_lds_kernel",
-        "conv1x1_lds_kernel", "bn_bwd_finalize_kernel", "bn_bwd_finalize2_kernel", "wgrad_reduce_multi_kernel", "frontend_pk3_kernel", "pw_wgrad_glds_kernel", "pw_wgrad_lds_p_kernel", "frontend_deploy_f64_kernel", "net_small_tc8_kernel", "bn_bwd_apply4x_kernel", "dscnn_dw_dgrad_rows_kernel", "dscnn_dw_dgrad_rows_s2_kernel", "dscnn_dw_wgrad_rows_kernel", "dscnn_dw_wgrad_rows_s2_kernel", "dscnn_depthwise_rows_kernel", "dscnn_depthwise_rows_s2_kernel", "plane_mean_block_kernel",
+        "conv1x1_lds_kernel", "bn_bwd_finalize_kernel", "bn_bwd_finalize2_kernel", "wgrad_reduce_multi_kernel", "frontend_pk3_kernel", "pw_wgrad_glds_kernel", "pw_wgrad_lds_p_kernel", "frontend_deploy_f64_kernel", "net_small_tc8_kernel", "bn_bwd_apply4x_kernel", "dscnn_dw_dgrad_rows_kernel", "dscnn_dw_dgrad_rows_s2_kernel", "dscnn_dw_wgrad_rows_kernel", "dscnn_dw_wgrad_rows_s2_kernel", "dscnn_depthwise_rows_kernel", "dscnn_depthwise_rows_s2_kernel", "plane_mean_block_kernel", "dscnn_conv1_dw_loop_kernel",
     };
     const int n = (int)(sizeof(names) / sizeof(names[0]));
     return (index >= 0 && index < n) ? names[index] : nullptr;
