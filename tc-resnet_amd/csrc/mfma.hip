@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
 // grid --, so the bn_bwd_apply pass (3 tensor passes, 0.2 ms per layer in the backward's main chain) disappears.  Sums: the 16 positions of a tile column
 // block live in the 16 lanes of a DPP row -> row16_sum; the two position halves (wn) meet in LDS; one partial row per workgroup.
 // Timing what-ifs (scripts/build_whatif_src.sh mfma TCR_PW_WHATIF <mask>; wrong results, never the product build): 1 no global loads
-// after the first chunk, 2 no LDS stores after the first chunk, 4 no barrier in the chunk loop, 8 no MFMAs, 16 no output stores.
+// after the first chunk, 2 no LDS stores after the first chunk, 4 no barrier in the chunk loop, 8 no MFMAs, 16 no output stores (register-path epilogue),
+// 32 / 64 no epilogue affine / no halo zeroing (register-path epilogue), 128 the lean epilogue's stores as fully coalesced 256-byte runs (round 5:
+// -15 us per 460 us launch -- an LDS transpose of the output tile would buy less than that).
 #ifndef TCR_PW_WHATIF
 #define TCR_PW_WHATIF 0
 #endif
@@ -415,6 +417,9 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
                         if (a.relu) v = fmaxf(v, 0.f);
                     }
                     const size_t off = yo[nt] + (size_t)(cc * a.tpo);
+                    if (TCR_PWW(128)) {     // timing what-if: the same bytes as fully coalesced 256-byte runs (wrong addresses)
+                        if (ok) a.y[(size_t)blockIdx.x * (4 * MT * 4 * NT * 64) + (size_t)wave * (MT * 4 * NT * 64) + (size_t)((m * 4 + reg) * NT + nt) * 64 + lane] = v;
+                    } else
                     if (ok) a.y[off] = v;
                     if (MODE == 1) {
                         const float yv = ok ? v : 0.f;
