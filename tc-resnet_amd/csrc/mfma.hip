@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const Conv1x1Args a) 
 template <int MT, int NT, int EPI, int MODE, int NWN = 2, int MINW = 1, bool WDMA = false>
 __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv1x1Args a) {     // MINW = 4: <= 128 registers (four waves per SIMD)
     constexpr int NTHR = 128 * NWN;
-    constexpr int KC = 12;                  // input channels per chunk = 3 MFMA k-steps
+#ifndef TCR_PW_KC
+#define TCR_PW_KC 12
+#endif
+    constexpr int KC = WDMA ? TCR_PW_KC : 12;       // input channels per chunk = 3 MFMA k-steps  (side builds: -DTCR_PW_KC=16, round 5: see OPTLOG)
     constexpr int MW = 32 * MT;             // output channels covered (2 wave rows)
     constexpr int XN = 16 * NT * NWN;       // positions per workgroup (NWN wave columns)
     constexpr int WLD = MW + 16;            // (32 MT + 16) % 64 in {16, 48} for MT = 6, 9
