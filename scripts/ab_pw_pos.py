@@ -30,7 +30,7 @@ def timeit(fn, n=15, warm=5):
 for size in os.environ.get("AB_SIZES", "L,M").split(","):
     st = [0]
     for rnd in range(2):
-        for knob in (0, 1):
+        for knob in tuple(int(x) for x in os.environ.get("AB_ARMS", "0,1").split(",")):
             lib.tcr_tune(28, knob)
             ds = T.DSCNN(size, fe.n_frames, 10, 12, device=dev); ds.init_xavier(0)
             def step():
