@@ -48,7 +48,7 @@ def synth_batch(batch: int, device, seed: int, start: int = 0) -> torch.Tensor:
 # collectives, the JSON line) on the host-emulator build of the kernel sources -- test infrastructure (tests/test_distributed.py), never
 # a measurement: the line it prints says so ("rehearsal").  Without it the gfx950 library and a GPU are required.
 EMU = os.environ.get("TCR_BENCH_EMU") or None
-LEGS = ("latency", "train", "train14", "forward_3010", "dscnn_forward", "dscnn_train", "train_3010", "augment")
+LEGS = ("latency", "train", "train14", "train14_3010", "forward_3010", "dscnn_forward", "dscnn_train", "train_3010", "augment")
 
 
 def sync():
@@ -107,7 +107,7 @@ def main():
     if args.no_extras or args.legs == "none":
         legs = set()
     elif args.legs == "all":
-        legs = set(LEGS) if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and os.environ.get("TCR_BENCH_FORCE_DIST") != "1" else {"train", "train14"}      # (several ranks: the two legs whose gradient all-reduce crosses xGMI -- configs[2] and configs[3], TCResNet14-1.5 at global batch 4096 N; see "secondary legs" below)
+        legs = set(LEGS) if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and os.environ.get("TCR_BENCH_FORCE_DIST") != "1" else {"train", "train14", "train14_3010"}      # (several ranks: the two legs whose gradient all-reduce crosses xGMI -- configs[2] and configs[3], TCResNet14-1.5 at global batch 4096 N; see "secondary legs" below)
     else:
         legs = set(x for x in args.legs.split(",") if x)
         if legs - set(LEGS):
@@ -197,6 +197,13 @@ def main():
         from tcresnet_amd.pipeline import InferencePipeline
         pipe = InferencePipeline(fe, net, B, mode="alternate", ways=int(os.environ.get("TCR_BENCH_WAYS", "3")))     # (2 / 4: A/B arms)
         step_out = pipe.out
+    # (0) the COLD figure: the headline schedule's first 20 steps after 5 warm-up steps, ahead of every pre-warm launch of
+    #     this process -- what `--steps 20 --warmup 5 --prewarm 0` sees on an idle GPU whose clocks have not ramped.  Reported, never `value`.
+    cold_ms = None
+    if not EMU and args.prewarm > 0:
+        cold_fn = (lambda: pipe.submit(wav)) if pipelined else (lambda: seq_step())
+        dt_cold = timed(cold_fn, 20, 5, dist_on)
+        cold_ms = round(dt_cold / 20 * 1e3, 4)
     # (1) clock pre-warm + the one-stream sequence: labelled, untimed by the contract (outside the K timed steps and the W warm-up steps).
     #     The first ~50 launches on an idle GPU run ~15 % slower whatever --warmup says; the sequence's sampled events give the solo kernels.
     for _ in range(max(0, args.prewarm)):
@@ -252,7 +259,9 @@ def main():
     fe_tf = fe_flops / (fe_ms * 1e-3) / 1e12
     hbm_frac, fp_frac = fe_gbs / HBM_PEAK_GBS, fe_tf / FP32_PEAK_TFLOPS
     if fp_frac >= hbm_frac:
-        roof = {"bound": "mfma", "achieved": round(fe_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fp_frac, 4)}
+        # ("valu": the kernel's flops issue on the packed-FP32 vector pipe, not on the matrix cores -- the f32 peak of both pipes is the
+        #  same 157.3 TFLOP/s, so `peak` is what the contract's "mfma" bound would carry)
+        roof = {"bound": "valu", "achieved": round(fe_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fp_frac, 4)}
     else:
         roof = {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
     traffic, traffic_src = pmc_traffic("frontend_pk3_kernel<512,")
@@ -265,6 +274,9 @@ def main():
                          "other stream's network kernel -- see pair_roofline for the co-running pair",
                  "hbm_gbs": round(fe_gbs, 1), "hbm_frac": round(hbm_frac, 4), "fp32_tflops": round(fe_tf, 3), "fp32_frac": round(fp_frac, 4),
                  "algorithmic_bytes_per_launch": fe_bytes, "algorithmic_flops_per_launch": fe_flops})
+    if prof_avg_us and abs(prof_avg_us - fe_ms * 1e3) > 0.05 * fe_ms * 1e3:
+        roof["profile_stale_warning"] = (f"committed profile says {prof_avg_us} us per launch, this run measured {round(fe_ms * 1e3, 1)} us (> 5 % apart): "
+                                         f"{prof_src} (and the PMC traffic beside it) describes another build or another clock state")
     whole_tf = value / world * (w["mfcc_flops"] + w["net_flops"]) / 1e12
     out = {
         "metric": "utterances/sec (1 s@16 kHz) TCResNet8-1.0 forward", "value": round(value, 1), "unit": "utterances/s",
@@ -286,6 +298,7 @@ def main():
         ("batch_latency_ms_p10_p50_p90" if pipelined else "step_ms_p10_p50_p90"): [pct(0.1), pct(0.5), pct(0.9)],     # (pipelined: e0 -> e2 of a batch on its own stream, three batches in flight)
         "event_timed_steps": len(timed_ev),
         "pre_warm_launches": max(0, args.prewarm) + (max(0, args.prewarm) // 2 if pipelined else 0),
+        "cold_ms_per_step": cold_ms,        # (steps 6..25 of this process's headline schedule, ahead of the pre-warm; None with --prewarm 0, where ms_per_step IS the cold figure)
         "whole_path_fp32_frac": round(whole_tf / FP32_PEAK_TFLOPS, 4),
         "whole_path_hbm_frac": round(value / world * 64048 / 1e9 / HBM_PEAK_GBS, 4),
     }
@@ -382,8 +395,18 @@ def main():
                                                        + (f", {coll} all-reduce of the 1.21 MB gradient arena" if dist_on else ""))
             out["collectives_per_step"]["train_tcresnet14_1.5"] = out["train_tcresnet14_1.5"]["collectives_per_step"]
             del net14
-        if legs & {"forward_3010", "train_3010"}:
+        if legs & {"forward_3010", "train_3010", "train14_3010"}:
             fe2, net2 = build("3010")
+        if "train14_3010" in legs:
+            # ---------------- configs[3] at the reference's own front-end setting: the only TCResNet14-1.5 script is 30/10 ms -> 98 frames
+            # (scripts/commands/TCResNet14Model-1.5_mfcc_40_3010_0.001_mom_l1.sh:3) ----------------
+            net14b = T.TCResNet("TCResNet14", [24, 36, 36, 48, 48, 72, 72], 40, fe2.n_frames, 12, lib=lib, device=dev)
+            net14b.init_xavier(0)
+            out["train_tcresnet14_1.5_3010"] = train_leg(fe2, net14b, floor(20, max(1, args.steps // 4)), floor(10, args.warmup // 2))
+            out["train_tcresnet14_1.5_3010"]["workload"] = (f"TCResNet14-1.5 train step, 98x40 MFCC (30/10 ms: the reference's script for this model), batch {B}/GPU (global {world * B})"
+                                                            + (f", {coll} all-reduce of the 1.21 MB gradient arena" if dist_on else ""))
+            out["collectives_per_step"]["train_tcresnet14_1.5_3010"] = out["train_tcresnet14_1.5_3010"]["collectives_per_step"]
+            del net14b
         if "forward_3010" in legs:
             # ---------------- 30/10 ms front-end (98x40, the reference's training scripts) ----------------
             feat2 = torch.empty((B, 40, fe2.n_frames + 8), device=dev)

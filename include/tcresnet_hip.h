@@ -434,7 +434,8 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_DW_DGRAD = 30,   /* DS-CNN depthwise data gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (dz / raw / dx blocks of 16 planes as contiguous float4 through LDS, one lane per map row; default since round 5), 1 the zero-padded-image kernel of rounds 2-4.  Bitwise the same dx and backward sums. */
        TCR_TUNE_DW_WGRAD = 31,   /* DS-CNN depthwise filter gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (a wave owns four channels, their x / dz planes as contiguous float4 through wave-private LDS; default since round 5), 1 the gather kernel of rounds 2-4 (another summation order: equal to rounding). */
        TCR_TUNE_DW_FWD = 32,     /* DS-CNN depthwise conv (eval and training forward), stride-1 layers on 13 x 5 maps: 0 the row kernels (x / y blocks of 16 planes as contiguous float4 through LDS; also the global pooling's block-copy kernel and the row-per-lane stencil of the fused conv_1 + depthwise eval kernel; default since round 5), 1 the zero-padded-image kernels of rounds 2-4.  Bitwise the same outputs and statistics. */
-       TCR_TUNE_COUNT = 33 };
+       TCR_TUNE_WGRAD_PIPE = 33, /* 16-byte-load filter gradients (conv_wgrad_mfma4_kernel): 0 software-pipelined -- the operands of a wave's NEXT trip (the next 16 / 8 positions, or the next utterance's first) are requested before the current trip's MFMAs, two register sets alternating (round 6; bitwise the old kernel: same trips, same order; default), 1 every trip loads, waits, multiplies (rounds 3-5) */
+       TCR_TUNE_COUNT = 34 };
 int tcr_tune(int knob, int value);
 
 /* The library's internal streams (hipStream_t), one set per device and process.  HIP multiplexes streams onto a few hardware queues

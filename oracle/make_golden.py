@@ -217,12 +217,18 @@ def main():
     if "--edges-only" in sys.argv:          # (adds frontend_edge_*.npz without rewriting the other fixtures)
         make_frontend_edges()
         return
+    if "--tcresnet14-3010-only" in sys.argv:        # (round 6: adds the configs[3] fixture at the reference's own setting without rewriting the others)
+        make_net("TCResNet14", 1.5, "3010", batch=2, full=False)
+        return
     make_dscnn()
     make_frontend()
     make_frontend_edges()
     make_net("TCResNet8", 1.0, "4020")
     make_net("TCResNet8", 1.0, "3010", batch=3)
     make_net("TCResNet14", 1.5, "4020", batch=3, full=False)
+    # BASELINE configs[3] at the reference's own front-end setting: its only TCResNet14-1.5 script is 30 / 10 ms -> 98 frames
+    # (scripts/commands/TCResNet14Model-1.5_mfcc_40_3010_0.001_mom_l1.sh:3): the asymmetric SAME pads (3, 4) of the stride-2 convs at T = 98
+    make_net("TCResNet14", 1.5, "3010", batch=2, full=False)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

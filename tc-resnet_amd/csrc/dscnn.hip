@@ -701,7 +701,12 @@ static int launch_dscnn_conv1_dw(const DsConv1Args& a, const DsDwArgs& d, int ba
         if (lds_all > 64 * 1024) { fs_off = 0; fs_sz = 0; lds_all = lds; }
     }
     if (fs_off > 0 && d.ow == 5 && d.sw == 2 && d.sh == 2 && ic == 11 && fs_sz <= 4 * 256 && 32 * d.oh <= 512) {
-        const int upw = 8;              // utterances per workgroup (4096 / 8 x 9 channel groups = 4608 workgroups)
+        // utterances per workgroup: 8 at throughput sizes (4096 / 8 x 9 channel groups = 4608 workgroups, six rounds of the ~768 slots
+        // -- ~50 KB of LDS: three workgroups per CU); fewer while the grid would not fill those slots even once, so that small and mid
+        // batches keep one workgroup per (utterance, channel group) instead of walking 8 utterances serially on a mostly idle chip
+        // (advisor, round 5).  An utterance's result does not depend on upw: the loop handles them one after the other.
+        const int slots = 3 * device_cus();
+        const int upw = max(1, min(8, (batch * (int)grid.y) / slots));
         const dim3 lgrid(ceil_div(batch, upw), grid.y);
         hipLaunchKernelGGL((dscnn_conv1_dw_loop_kernel<2>), lgrid, dim3(256), lds_all, s, a, d2, ir, ic, fs_off, fs_sz, upw, batch);
         return check_launch("dscnn_conv1_dw_loop_kernel");
@@ -1591,9 +1596,9 @@ static int ds_backward_stages(const tcr_dscnn* net, const float* params, const f
     if (tune_get(TCR_TUNE_WGRAD_STREAM) != 1) {
         if (!net->side) {
             bool ok = (net->side = shared_stream(0, s)) != nullptr &&         // (process-wide: see tcr::shared_stream)
-                      hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) == hipSuccess &&
-                      hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) == hipSuccess;
-            for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&net->ev_done[i], hipEventDisableTiming) == hipSuccess;
+                      hipEventCreateWithFlags(&net->ev_fork, internal_event_flags()) == hipSuccess &&
+                      hipEventCreateWithFlags(&net->ev_join, internal_event_flags()) == hipSuccess;
+            for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&net->ev_done[i], internal_event_flags()) == hipSuccess;
             if (!ok) { net->side = nullptr; set_error("tcr_dscnn_backward: cannot create the filter-gradient stream"); return TCR_ERR_HIP; }
         }
         side = net->side;

@@ -303,23 +303,38 @@ __global__ __launch_bounds__(256) void frontend_deploy_f64_kernel(const Frontend
     __shared__ double s_re[1024], s_im[1024];
     __shared__ double s_mag[513];
     __shared__ double s_lm[64];
+    // Tables filled once per (persistent) workgroup -- round 6, advisor: as cos / sin calls inside the frame loop they were 1024 window
+    // + 5120 butterfly + 64 n_coef evaluations in double PER FRAME, which made a large-batch call through this method orders of
+    // magnitude slower than it has to be.  Window and twiddles are bitwise the per-butterfly expressions (-pi pos / half and
+    // -pi j / (nfft / 2) with j = pos (nfft / 2) / half differ by exact power-of-two scalings of numerator and denominator).
+    __shared__ double s_win[1024];
+    __shared__ double s_twr[512], s_twi[512];
+    __shared__ double s_dct[256];           // cos(pi j / 128): the DCT-II's cos(pi c (2 m + 1) / 128) at j = c (2 m + 1) mod 256
     const int tid = threadIdx.x;
     const float2* wud = reinterpret_cast<const float2*>(a.wud);
+    for (int i = tid; i < nfft; i += 256) s_win[i] = i < a.win ? 0.5 - 0.5 * cos(2.0 * kPi * (double)i / (double)a.win) : 0.0;
+    for (int j = tid; j < nfft / 2; j += 256) {
+        const double ang = -kPi * (double)j / (double)(nfft / 2);
+        s_twr[j] = cos(ang);
+        s_twi[j] = sin(ang);
+    }
+    s_dct[tid] = cos(kPi * (double)tid / 128.0);
+    __syncthreads();
     for (int g = blockIdx.x; g < a.total_frames; g += gridDim.x) {
         const int n = g / a.n_frames, t = g - n * a.n_frames;
         const float* src = a.wav + (size_t)n * a.n_samples + (size_t)t * a.hop;
         for (int i = tid; i < nfft; i += 256) {
-            const double x = i < a.win ? (double)src[i] * (0.5 - 0.5 * cos(2.0 * kPi * (double)i / (double)a.win)) : 0.0;
+            const double x = i < a.win ? (double)src[i] * s_win[i] : 0.0;
             const int j = (int)(__brev((unsigned)i) >> (32 - log_nfft));
             s_re[j] = x;
             s_im[j] = 0.0;
         }
         __syncthreads();
-        for (int half = 1; half < nfft; half <<= 1) {
+        int tstep = nfft / 2;               // table stride of the stage: (nfft / 2) / half
+        for (int half = 1; half < nfft; half <<= 1, tstep >>= 1) {
             for (int b = tid; b < nfft / 2; b += 256) {
                 const int pos = b & (half - 1), i0 = ((b - pos) << 1) + pos, i1 = i0 + half;
-                const double ang = -kPi * (double)pos / (double)half;
-                const double wr = cos(ang), wi = sin(ang);
+                const double wr = s_twr[pos * tstep], wi = s_twi[pos * tstep];
                 const double xr = s_re[i1], xi = s_im[i1];
                 const double tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
                 const double ur = s_re[i0], ui = s_im[i0];
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(256) void frontend_deploy_f64_kernel(const Frontend
         __syncthreads();
         if (tid < a.n_coef) {
             double v = 0.0;
-            for (int m = 0; m < 64; ++m) v += s_lm[m] * cos(kPi * (double)tid * ((double)m + 0.5) / 64.0);
+            for (int m = 0; m < 64; ++m) v += s_lm[m] * s_dct[(tid * (2 * m + 1)) & 255];
             float* row = a.out + ((size_t)n * a.n_coef + tid) * a.tp + kHalo + t;
             row[0] = (float)(v * sqrt(2.0 / 64.0));
             if (t == 0) { row[-4] = 0.f; row[-3] = 0.f; row[-2] = 0.f; row[-1] = 0.f; }
@@ -425,6 +440,8 @@ extern "C" int tcr_frontend_fwd_rounds(const tcr_frontend_cfg* cfg, const void* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int knob = tune_get(TCR_TUNE_FRONTEND);
     if (cfg->method == 2 && tune_get(TCR_TUNE_DEPLOY_F32) == 0) {      // deploy path: float64 (the ops it restates compute in double)
+        TCR_REQUIRE(cfg->n_mel == 64 && cfg->nfft <= 1024 && cfg->n_coef <= 64,
+                    "tcr_frontend_fwd: the float64 deploy kernel is built for 64 mel bands, <= 64 coefficients and nfft <= 1024 (got %d / %d / %d)", cfg->n_mel, cfg->n_coef, cfg->nfft);
         int lg = 0;
         while ((1 << lg) < cfg->nfft) ++lg;
         hipLaunchKernelGGL(frontend_deploy_f64_kernel, dim3(min(a.total_frames, 16 * device_cus())), dim3(256), 0, s, a, cfg->nfft, lg);

@@ -10,6 +10,8 @@
 // across utterances, A = weights straight from L1/L2, B = activations from the LDS rows (taps, stride and SAME
 // padding are plain offsets into the zero-halo rows).  A job is (16 output channels) x (32 positions); the four
 // waves of the workgroup take jobs round-robin, one s_barrier per layer.
+#include <cstdint>
+
 #include "kernels.h"
 
 namespace tcr {
@@ -1035,6 +1037,11 @@ __global__ __launch_bounds__(NW * 64) void net_fused_kernel(const FusedArgs a) {
 static int launch_net_small(const FusedArgs& a0, hipStream_t s) {
     constexpr int kWA = 9 * 48 * 48, kWB = 32 * 48 + 9 * 32 * 48;       // the two largest consecutive phases: conv2_1 | down2 + conv2_0
     FusedArgs a = a0;
+    // the weight copies are 16-byte DMA reads (global_load_lds_dwordx4) at params + w_off: a C-ABI caller's arena aligned to 4 bytes only
+    // (or a layer whose weights do not start on a 16-byte boundary) takes the throughput kernel instead (advisor, round 5)
+    if (reinterpret_cast<uintptr_t>(a.params) % 16 != 0) return 1;
+    for (int li = 0; li < a.n_layers; ++li)
+        if (a.layer[li].w_off % 4 != 0) return 1;
     const int act = a.buf_off[2] + a.buf_sz[2];                         // group == 1
     const int wa_off = (act + 64 + 63) / 64 * 64, wb_off = wa_off + kWA + 64;      // (+ pad: the layers' one-step operand lookahead)
     const size_t lds = ((size_t)wb_off + kWB + 64) * sizeof(float);

@@ -6,6 +6,8 @@
 //
 // Fragment layout of the 16x16x4 f32 MFMA (wave64): A[i = lane & 15][k = lane >> 4],
 // B[k = lane >> 4][j = lane & 15], D[row = 4 * (lane >> 4) + reg][col = lane & 15].
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.h"
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(128 * NWN, MINW) void conv1x1_lds_kernel(const Conv
     constexpr int WBUF = WDMA ? ND * 256 : WIMG;                // (the last copy's tail lands in the buffer's own padding)
     constexpr int DPW = (ND + NTHR / 64 - 1) / (NTHR / 64);     // copies per wave and chunk
     __shared__ __attribute__((aligned(16))) float s_w[2][WBUF];
-    __shared__ float s_x[2][KC * XLD];
+    __shared__ __attribute__((aligned(16))) float s_x[2][KC * XLD];      // (the lean epilogue reads its constant table from here with 16-byte LDS loads)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -700,6 +702,27 @@ __device__ __forceinline__ void conv_mfma_store(const f32x4 (&acc)[MT][2], float
         if (p >= wg_p1) continue;
         const int n = wg_p1 < (1 << 23) ? fast_div(p, tout, inv_tout) : p / tout, t = p - n * tout;
         const size_t ob = (size_t)n * cout * tpo + kHalo + t * ex.ostride + ex.ooff;
+        // The data gradient's addend (an identity shortcut's gradient under its mask, or the phases another conv wrote first): ALL of a
+        // lane's 4 MT addend / mask loads are requested before the first is used.  (Round 6: as part of the store loop below every
+        // element was load -> s_waitcnt vmcnt(0) -> add -> store, 4 MT dependent memory round trips per position tile in a ~50 us kernel.)
+        float addv[MT][4];
+        if (EPI != EPI_AFFINE && ex.add) {
+            float mkv[MT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int co = min((cot0 + m) * 16 + q * 4 + reg, cout - 1);       // (clamped: rows past Cout are never stored)
+                    const size_t o = ob + (size_t)(co * tpo);
+                    addv[m][reg] = ex.add_bcast ? ex.add[(size_t)n * cout + co] : ex.add[o];
+                    mkv[m][reg] = ex.add_mask ? ex.add_mask[o] : 1.f;
+                }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (!(mkv[m][reg] > 0.f)) addv[m][reg] = 0.f;
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -713,9 +736,7 @@ __device__ __forceinline__ void conv_mfma_store(const f32x4 (&acc)[MT][2], float
                     if (res) v = fmaxf(v + res[o], 0.f);            // net += layer_in; relu  (tc_resnet.py:40-41)
                     else if (relu) v = fmaxf(v, 0.f);
                 } else if (ex.add) {
-                    float av = ex.add_bcast ? ex.add[(size_t)n * cout + co] : ex.add[o];
-                    if (ex.add_mask && !(ex.add_mask[o] > 0.f)) av = 0.f;
-                    v += av;
+                    v += addv[m][reg];
                 }
                 float* dst = y + o;
                 dst[0] = v;
@@ -1359,12 +1380,64 @@ __device__ __forceinline__ void wgrad4_trip(f32x4 (&acc)[K][NCO], const float* x
     }
 }
 
+// The same trip in two halves -- the operand loads and the arithmetic -- for the software-pipelined loop below (round 6).  The ISA of the
+// one-piece trip is  loads -> s_waitcnt 0 -> K x NCO x NPL MFMAs  per trip: with 1 .. 1.5 waves on a SIMD (128 split-K chunks x 1 .. 3
+// input tiles) every trip's L2 / HBM round trip stands in front of its MFMAs.  Same loads, same arithmetic, same order: bitwise the same.
+// npl: positions per lane of the trip (4: a 16-position trip, 2: an 8-position trip) -- a run-time, wave-uniform value here, so that
+// ONE code path serves both trip lengths (two paths selected by a branch made the compiler keep two copies of the K x NCO accumulator
+// tiles and move all of them between the paths).  An 8-position trip loads the x window of a 16-position trip (up to one 16-byte load
+// more than it needs, inside the readable slack behind x) and uses the same elements wgrad4_trip<.., 8, ..> does.
+template <int K, int S, int NCO, bool FLY, int NW4M>
+__device__ __forceinline__ void wgrad4_load(wg_f4u (&d4)[NCO], wg_f4u (&r4)[NCO], wg_f4u (&w4)[NW4M], const float* xr, const float* dr, const float* rr,
+                                            const int (&doff)[NCO], int lq, int t0) {      // lq = npl * q
+#pragma unroll
+    for (int m = 0; m < NCO; ++m) d4[m] = *reinterpret_cast<const wg_f4u*>(dr + doff[m] + t0 + lq);
+    if (FLY) {
+#pragma unroll
+        for (int m = 0; m < NCO; ++m) r4[m] = *reinterpret_cast<const wg_f4u*>(rr + doff[m] + t0 + lq);
+    }
+#pragma unroll
+    for (int i = 0; i < NW4M; ++i) w4[i] = *reinterpret_cast<const wg_f4u*>(xr + (t0 + lq) * S + 4 * i);
+}
+
+template <int K, int S, int NCO, bool FLY, int NW4M>
+__device__ __forceinline__ void wgrad4_mma(f32x4 (&acc)[K][NCO], wg_f4u (&d4)[NCO], const wg_f4u (&r4)[NCO], const wg_f4u (&w4)[NW4M], const bool (&cov)[NCO],
+                                           bool civ, int lq, int npl, int t0, int tout, const float (&kk)[NCO][6]) {
+    if (FLY) {          // (wgrad4_trip's expression; elements past the trip's positions are computed and never used)
+#pragma unroll
+        for (int m = 0; m < NCO; ++m)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float g = d4[m].v[c];
+                const float y = r4[m].v[c];
+                if (!(fmaf(y, kk[m][4], kk[m][5]) > 0.f)) g = 0.f;
+                d4[m].v[c] = kk[m][0] * (g - kk[m][1] - (y - kk[m][3]) * kk[m][2]);
+            }
+    }
+    const int nsteps = min(npl, tout - t0);                     // (wave-uniform: k-steps in which some lane has a position)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= nsteps) break;
+        const bool pv = t0 + lq + c < tout;
+        float bf[NCO], af[K];
+#pragma unroll
+        for (int m = 0; m < NCO; ++m) bf[m] = (pv && cov[m]) ? d4[m].v[c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) af[j] = (pv && civ) ? w4[(c * S + j) / 4].v[(c * S + j) % 4] : 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int m = 0; m < NCO; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[m], acc[j][m], 0, 0, 0);
+    }
+}
+
 // NWV waves per workgroup (4, 8, 12 or 16): a wave takes every NWV-th utterance of the workgroup's chunk.  With four waves the 9-tap
 // layers of TCResNet8 put 1 .. 1.5 waves on a SIMD (128 split-K chunks x 1 .. 3 input-channel tiles), and every trip's operand loads --
 // an L2 / HBM round trip -- are waited out in front of its MFMAs; more waves per workgroup hide them without more slabs to reduce.  The
 // waves are combined in LDS in a fixed order: wave w adds onto slab w / 4 in round w % 4, the slabs are added in order on the way out.
-template <int K, int S, int NCO, bool SAFE, bool FLY, int NWV = 4>
+template <int K, int S, int NCO, bool SAFE, bool FLY, int NWV = 4, bool PIPE = false>
 __global__ __launch_bounds__(NWV * 64) void conv_wgrad_mfma4_kernel(const WgradArgs a) {
+    static_assert(!(PIPE && SAFE), "the clamped-load instantiation keeps the one-piece trips");
     constexpr int SLAB = K * 16 * NCO * 16, NG = NWV / 4;
     __shared__ float s_acc[NG * SLAB];
     const int lane = threadIdx.x & 63;
@@ -1399,14 +1472,62 @@ __global__ __launch_bounds__(NWV * 64) void conv_wgrad_mfma4_kernel(const WgradA
     const int n_end = min(n_begin + a.utt_per_block, a.batch);
     const int xlane = cic * a.tpi + a.xoff;
     const int xmax = a.tpi - 1 - a.xoff;            // last element of a row, relative to xr
-    for (int n = n_begin + wave; n < n_end; n += NWV) {
-        const float* xr = a.x + (size_t)n * a.cin * a.tpi + xlane;
-        const float* dr = a.dy + (size_t)n * a.cout_all * a.tpo;
-        const float* rr = FLY ? a.fly.raw + (size_t)n * a.cout_all * a.tpo : nullptr;
-        const bool safe = SAFE && n == a.batch - 1;
-        int t0 = 0;
-        for (; a.tout - t0 > 12; t0 += 16) wgrad4_trip<K, S, NCO, 16, SAFE, FLY>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax, rr, kk);
-        for (; t0 < a.tout; t0 += 8) wgrad4_trip<K, S, NCO, 8, SAFE, FLY>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax, rr, kk);
+    if constexpr (PIPE) {
+        constexpr int NW4M = (3 * S + K + 3) / 4;
+        wg_f4u dA[NCO], rA[NCO], wA[NW4M], dB[NCO], rB[NCO], wB[NW4M];
+        const int tout = a.tout;
+        // a wave's trips in order: utterance n_begin + wave (+ NWV ...), positions 0, 16, ... while more than 12 remain, then 8 at a time;
+        // the operands of trip i + 1 are requested before the MFMAs of trip i (two register sets, the loop unrolled by two)
+#define TCR_WG4_ISSUE(D_, R_, W_, N_, T0_)                                                                            \
+        {                                                                                                             \
+            const float* xr = a.x + (size_t)(N_) * a.cin * a.tpi + xlane;                                             \
+            const float* dr = a.dy + (size_t)(N_) * a.cout_all * a.tpo;                                               \
+            const float* rr = FLY ? a.fly.raw + (size_t)(N_) * a.cout_all * a.tpo : nullptr;                          \
+            wgrad4_load<K, S, NCO, FLY, NW4M>(D_, R_, W_, xr, dr, rr, doff, (tout - (T0_) > 12 ? 4 : 2) * q, T0_);    \
+        }
+#define TCR_WG4_RUN(D_, R_, W_, T0_)                                                                                  \
+        {                                                                                                             \
+            const int npl = tout - (T0_) > 12 ? 4 : 2;                                                                \
+            wgrad4_mma<K, S, NCO, FLY, NW4M>(acc, D_, R_, W_, cov, civ, npl * q, npl, T0_, tout, kk);                 \
+        }
+#define TCR_WG4_ADVANCE(N_, T0_)                                                                                      \
+        {                                                                                                             \
+            T0_ += tout - (T0_) > 12 ? 16 : 8;                                                                        \
+            if (T0_ >= tout) { T0_ = 0; N_ += NWV; }                                                                  \
+        }
+        // (the request for "the trip after the last" repeats the last one instead of being skipped: a conditional request would
+        //  leave the compiler's s_waitcnt counting to the worst case -- vmcnt(0) in front of every trip's MFMAs, i.e. no overlap)
+        int n = n_begin + wave, t0 = 0;
+        if (n < n_end) {
+            TCR_WG4_ISSUE(dA, rA, wA, n, t0)
+            for (;;) {
+                int n1 = n, t1 = t0;
+                TCR_WG4_ADVANCE(n1, t1)
+                const bool h1 = n1 < n_end;
+                { const int nl = h1 ? n1 : n, tl = h1 ? t1 : t0; TCR_WG4_ISSUE(dB, rB, wB, nl, tl) }
+                TCR_WG4_RUN(dA, rA, wA, t0)
+                if (!h1) break;
+                n = n1; t0 = t1;
+                TCR_WG4_ADVANCE(n, t0)
+                const bool h2 = n < n_end;
+                { const int nl = h2 ? n : n1, tl = h2 ? t0 : t1; TCR_WG4_ISSUE(dA, rA, wA, nl, tl) }
+                TCR_WG4_RUN(dB, rB, wB, t1)
+                if (!h2) break;
+            }
+        }
+#undef TCR_WG4_ISSUE
+#undef TCR_WG4_RUN
+#undef TCR_WG4_ADVANCE
+    } else {
+        for (int n = n_begin + wave; n < n_end; n += NWV) {
+            const float* xr = a.x + (size_t)n * a.cin * a.tpi + xlane;
+            const float* dr = a.dy + (size_t)n * a.cout_all * a.tpo;
+            const float* rr = FLY ? a.fly.raw + (size_t)n * a.cout_all * a.tpo : nullptr;
+            const bool safe = SAFE && n == a.batch - 1;
+            int t0 = 0;
+            for (; a.tout - t0 > 12; t0 += 16) wgrad4_trip<K, S, NCO, 16, SAFE, FLY>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax, rr, kk);
+            for (; t0 < a.tout; t0 += 8) wgrad4_trip<K, S, NCO, 8, SAFE, FLY>(acc, xr, dr, doff, cov, civ, q, t0, a.tout, safe, xmax, rr, kk);
+        }
     }
     // combine the waves in LDS (fixed order), then write the slab
     float* sa = s_acc + (wave >> 2) * SLAB;
@@ -2100,6 +2221,9 @@ static bool wgrad_lds_shape(int k, int cin, int cout) { return tune_get(TCR_TUNE
 // whichever kernel runs: the LDS-staged kernel is one workgroup per chunk (no input-tile dimension in its grid), 256 of them (512: +35 us
 // per TCResNet8 step, 1024: +110: slab traffic and the reduction).
 static int wgrad_nchunk(int k, int cin, int cout, int batch, bool fine) {
+    // (round 6, software-pipelined kernel, chunk counts by input-channel tiles: whole rounds of SIMD slots -- 170 chunks for three tiles,
+    //  102 for five -- measured +90 us per TCResNet14-1.5 step, half as many chunks +-0: the filter gradients are the main chain's
+    //  neighbours, and more of their waves on a CU cost the data-gradient chain more than they gain)
     if (!wgrad_lds_shape(k, cin, cout)) return wgrad_chunks_for(batch, fine);
     int n = ceil_div(batch, 4);
     if (n > 256) n = 256;
@@ -2180,6 +2304,22 @@ static int wgrad4_waves(int nco) {
 
 template <int K, int S, bool SAFE>
 static int launch_wgrad4_k(const WgradArgs& a, int nco, dim3 grid, hipStream_t s) {
+    // software-pipelined trips (round 6; TCR_TUNE_WGRAD_PIPE = 1: the one-piece trips): the four-wave instantiations of the 9-tap and
+    // 1-tap layers whose K x NCO accumulator tiles leave room for two operand sets (<= 27 tiles: every TC-ResNet launch)
+    if constexpr (!SAFE && (K == 9 || K == 1)) {
+        const bool four = !(K == 9 && a.fly.raw && wgrad4_waves(nco) != 4);
+        if (tune_get(TCR_TUNE_WGRAD_PIPE) != 1 && four && K * nco <= 27) {
+#define TCR_W4P(NCO_)                                                                                                           \
+            if (nco == NCO_) {                                                                                                  \
+                if (a.fly.raw) hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, NCO_, false, true, 4, true>), grid, dim3(256), 0, s, a);   \
+                else hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, NCO_, false, false, 4, true>), grid, dim3(256), 0, s, a);            \
+                return check_launch("conv_wgrad_mfma4_kernel");                                                                 \
+            }
+            TCR_W4P(1) TCR_W4P(2) TCR_W4P(3)
+            if constexpr (K == 1) { TCR_W4P(4) TCR_W4P(5) }
+#undef TCR_W4P
+        }
+    }
 #define TCR_W4(NCO_)                                                                                                            \
     if (a.fly.raw) hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, NCO_, SAFE, true>), grid, dim3(256), 0, s, a);            \
     else hipLaunchKernelGGL((conv_wgrad_mfma4_kernel<K, S, NCO_, SAFE, false>), grid, dim3(256), 0, s, a)

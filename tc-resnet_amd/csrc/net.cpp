@@ -2,6 +2,7 @@
 // audio_nets/tc_resnet.py:6-54), lays out the flat parameter / moving-stat arenas and the caller's
 // workspace, and sequences the gfx950 kernels for eval-mode forward, train-mode forward and
 // backward.  Host-only state; every device buffer belongs to the caller.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -588,11 +589,11 @@ static int side_stream(const tcr_net& net, hipStream_t caller, hipStream_t* out)
     if (!net.side) {
         net.side2 = shared_stream(1, caller);
         if (!(net.side = shared_stream(0, caller)) || !net.side2 ||
-            hipEventCreateWithFlags(&net.ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&net.ev_join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&net.ev_down, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&net.ev_down_dg, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&net.ev_join2, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&net.ev_fork, internal_event_flags()) != hipSuccess ||
+            hipEventCreateWithFlags(&net.ev_join, internal_event_flags()) != hipSuccess ||
+            hipEventCreateWithFlags(&net.ev_down, internal_event_flags()) != hipSuccess ||
+            hipEventCreateWithFlags(&net.ev_down_dg, internal_event_flags()) != hipSuccess ||
+            hipEventCreateWithFlags(&net.ev_join2, internal_event_flags()) != hipSuccess) {
             net.side = nullptr;
             set_error("cannot create the internal side stream");
             return TCR_ERR_HIP;
@@ -1011,6 +1012,11 @@ extern "C" int tcr_net_stage_sums(const tcr_net* net, int backward, int stage, v
 // ---- backward ---------------------------------------------------------------------------------
 namespace tcr {
 
+#if defined(TCR_NET_WHATIF_ENV)
+// TCR_WHATIF_BWD: 1 no chan_reduce, 2 no filter gradients (16: nor the first conv's), 4 no BN-backward apply, 8 no data gradients
+static int whatif_bwd() { static const int v = getenv("TCR_WHATIF_BWD") ? atoi(getenv("TCR_WHATIF_BWD")) : 0; return v; }
+#endif
+
 struct BwdUnit {
     int li;                 // conv layer
     const float* da;        // gradient wrt the unit's (post-activation) output
@@ -1068,6 +1074,9 @@ static int bwd_unit_pre(const TrainCtx& c, const BwdUnit& u, hipStream_t st, flo
     r.partial = partial;
     r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout); r.bcast = u.da_bcast;
     int nchunk = 0;
+#if defined(TCR_NET_WHATIF_ENV)     // (diagnostic builds: TCR_BUILD_EXTRA=-DTCR_NET_WHATIF_ENV; TCR_WHATIF_BWD bits skip launches -- wrong results, timing only)
+    if (whatif_bwd() & 1) return TCR_OK;
+#endif
     TCR_TRY(launch_chan_reduce(1, r, &nchunk, st));
     if (!c.sync_bn) return TCR_OK;
     return launch_chan_sums(partial, nchunk, l.cout, sums_of(c, u.li), st);
@@ -1096,6 +1105,11 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     const int tp = tcr_padded_len(l.tout), tpi = tcr_padded_len(l.tin);
     const int64_t kstride = align_up(l.cout, 64);
     float* dy = c.base + c.w.dyb[u.li];
+#if defined(TCR_NET_WHATIF_ENV)
+    if (whatif_bwd() & 4) parts &= ~BWD_BN;
+    if (whatif_bwd() & 2) parts &= ~BWD_WGRAD;
+    if (whatif_bwd() & 8) parts &= ~BWD_DGRAD;
+#endif
     if (parts & BWD_BN) {
         BnBwdFinalizeArgs f;
         f.partial = partial;
@@ -1124,6 +1138,8 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
         // (not this call)
     } else if (conv_wgrad_deferrable(l.k, l.cin, l.cout)) {     // slabs summed for all layers at once at the end of backward
         hipStream_t ws = u.li == 0 ? c.s : c.side;      // (the first conv's: the step's last, on the main stream -- see reduce_slabs)
+        if (ws == c.side && c.side != c.s && tune_get(TCR_TUNE_WGRAD_STREAM) == 4)      // conv_a units on the second internal stream (as the lazy chain)
+            for (const Block& b : net.blocks) if (u.li == b.a) ws = net.side2;
         if (bn_stream != c.s) ws = bn_stream;           // dy was written off the main stream (a shortcut unit): its filter gradient follows it there
         else if (ws != c.s) {                           // fork: the side stream waits for dy, the main stream carries on
             if (hipEventRecord(c.net->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(c.side, c.net->ev_fork, 0) != hipSuccess) {
@@ -1472,6 +1488,9 @@ static int lazy_wgrad(const TrainCtx& c, int li, hipStream_t ws) {
 #if defined(TCR_NET_WHATIF) && (TCR_NET_WHATIF & 1)      // timing what-if (scripts/build_whatif_src.sh): no filter-gradient launches; wrong results
     if (li != 0 || (TCR_NET_WHATIF & 2)) return TCR_OK;
 #endif
+#if defined(TCR_NET_WHATIF_ENV)
+    if ((whatif_bwd() & 2) && (li != 0 || (whatif_bwd() & 16))) return TCR_OK;
+#endif
     const tcr_net& net = *c.net;
     const ConvLayer& l = net.layers[li];
     const LazySrc src = lazy_src_of(c, li);
@@ -1520,6 +1539,9 @@ static int backward_lazy(const TrainCtx& c, float* grads, const LevelPlan* plan)
         return TCR_OK;
     };
     auto launch_d = [&](const BwdLazyArgs& a) -> int {
+#if defined(TCR_NET_WHATIF_ENV)
+        if (whatif_bwd() & 8) return TCR_OK;
+#endif
         const int rc = launch_bwd_lazy(a, nullptr, c.s);
         if (rc == 1) { set_error("tcr_net_backward: lazy data gradient does not cover a layer it was planned for"); return TCR_ERR_ARG; }
         return rc;
@@ -1674,8 +1696,8 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
             return rm.n ? launch_wgrad_reduce_multi(rm, st) : TCR_OK;
         };
         if (!split) return run(2, c.s);
-        if (down_stream != c.side &&                    // the shortcut units' slabs were written on the second internal stream
-            (hipEventRecord(net->ev_join2, down_stream) != hipSuccess || hipStreamWaitEvent(c.side, net->ev_join2, 0) != hipSuccess)) {
+        if ((down_stream != c.side || tune_get(TCR_TUNE_WGRAD_STREAM) == 4) &&      // slabs were written on the second internal stream
+            (hipEventRecord(net->ev_join2, net->side2) != hipSuccess || hipStreamWaitEvent(c.side, net->ev_join2, 0) != hipSuccess)) {
             set_error("tcr_net_backward: stream join failed");
             return TCR_ERR_HIP;
         }

@@ -1,6 +1,7 @@
 // Error plumbing and ABI bookkeeping shared by every translation unit.
 #include "tcr_common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 #include <mutex>
@@ -95,6 +96,13 @@ static void choose_streams(hipStream_t caller, hipStream_t (&out)[kSharedStreams
     if (ea) (void)hipEventDestroy(ea);
     if (eb) (void)hipEventDestroy(eb);
     (void)hipGetLastError();
+}
+
+// The fork / join events order streams of one device; no host thread ever waits on them.  A default event's record carries a SYSTEM-scope
+// release (cache write-back for host / peer visibility) that such an edge does not need: TCR_EVENT_FENCE=1 keeps it (A/B).
+unsigned internal_event_flags() {
+    static const bool fence = getenv("TCR_EVENT_FENCE") != nullptr && getenv("TCR_EVENT_FENCE")[0] == '1';
+    return fence ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
 }
 
 hipStream_t shared_stream(int idx, hipStream_t caller) {

@@ -27,6 +27,8 @@ int check_launch(const char* what);      // hipGetLastError -> TCR_OK / TCR_ERR_
 // the library's internal streams (0: filter gradients / shortcut branch, 1: classifier gradients, 2 / 3: tcr_internal_stream), chosen on first
 // use so that they do not share a hardware queue with `caller` (the stream of that first call) or each other; nullptr on failure
 hipStream_t shared_stream(int idx, hipStream_t caller);
+// flags of the library's fork / join events (stream-to-stream ordering on ONE device, never inspected by the host)
+unsigned internal_event_flags();
 int tune_get(int knob);                  // process-wide tuning knobs (tcr_tune)
 int device_cus();                        // compute units of the current device (cached per device; 256 on MI355X)
 

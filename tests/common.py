@@ -508,9 +508,10 @@ def check_dscnn_staged_equals_unstaged(lib, size, batch):
     p, s = D.init_params(D.net_def(size), seed=4)
     fe = make_frontend(lib, 640, 320, num_mfccs=10)
     base = R.synth_waveforms(min(batch, 32), seed=8)
-    reps = max(batch // base.shape[0], 1)
-    feat = fe(to_dev(lib, np.tile(base, (reps, 1))))
-    labels = to_dev(lib, np.tile(R.synth_labels(base.shape[0]), (reps, 1)))
+    reps = -(-batch // base.shape[0])           # (ceil: the REQUESTED batch runs -- ragged sizes reach the kernels' fallback dispatch)
+    feat = fe(to_dev(lib, np.tile(base, (reps, 1))[:batch]))
+    labels = to_dev(lib, np.tile(R.synth_labels(base.shape[0]), (reps, 1))[:batch])
+    assert feat.shape[0] == batch
     outs, seen = [], []
     for hook in (None, lambda sums: seen.append(sums.dtype)):
         net = T.DSCNN(size, fe.n_frames, 10, 12, lib=lib, device=device_of(lib))
@@ -532,9 +533,10 @@ def check_dscnn_pointwise_wgrad_kernels(lib, size, batch, knob_id=25):
     p, s = D.init_params(D.net_def(size), seed=4)
     fe = make_frontend(lib, 640, 320, num_mfccs=10)
     base = R.synth_waveforms(min(batch, 32), seed=8)
-    reps = max(batch // base.shape[0], 1)
-    feat = fe(to_dev(lib, np.tile(base, (reps, 1))))
-    labels = to_dev(lib, np.tile(R.synth_labels(base.shape[0]), (reps, 1)))
+    reps = -(-batch // base.shape[0])           # (ceil: the REQUESTED batch runs)
+    feat = fe(to_dev(lib, np.tile(base, (reps, 1))[:batch]))
+    labels = to_dev(lib, np.tile(R.synth_labels(base.shape[0]), (reps, 1))[:batch])
+    assert feat.shape[0] == batch
     grads = []
     try:
         for knob in (0, 1):

@@ -65,6 +65,7 @@ static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int)
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 #define hipEventDisableTiming 0x2
+#define hipEventDisableSystemFence 0x20000000
 #define hipStreamNonBlocking 0x1
 // (distinct handles, never dereferenced: the host code takes its multi-stream branches; launches still run in issue order)
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static char ids[64]; static int n = 0; *s = &ids[n++ & 63]; return hipSuccess; }

@@ -110,13 +110,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b, grad_tol=2e-5):
-    world = 2
+def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b, grad_tol=2e-5, world=2):
     mp.spawn(_worker, args=(world, _free_port(), sync_bn, str(tmp_path), kind, name, width, b), nprocs=world, join=True)
     r = [dict(np.load(tmp_path / f"rank{i}.npz")) for i in range(world)]
     # replicas hold identical gradients / parameters / moving statistics after the all-reduce
-    assert np.array_equal(r[0]["grads"], r[1]["grads"]) and np.array_equal(r[0]["params"], r[1]["params"])
-    assert abs(float(r[0]["loss"]) - float(r[1]["loss"])) == 0.0
+    for ri in r[1:]:
+        assert np.array_equal(r[0]["grads"], ri["grads"]) and np.array_equal(r[0]["params"], ri["params"])
+        assert abs(float(r[0]["loss"]) - float(ri["loss"])) == 0.0
     # collectives per step: ONE for the gradient arena (the loss sum rides in its tail), plus -- cross-replica BN only -- one per
     # dependency level in the forward and one in the backward: TC-ResNet 2 x (1 + 2 x blocks) (TCResNet8: 14, TCResNet14: 26; a block's
     # shortcut unit rides with the conv of its level), DS-CNN one per BN unit (2 x 11)
@@ -127,17 +127,18 @@ def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b, grad_tol=2e-5):
         elif name == "TCResNet14":
             assert int(ri["handoffs"]) == 26
     if sync_bn:
-        assert np.array_equal(r[0]["stats"], r[1]["stats"])
-    # single process, global batch of 2b, same dropout stream (masks are indexed by global sample id)
+        for ri in r[1:]:
+            assert np.array_equal(r[0]["stats"], ri["stats"])
+    # single process, global batch of world x b, same dropout stream (masks are indexed by global sample id)
     fe, net = _make(lib, name, width)
-    wav = torch.from_numpy(R.synth_waveforms(2 * b, seed=77)).to(fe.device)
-    lab = torch.from_numpy(R.synth_labels(2 * b)).to(fe.device)
+    wav = torch.from_numpy(R.synth_waveforms(world * b, seed=77)).to(fe.device)
+    lab = torch.from_numpy(R.synth_labels(world * b)).to(fe.device)
     logits, probs, loss_sum = net.forward_train(fe(wav), lab, keep_prob=0.5, seed=3)
     g = net.backward().cpu().numpy().copy()
     if sync_bn:
         # cross-replica statistics == the reference's single-device global-batch BN: everything matches
-        assert np.abs(np.concatenate([r[0]["logits"], r[1]["logits"]]) - logits.cpu().numpy()).max() < 2e-5
-        assert abs(float(r[0]["loss"]) - float(loss_sum) / (2 * b)) < 1e-5
+        assert np.abs(np.concatenate([ri["logits"] for ri in r]) - logits.cpu().numpy()).max() < 2e-5
+        assert abs(float(r[0]["loss"]) - float(loss_sum) / (world * b)) < 1e-5
         assert np.abs(r[0]["grads"] - g).max() < grad_tol * max(1.0, np.abs(g).max())
         net.sgd_momentum_step(0.1, 0.9, 0.001)
         assert np.abs(r[0]["params"] - net.params.cpu().numpy()).max() < max(1e-5, 0.1 * grad_tol * max(1.0, np.abs(g).max()))
@@ -150,6 +151,20 @@ def _two_replicas(lib, kind, tmp_path, sync_bn, name, width, b, grad_tol=2e-5):
 @pytest.mark.parametrize("sync_bn", [True, False])
 def test_two_replicas_match_global_batch(emu_lib, tmp_path, sync_bn):
     _two_replicas(emu_lib, "emu", tmp_path, sync_bn, "TCResNet8", 1.0, 3)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("sync_bn", [True, False])
+def test_many_replicas_match_global_batch(emu_lib, tmp_path, sync_bn, world):
+    """BASELINE configs[3]'s layout is EIGHT ranks: sample offsets (rank x b), dropout indices by global sample, the 1 / global_batch
+    scale, the level-by-level statistic hand-off and the moving-statistics update at world_size 4 and 8 (emulator, gloo) against the
+    single-process global batch."""
+    _two_replicas(emu_lib, "emu", tmp_path, sync_bn, "TCResNet8", 1.0, 2, world=world)
+
+
+def test_eight_replicas_match_global_batch_tcresnet14(emu_lib, tmp_path):
+    """configs[3]'s model (TCResNet14-1.5: identity and shortcut blocks, 26 hand-offs) at eight ranks with cross-replica statistics."""
+    _two_replicas(emu_lib, "emu", tmp_path, True, "TCResNet14", 1.5, 1, world=8)
 
 
 def test_two_replicas_match_global_batch_graph_engine(emu_lib, tmp_path):
@@ -224,31 +239,36 @@ def test_train_audio_cli_two_ranks_hip(hip_lib, tmp_path):
     _cli_two_ranks("hip", tmp_path, True)
 
 
-def _bench_plain_command(env_extra, batch, legs_ok=True):
-    """`python bench.py --gpus 2 ...` as a PLAIN command (no launcher, WORLD_SIZE unset): bench.py launches its own two ranks under
+BENCH_COLLECTIVES = {"forward": 0, "train": 1.0, "train_tcresnet14_1.5": 1.0, "train_tcresnet14_1.5_3010": 1.0}
+
+
+def _bench_plain_command(env_extra, batch, legs_ok=True, ranks=2):
+    """`python bench.py --gpus N ...` as a PLAIN command (no launcher, WORLD_SIZE unset): bench.py launches its own N ranks under
     torch.distributed.run, rank 0 prints the one JSON line."""
     import json
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--batch", str(batch),
-           "--no-cpu-baseline"]           # (several ranks: the default legs are the two training legs, configs[2] and configs[3])
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--prewarm", "0", "--batch", str(batch),
+           "--no-cpu-baseline"]           # (several ranks: the default legs are the training legs, configs[2] and configs[3] at 49 and 98 frames)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]              # ONE JSON line, from rank 0
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
-    assert out["config"]["global_batch"] == 2 * batch and out["value"] > 0
+    assert out["n_gpus"] == ranks and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == ranks * batch and out["value"] > 0
     if not legs_ok:
         return out
     assert "secondary_legs" not in out and "dscnn_l_forward" not in out
     # replicas only / ONE all-reduce of the gradient arena per step, for TCResNet8-1.0 and for BASELINE configs[3] (TCResNet14-1.5, global batch 4096 N at full size)
-    assert out["collectives_per_step"] == {"forward": 0, "train": 1.0, "train_tcresnet14_1.5": 1.0}
+    assert out["collectives_per_step"] == BENCH_COLLECTIVES
     assert out["train"]["value"] > 0 and out["train"]["collectives_per_step"] == 1.0
-    t14 = out["train_tcresnet14_1.5"]
-    assert t14["value"] > 0 and t14["collectives_per_step"] == 1.0 and f"global {2 * batch}" in t14["workload"] and "all-reduce" in t14["workload"]
+    for key in ("train_tcresnet14_1.5", "train_tcresnet14_1.5_3010"):      # (98 frames: the reference's own script for this model)
+        t14 = out[key]
+        assert t14["value"] > 0 and t14["collectives_per_step"] == 1.0 and f"global {ranks * batch}" in t14["workload"] and "all-reduce" in t14["workload"]
+    assert "98x40" in out["train_tcresnet14_1.5_3010"]["workload"]
     return out
 
 
@@ -256,6 +276,14 @@ def test_bench_self_launches_two_ranks(emu_lib):
     """CPU rehearsal (emulator build, gloo): the launcher, rendezvous, barriers, max-over-ranks timing and the JSON contract."""
     out = _bench_plain_command({"TCR_BENCH_EMU": EMU}, 4)
     assert "rehearsal" in out and out["collective_backend"].startswith("gloo")
+
+
+def test_bench_self_launches_eight_ranks(emu_lib):
+    """The driver's `bench.py --gpus 8`, rehearsed on the emulator over gloo: eight ranks' sample offsets, the 1 / global_batch scale of
+    the loss gradient, ONE all-reduce per training step for configs[2] and configs[3] -- so that the first run on an 8-GPU node cannot
+    fail on arithmetic or control flow (the collective there is RCCL; this is not a measurement)."""
+    out = _bench_plain_command({"TCR_BENCH_EMU": EMU, "OMP_NUM_THREADS": "1"}, 2, ranks=8)
+    assert "rehearsal" in out and out["collective_backend"].startswith("gloo") and out["config"]["global_batch"] == 16
 
 
 @pytest.mark.parametrize("how", ["raise", "hang"])
@@ -298,5 +326,5 @@ def test_bench_single_rank_goes_through_rccl(hip_lib):
     out = json.loads(lines[0])
     assert out["collective_backend"] == "RCCL (backend nccl)" and out["n_gpus"] == 1 and out["value"] > 0
     assert "secondary_legs" not in out, out["secondary_legs"]
-    assert out["train"]["value"] > 0 and out["train_tcresnet14_1.5"]["value"] > 0
-    assert out["collectives_per_step"] == {"forward": 0, "train": 1.0, "train_tcresnet14_1.5": 1.0}
+    assert out["train"]["value"] > 0 and out["train_tcresnet14_1.5"]["value"] > 0 and out["train_tcresnet14_1.5_3010"]["value"] > 0
+    assert out["collectives_per_step"] == BENCH_COLLECTIVES

@@ -87,7 +87,7 @@ def test_no_preprocessing_relayout(emu_lib):
 
 
 @pytest.mark.parametrize("fname,name,width", [("tcresnet8_1.0_4020.npz", "TCResNet8", 1.0), ("tcresnet8_1.0_3010.npz", "TCResNet8", 1.0),
-                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5)])
+                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5), ("tcresnet14_1.5_3010.npz", "TCResNet14", 1.5)])
 def test_eval_forward(emu_lib, fname, name, width):
     Cm.check_eval(emu_lib, fname, name, width)
 
@@ -102,6 +102,12 @@ def test_train_asymmetric_padding(emu_lib):
 
 def test_train_identity_shortcuts_and_wide_channels(emu_lib):
     Cm.check_train(emu_lib, "tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, steps=1)
+
+
+def test_train_configs3_at_the_reference_setting(emu_lib):
+    """TCResNet14-1.5 at 30 / 10 ms -> 98 frames, the reference's own script for this model (BASELINE configs[3];
+    scripts/commands/TCResNet14Model-1.5_mfcc_40_3010_0.001_mom_l1.sh:3): asymmetric SAME pads (3, 4) in the 36- / 48- / 72-channel blocks."""
+    Cm.check_train(emu_lib, "tcresnet14_1.5_3010.npz", "TCResNet14", 1.5, steps=1)
 
 
 def test_batch_independence_in_eval(emu_lib):

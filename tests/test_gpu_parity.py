@@ -150,13 +150,13 @@ def test_frontend_variants(hip_lib):
 
 
 @pytest.mark.parametrize("fname,name,width", [("tcresnet8_1.0_4020.npz", "TCResNet8", 1.0), ("tcresnet8_1.0_3010.npz", "TCResNet8", 1.0),
-                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5)])
+                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5), ("tcresnet14_1.5_3010.npz", "TCResNet14", 1.5)])
 def test_eval_forward(hip_lib, fname, name, width):
     Cm.check_eval(hip_lib, fname, name, width)
 
 
 @pytest.mark.parametrize("fname,name,width,steps", [("tcresnet8_1.0_4020.npz", "TCResNet8", 1.0, 3), ("tcresnet8_1.0_3010.npz", "TCResNet8", 1.0, 1),
-                                                    ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, 1)])
+                                                    ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5, 1), ("tcresnet14_1.5_3010.npz", "TCResNet14", 1.5, 1)])
 def test_train(hip_lib, fname, name, width, steps):
     Cm.check_train(hip_lib, fname, name, width, steps=steps)
 
@@ -522,7 +522,7 @@ def test_dscnn_pointwise_filter_gradient_unrolled_kernel_is_bitwise(hip_lib, siz
     Cm.check_dscnn_pointwise_geometries(hip_lib, size, batch, knob_id=25, alt=2)
 
 
-@pytest.mark.parametrize("size,batch", [("L", 36), ("M", 256)])         # (the row kernel takes whole blocks of 16 planes)
+@pytest.mark.parametrize("size,batch", [("L", 36), ("M", 256), ("L", 37)])         # (the row kernel takes whole blocks of 16 planes; 37 x 276 planes: its fallback, row and image kernels mixed within one step)
 def test_dscnn_depthwise_forward_kernels_agree(hip_lib, size, batch):
     Cm.check_dscnn_pointwise_geometries(hip_lib, size, batch, knob_id=32)
 
@@ -532,7 +532,7 @@ def test_dscnn_depthwise_filter_gradient_kernels_agree(hip_lib, size, batch):
     Cm.check_dscnn_pointwise_wgrad_kernels(hip_lib, size, batch, knob_id=31)
 
 
-@pytest.mark.parametrize("size,batch", [("L", 36), ("M", 256)])         # (the row kernel takes whole blocks of 16 planes)
+@pytest.mark.parametrize("size,batch", [("L", 36), ("M", 256), ("L", 37)])         # (37 x 276 planes are not whole blocks of 16: the fallback dispatch)
 def test_dscnn_depthwise_data_gradient_kernels_agree(hip_lib, size, batch):
     Cm.check_dscnn_pointwise_geometries(hip_lib, size, batch, knob_id=30)
 

@@ -65,7 +65,7 @@ def test_param_counts():
 
 
 @pytest.mark.parametrize("fname,name,width", [("tcresnet8_1.0_4020.npz", "TCResNet8", 1.0), ("tcresnet8_1.0_3010.npz", "TCResNet8", 1.0),
-                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5)])
+                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5), ("tcresnet14_1.5_3010.npz", "TCResNet14", 1.5)])
 def test_net_matches_golden_and_torch(fname, name, width):
     fx = Cm.load(fname)
     arch, p, s = Cm.fixture_params(fx, name, width)
@@ -87,7 +87,7 @@ def test_net_matches_golden_and_torch(fname, name, width):
 
 
 @pytest.mark.parametrize("fname,name,width", [("tcresnet8_1.0_4020.npz", "TCResNet8", 1.0), ("tcresnet8_1.0_3010.npz", "TCResNet8", 1.0),
-                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5)])
+                                              ("tcresnet14_1.5_4020.npz", "TCResNet14", 1.5), ("tcresnet14_1.5_3010.npz", "TCResNet14", 1.5)])
 def test_oracle_against_pinned_reference(fname, name, width):
     """Runs only on fixtures that oracle/pin_from_reference.py has extended with `tf:*` keys (outputs of the REAL reference under
     TF 1.13): the restatement must reproduce them.  In this image no fixture is pinned (TF cannot run): the test then documents, by
