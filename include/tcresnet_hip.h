@@ -412,7 +412,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_TRAIN_FWD = 8,   /* train-mode forward: 0 group-resident phases (train_fused.hip; BN affine / ReLU / residual applied while the next conv stages its input, statistics from the conv epilogue), 1 per-layer kernels (conv -> statistics -> finalize -> normalise) */
        TCR_TUNE_TRAIN_BWD = 9,   /* TC-ResNet backward: 0 "lazy" BN backward (bwd_lazy.hip: dy never written -- the data-gradient kernel applies BN backward while it stages a group of utterances into LDS, runs every stride phase and the block's shortcut conv from that image and leaves the next unit's sums from its epilogue; the filter-gradient kernels compute dy where they load it; default for nets of <= 48 channels, where it measured faster; 3: for every net it covers), 1 the group-resident phases of round 2 (train_fused_bwd.hip), 2 the per-layer chain (reduce -> finalize + bn_bwd_apply -> data gradient per phase; the default until round 3) */
        TCR_TUNE_PHASE_CFG = 10,  /* training phases: waves per workgroup * 100 + utterances per group (0: default) */
-       TCR_TUNE_BWD_BN_FUSED = 11, /* BN backward: 0 finalize folded into the apply pass for layers of <= 48 channels (one launch; default), 1 finalize + apply kernels, >= 2: folded everywhere, that many workgroups aimed at */
+       TCR_TUNE_BWD_BN_FUSED = 11, /* BN backward: 0 finalize folded into the apply pass (one launch, ~512 workgroups; round 6: for every layer width -- rounds 3-5: <= 48 channels, 1024 workgroups), 1 finalize + apply kernels, >= 2: folded, that many workgroups aimed at */
        TCR_TUNE_BWD_MASK = 12,   /* BN backward: 0 a unit's own ReLU mask recomputed from its raw conv output ([fmaf(y, scale, shift) > 0], bitwise the activation's; default), 1 read back from the stored activation, 2: as 0 with the scalar (one element per thread) elementwise BN kernels instead of the 16-byte ones (bitwise the same), 3: also the scalar per-channel reduction kernel (another summation order), 4: the 16-byte reduction kernel also where its grid would be small (tests) */
        TCR_TUNE_FE_GRID = 13,    /* front-end: cap on the number of persistent workgroups (0: two per CU). 256 = one per CU, which leaves half of every CU's LDS and registers to a co-resident network kernel on another stream */
        TCR_TUNE_FUSED_GRID = 14, /* fused eval network: cap on the number of persistent workgroups (0: as many as the LDS allows per CU) */
@@ -430,7 +430,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_DEPLOY_F32 = 26, /* deploy-path MFCC (method 2): 0 the float64 kernel (one workgroup per frame; TF's ops compute in double; default), 1 the float32 throughput kernels with the op's filterbank / log floor (rounds 3-4: up to 0.5 off on noise-free tones, where the empty bands are pure round-off) */
        TCR_TUNE_NET_SMALL = 27,  /* eval network, TCResNet8-1.0 at 49 frames, batches of <= 64 utterances: 0 the small-batch kernel (one utterance per 8-wave workgroup, each phase's weights DMA-copied into LDS one phase ahead; default), 1 the throughput kernel at one utterance per group (rounds 2-4).  Bitwise the same outputs. */
        TCR_TUNE_PW_POS = 28,     /* wide pointwise convs (DS-CNN-L, 276 channels; forward, data gradient): 0 the nine-tile kernel built for <= 128 registers = four waves per SIMD, its weight chunks copied global -> LDS by the DMA path and its LDS fragment reads one step ahead of the MFMAs (default since round 5), 1 the unconstrained build of rounds 3-4 (92 VGPRs + 72 AGPRs, three waves per SIMD, register-staged weights), 2 the <= 128-register build with register-staged weights.  Bitwise the same results. */
-       TCR_TUNE_BN_APPLY = 29,   /* BN-backward apply pass over large tensors (DS-CNN): 0 four float4 per thread and operand, per-channel coefficients staged in LDS (default since round 5), 1 the one-float4-per-thread kernel of rounds 2-4.  Bitwise the same dy. */
+       TCR_TUNE_BN_APPLY = 29,   /* BN-backward apply passes: 0 four float4 per thread and operand, per-channel coefficients staged in LDS (large tensors, DS-CNN: default since round 5; the finalize-folded pass of the TC-ResNet chain, bn_bwd_apply_fused_kernel: round 6), 1 the one-float4-per-thread loops of rounds 2-5.  Bitwise the same dy. */
        TCR_TUNE_DW_DGRAD = 30,   /* DS-CNN depthwise data gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (dz / raw / dx blocks of 16 planes as contiguous float4 through LDS, one lane per map row; default since round 5), 1 the zero-padded-image kernel of rounds 2-4.  Bitwise the same dx and backward sums. */
        TCR_TUNE_DW_WGRAD = 31,   /* DS-CNN depthwise filter gradient, stride-1 units on 13 x 5 maps: 0 the row kernel (a wave owns four channels, their x / dz planes as contiguous float4 through wave-private LDS; default since round 5), 1 the gather kernel of rounds 2-4 (another summation order: equal to rounding). */
        TCR_TUNE_DW_FWD = 32,     /* DS-CNN depthwise conv (eval and training forward), stride-1 layers on 13 x 5 maps: 0 the row kernels (x / y blocks of 16 planes as contiguous float4 through LDS; also the global pooling's block-copy kernel and the row-per-lane stencil of the fused conv_1 + depthwise eval kernel; default since round 5), 1 the zero-padded-image kernels of rounds 2-4.  Bitwise the same outputs and statistics. */

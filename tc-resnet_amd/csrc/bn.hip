@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
 
 int chan_reduce_chunks(int npos) {      // upper bound of the partial rows (workspace sizing)
     int n = ceil_div(npos, 512);        // >= 2 positions per thread; many short workgroups hide the load latency
-    if (n > 512) n = 512;
+    if (n > 512) n = 512;               // (round 6, re-measured with the faster apply pass: 128 / 256 / 384 rows are within noise of 512)
     if (n < 1) n = 1;
     return n;
 }
@@ -671,6 +671,7 @@ int launch_bn_bwd_apply(const BnBwdApplyArgs& a0, hipStream_t s) {
 // its [slab][kFG][Tp] block (contiguous per utterance).  Slab 0 of every channel group writes dgamma / dbeta.
 constexpr int kFG = 8;                  // channels per workgroup (divides kBnCB: a group never straddles a finalize block)
 constexpr int kFusedMaxParts = 64;
+constexpr int kFusedU = 4;              // float4 per thread, operand and trip of the wide apply loop
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFinalizeArgs f, const BnBwdApplyArgs a, int utt_per_slab, int batch, int vec4) {
     __shared__ double s_slices[kFusedMaxParts * 2 * kFG];
@@ -721,6 +722,77 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFina
     const int e_per = gw * a.tp;                                // this group's floats of one utterance (contiguous)
     const float inv_e = 1.0f / (float)e_per;
     const int total = (n1 - n0) * e_per;
+    if (vec4 == 2) {
+        // Round 6: kFusedU float4 per thread, operand and trip, every load of a trip requested before the first is used, and the
+        // group's per-channel coefficients (k1, k2, k3, mean, own-mask scale / shift) read from an LDS table as two 16-byte rows per
+        // float4 -- the one-float4 loop below keeps 32 B per lane in flight and gathers three coefficients per ELEMENT from global
+        // memory (the apply passes ran at ~3 TB/s where a float4 copy measures 6.3).  Same expression per element: bitwise the same dy.
+        constexpr int U = kFusedU;
+        __shared__ __attribute__((aligned(16))) float s_tab[(kFG + 1) * 8];
+        for (int i = threadIdx.x; i < (kFG + 1) * 8; i += 256) {
+            const int cl = min(i >> 3, gw - 1), k = i & 7;
+            float v = 0.f;
+            if (k < 3) v = s_k[k][cl];
+            else if (k == 3) v = a.mean[g0 + cl];
+            else if (k == 4) v = a.self_scale ? a.self_scale[g0 + cl] : 0.f;         // (no own mask: fmaf(y, 0, 1) > 0 always)
+            else if (k == 5) v = a.self_scale ? a.self_shift[g0 + cl] : 1.f;
+            s_tab[i] = v;
+        }
+        __syncthreads();
+        const bool has_m1 = a.m1 != nullptr, has_m2 = a.m2 != nullptr;
+        for (int base = threadIdx.x * 4; base < total; base += 1024 * U) {
+            bn_f4 y4[U], d4[U], m14[U], m24[U];
+            size_t i0[U];
+            int e0[U], c0[U], nn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = min(base + u * 1024, total - 4);        // (past the slab's end: its last float4 again, not stored)
+                int nl = (int)(((float)idx + 0.5f) * inv_e);
+                nl += (nl + 1) * e_per <= idx ? 1 : (nl * e_per > idx ? -1 : 0);
+                e0[u] = idx - nl * e_per;                               // (e_per % 4 == 0: the four stay inside one utterance)
+                int cc = (int)(((float)e0[u] + 0.5f) * a.inv_tp);
+                cc += (cc + 1) * a.tp <= e0[u] ? 1 : (cc * a.tp > e0[u] ? -1 : 0);
+                c0[u] = cc;
+                nn[u] = n0 + nl;
+                i0[u] = ((size_t)nn[u] * a.c + g0) * a.tp + e0[u];
+                y4[u] = *reinterpret_cast<const bn_f4*>(a.y + i0[u]);
+                d4[u] = (bn_f4){0.f, 0.f, 0.f, 0.f};
+                m14[u] = (bn_f4){1.f, 1.f, 1.f, 1.f};
+                m24[u] = m14[u];
+                if (!a.bcast) d4[u] = *reinterpret_cast<const bn_f4*>(a.da + i0[u]);
+                if (has_m1) m14[u] = *reinterpret_cast<const bn_f4*>(a.m1 + i0[u]);
+                if (has_m2) m24[u] = *reinterpret_cast<const bn_f4*>(a.m2 + i0[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (base + u * 1024 >= total) break;
+                const bn_f4 ka = *reinterpret_cast<const bn_f4*>(s_tab + c0[u] * 8), kb = *reinterpret_cast<const bn_f4*>(s_tab + c0[u] * 8 + 4);
+                const bn_f4 na = *reinterpret_cast<const bn_f4*>(s_tab + (c0[u] + 1) * 8), nb = *reinterpret_cast<const bn_f4*>(s_tab + (c0[u] + 1) * 8 + 4);
+                bn_f4 o4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = e0[u] + q;
+                    const bool nx = e >= (c0[u] + 1) * a.tp;
+                    const int cl = nx ? c0[u] + 1 : c0[u];
+                    const int tt = e - cl * a.tp - kHalo;
+                    const float k1 = nx ? na[0] : ka[0], k2 = nx ? na[1] : ka[1], k3 = nx ? na[2] : ka[2], mu = nx ? na[3] : ka[3];
+                    const float ssc = nx ? nb[0] : kb[0], ssh = nx ? nb[1] : kb[1];
+                    float v = 0.f;
+                    if (tt >= 0 && tt < a.t) {
+                        float dz = a.bcast ? a.da[(size_t)nn[u] * a.c + g0 + cl] : d4[u][q];
+                        if (has_m1 && !(m14[u][q] > 0.f)) dz = 0.f;
+                        if (has_m2 && !(m24[u][q] > 0.f)) dz = 0.f;
+                        const float yv = y4[u][q];
+                        if (a.self_scale && !(fmaf(yv, ssc, ssh) > 0.f)) dz = 0.f;
+                        v = k1 * (dz - k2 - (yv - mu) * k3);
+                    }
+                    o4[q] = v;
+                }
+                *reinterpret_cast<bn_f4*>(a.dy + i0[u]) = o4;
+            }
+        }
+        return;
+    }
     if (vec4) {                                                 // four consecutive elements per thread and trip (see bn_apply4_kernel)
         for (int idx = threadIdx.x * 4; idx < total; idx += 1024) {
             int nl = (int)(((float)idx + 0.5f) * inv_e);
@@ -781,8 +853,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFina
 // returns 1 (nothing launched) where the pair of kernels is needed: pre-reduced sums (sync BN), accumulate mode, odd channel blocks
 int launch_bn_bwd_apply_fused(const BnBwdFinalizeArgs& f, const BnBwdApplyArgs& a0, hipStream_t s) {
     if (f.nchunk <= 0 || a0.accumulate || tune_get(TCR_TUNE_BWD_BN_FUSED) == 1) return 1;
-    if (a0.c > 48 && tune_get(TCR_TUNE_BWD_BN_FUSED) == 0) return 1;       // measured (scripts/ab_bwd_bn.py): -1.6 % / -2.5 % per TCResNet8 step
-                                                                            // (49 / 98 frames), but +1.5 % with the 72-channel layers of TCResNet14-1.5
+    // (rounds 3-5: folded only for layers of <= 48 channels -- with the one-float4 apply loop the 72-channel layers of TCResNet14-1.5
+    //  measured +1.5 % per step folded.  Round 6, wide apply loop: folded everywhere and ~512 workgroups instead of 1024 --
+    //  TCResNet14-1.5 step 2519 -> 2480 us at 49 frames (384 / 512 / 768 workgroups alike, 256: 2512), 4096 -> 4048 at 98.)
     for (int c0 = 0; c0 < a0.c; c0 += kBnCB)
         if (512 / (2 * min(kBnCB, a0.c - c0)) > kFusedMaxParts) return 1;
     BnBwdApplyArgs a = a0;
@@ -791,14 +864,16 @@ int launch_bn_bwd_apply_fused(const BnBwdFinalizeArgs& f, const BnBwdApplyArgs& 
     const int batch = (int)(a.total / per_utt);
     if (kFG * a.tp >= (1 << 20) || batch >= (1 << 20)) return 1;
     const int groups = ceil_div(a.c, kFG);
-    int want = tune_get(TCR_TUNE_BWD_BN_FUSED) >= 2 ? tune_get(TCR_TUNE_BWD_BN_FUSED) : 1024;       // workgroups aimed at
+    int want = tune_get(TCR_TUNE_BWD_BN_FUSED) >= 2 ? tune_get(TCR_TUNE_BWD_BN_FUSED) : 512;        // workgroups aimed at
     int nslab = max(1, min(batch, want / groups));
     const int ups = ceil_div(batch, nslab);
     nslab = ceil_div(batch, ups);
     // 16-byte accesses: every channel group's block of an utterance is a multiple of four floats and starts on one
     const int vec4 = ((kFG * a.tp) % 4 == 0 && (a.c * a.tp) % 4 == 0 && ((a.c % kFG) * a.tp) % 4 == 0 &&
                       bn_vec4_ok(a.y, a.bcast ? nullptr : a.da, a.m1, a.m2, per_utt) && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(nslab, groups), dim3(256), 0, s, f, a, ups, batch, vec4);
+    // (2: the wide loop -- TCR_TUNE_BN_APPLY = 1 keeps the one-float4 loop; needs a slab of at least one float4)
+    const int vmode = (vec4 && tune_get(TCR_TUNE_BN_APPLY) != 1 && ups * kFG * a.tp >= 4) ? 2 : vec4;
+    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(nslab, groups), dim3(256), 0, s, f, a, ups, batch, vmode);
     return check_launch("bn_bwd_apply_fused_kernel");
 }
 

@@ -1105,6 +1105,9 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     const int tp = tcr_padded_len(l.tout), tpi = tcr_padded_len(l.tin);
     const int64_t kstride = align_up(l.cout, 64);
     float* dy = c.base + c.w.dyb[u.li];
+    // (see BWD_BN below; needs this call to do both halves, the unit's own mask recomputed from raw, and a kernel that takes WgradFly)
+    const bool fly_first = l.in_act < 0 && (parts & BWD_BN) && (parts & BWD_WGRAD) && !u.da_bcast && u.m1 == nullptr && u.m2 == nullptr && u.self_ss != nullptr &&
+                           conv_wgrad_deferrable(l.k, l.cin, l.cout) && conv_wgrad_fly_covers(l.k, l.stride, false);
 #if defined(TCR_NET_WHATIF_ENV)
     if (whatif_bwd() & 4) parts &= ~BWD_BN;
     if (whatif_bwd() & 2) parts &= ~BWD_WGRAD;
@@ -1125,11 +1128,19 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
         a.k1 = f.k1; a.k2 = f.k2; a.k3 = f.k3; a.dy = dy;
         a.total = (int64_t)c.batch * l.cout * tp; a.c = l.cout; a.t = l.tout; a.tp = tp; a.bcast = u.da_bcast;
         if (u.self_ss) { a.self_scale = u.self_ss; a.self_shift = u.self_ss + u.self_cpad; }
+        if (fly_first) {
+            // The FIRST conv's dy feeds nothing but its own filter gradient (no gradient flows into the features) and that kernel
+            // is the step's tail, alone on the main stream: dy = k1 (dz - k2 - (raw - mean) k3) is built where the filter gradient
+            // loads it (WgradFly, as in the lazy chain) instead of by an apply pass that writes it and a kernel that reads it back
+            // -- the finalize alone leaves the coefficients (round 6: -25 us at the end of a TCResNet14-1.5 step).
+            TCR_TRY(launch_bn_bwd_finalize(f, bn_stream));
+        } else {
         const int rc = launch_bn_bwd_apply_fused(f, a, bn_stream);      // finalize inside the apply pass where that applies
         if (rc != TCR_OK && rc != 1) return rc;
         if (rc == 1) {
             TCR_TRY(launch_bn_bwd_finalize(f, bn_stream));
             TCR_TRY(launch_bn_bwd_apply(a, bn_stream));
+        }
         }
     }
     // weight gradient
@@ -1147,6 +1158,13 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
                 return TCR_ERR_HIP;
             }
         }
+        if (fly_first) {
+            WgradFly fly;
+            fly.raw = c.base + c.w.raw[u.li]; fly.k1 = kc; fly.k2 = kc + kstride; fly.k3 = kc + 2 * kstride; fly.mean = c.base + c.w.mean[u.li];
+            fly.self_scale = u.self_ss; fly.self_shift = u.self_ss + u.self_cpad;
+            TCR_TRY(launch_conv_wgrad_partial(l.k, l.stride, l.pad_lo, x, u.da, c.base + c.w.wg[u.li], c.batch, l.cin, l.cout, tpi, l.tout, tp,
+                                              nullptr, ws, wgrad_fine(l), l.in_act >= 0, &fly));
+        } else
         TCR_TRY(launch_conv_wgrad_partial(l.k, l.stride, l.pad_lo, x, dy, c.base + c.w.wg[u.li], c.batch, l.cin, l.cout, tpi, l.tout, tp,
                                           nullptr, ws, wgrad_fine(l), l.in_act >= 0));
     } else {

@@ -662,3 +662,20 @@ def test_lazy_backward_staging_forms_are_bitwise(hip_lib):
 @pytest.mark.gpu
 def test_filter_gradient_waves_per_workgroup_agree(hip_lib):
     Cm.check_backward_knob_variants(hip_lib, 20, (8, 12, 16), False, batch=4096)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 4096, 49), ("TCResNet14", 1.5, 4096, 49), ("TCResNet14", 1.5, 1031, 98), ("TCResNet8", 1.0, 5, 98)])
+def test_pipelined_filter_gradient_is_bitwise(hip_lib, name, width, batch, t):
+    Cm.check_backward_knob_variants(hip_lib, 33, (1,), True, name=name, width=width, batch=batch, t=t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,width,batch", [("TCResNet8", 1.0, 4096), ("TCResNet14", 1.5, 4096), ("TCResNet14", 1.5, 37)])
+def test_wide_bn_backward_apply_loop_is_bitwise(hip_lib, name, width, batch):
+    for mask in (0, 1):
+        try:
+            hip_lib.tcr_tune(9, 2); hip_lib.tcr_tune(12, mask)
+            Cm.check_backward_knob_variants(hip_lib, 29, (1,), True, name=name, width=width, batch=batch, t=49)
+        finally:
+            hip_lib.tcr_tune(9, 0); hip_lib.tcr_tune(12, 0)
