@@ -413,7 +413,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_TRAIN_BWD = 9,   /* TC-ResNet backward: 0 "lazy" BN backward (bwd_lazy.hip: dy never written -- the data-gradient kernel applies BN backward while it stages a group of utterances into LDS, runs every stride phase and the block's shortcut conv from that image and leaves the next unit's sums from its epilogue; the filter-gradient kernels compute dy where they load it; default for nets of <= 48 channels, where it measured faster; 3: for every net it covers), 1 the group-resident phases of round 2 (train_fused_bwd.hip), 2 the per-layer chain (reduce -> finalize + bn_bwd_apply -> data gradient per phase; the default until round 3) */
        TCR_TUNE_PHASE_CFG = 10,  /* training phases: waves per workgroup * 100 + utterances per group (0: default) */
        TCR_TUNE_BWD_BN_FUSED = 11, /* BN backward: 0 finalize folded into the apply pass (one launch, ~512 workgroups; round 6: for every layer width -- rounds 3-5: <= 48 channels, 1024 workgroups), 1 finalize + apply kernels, >= 2: folded, that many workgroups aimed at */
-       TCR_TUNE_BWD_MASK = 12,   /* BN backward: 0 a unit's own ReLU mask recomputed from its raw conv output ([fmaf(y, scale, shift) > 0], bitwise the activation's; default), 1 read back from the stored activation, 2: as 0 with the scalar (one element per thread) elementwise BN kernels instead of the 16-byte ones (bitwise the same), 3: also the scalar per-channel reduction kernel (another summation order), 4: the 16-byte reduction kernel also where its grid would be small (tests) */
+       TCR_TUNE_BWD_MASK = 12,   /* BN backward: 0 a unit's own ReLU mask recomputed from its raw conv output ([fmaf(y, scale, shift) > 0], bitwise the activation's; default), 1 read back from the stored activation, 2: as 0 with the scalar (one element per thread) elementwise BN kernels instead of the 16-byte ones (bitwise the same), 3: also the scalar per-channel reduction kernel (another summation order), 4: the 16-byte reduction kernel also where its grid would be small (tests), 5: as 0 with the lazy backward's last block reduced by two launches (conv_b's unit, then the shortcut's reading the masked gradient back) instead of one two-unit pass (round 6; bitwise the same rows) */
        TCR_TUNE_FE_GRID = 13,    /* front-end: cap on the number of persistent workgroups (0: two per CU). 256 = one per CU, which leaves half of every CU's LDS and registers to a co-resident network kernel on another stream */
        TCR_TUNE_FUSED_GRID = 14, /* fused eval network: cap on the number of persistent workgroups (0: as many as the LDS allows per CU) */
        TCR_TUNE_DS_TRAIN = 15,   /* DS-CNN training: 0 normalised activations never materialised where every consumer has the form (172 / 276-channel nets): consumers apply BN + ReLU to the raw conv outputs, batch statistics and backward sums come from conv / data-gradient epilogues (default); 1 the materialising path (statistics reduce -> finalize -> normalise, backward reduce); 2: as 0, but every unit's BN backward by a bn_bwd_apply pass (default 0: conv_1's filter gradient computes dy where it reads it); 3: as 0, the depthwise units' kernels too; 4: as 0, and the pointwise units' data-gradient kernel applies the BN backward while staging and writes dy for the filter gradient instead of a bn_bwd_apply pass (measured slower) */

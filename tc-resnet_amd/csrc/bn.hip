@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
 #pragma unroll
     for (int c = 0; c < CT; ++c) { q1[c] = 0.f; q2[c] = 0.f; }
     float mu[CT], is[CT], ssc[CT], ssh[CT];
-    const bool self = MODE == 1 && a.self_scale != nullptr;
-    if (MODE == 1) {
+    const bool self = MODE >= 1 && a.self_scale != nullptr;
+    if (MODE >= 1) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const int cc = min(c0 + c, a.c - 1);
@@ -65,6 +65,19 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
             is[c] = a.invstd[cc];
             ssc[c] = self ? a.self_scale[cc] : 0.f;
             ssh[c] = self ? a.self_shift[cc] : 1.f;
+        }
+    }
+    // MODE 2: the second unit (same dz, its own mask and xhat)
+    float r1[MODE == 2 ? CT : 1], r2[MODE == 2 ? CT : 1], mu2[MODE == 2 ? CT : 1], is2[MODE == 2 ? CT : 1], sc2[MODE == 2 ? CT : 1], sh2[MODE == 2 ? CT : 1];
+    if (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int cc = min(c0 + c, a.c - 1);
+            r1[MODE == 2 ? c : 0] = 0.f; r2[MODE == 2 ? c : 0] = 0.f;
+            mu2[MODE == 2 ? c : 0] = a.mean2[cc];
+            is2[MODE == 2 ? c : 0] = a.invstd2[cc];
+            sc2[MODE == 2 ? c : 0] = a.self_scale2[cc];
+            sh2[MODE == 2 ? c : 0] = a.self_shift2[cc];
         }
     }
     const int blk0 = blockIdx.x * a.pos_per_block;
@@ -91,6 +104,13 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
                 if (a.g_out) a.g_out[o] = dz;
                 q1[c] += dz;
                 q2[c] = fmaf(dz, (yv - mu[c]) * is[c], q2[c]);
+                if (MODE == 2) {            // (the expressions of a MODE 1 pass over g_out with this unit's self mask)
+                    const float y2 = a.y2[o];
+                    float dz2 = dz;
+                    if (!(fmaf(y2, sc2[MODE == 2 ? c : 0], sh2[MODE == 2 ? c : 0]) > 0.f)) dz2 = 0.f;
+                    r1[MODE == 2 ? c : 0] += dz2;
+                    r2[MODE == 2 ? c : 0] = fmaf(dz2, (y2 - mu2[MODE == 2 ? c : 0]) * is2[MODE == 2 ? c : 0], r2[MODE == 2 ? c : 0]);
+                }
             }
         }
     }
@@ -109,6 +129,26 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
         if (c0 + c < a.c) {
             const float v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
             a.partial[((size_t)blockIdx.x * 2 + which) * a.c + c0 + c] = v;
+        }
+    }
+    if (MODE == 2) {                        // the second unit's row: the same wave / slice order
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            r1[MODE == 2 ? c : 0] = wave_sum(r1[MODE == 2 ? c : 0]);
+            r2[MODE == 2 ? c : 0] = wave_sum(r2[MODE == 2 ? c : 0]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) { s_red[wave][c] = r1[MODE == 2 ? c : 0]; s_red[wave][CT + c] = r2[MODE == 2 ? c : 0]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * CT) {
+            const int c = threadIdx.x % CT, which = threadIdx.x / CT;
+            if (c0 + c < a.c) {
+                const float v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+                a.partial2[((size_t)blockIdx.x * 2 + which) * a.c + c0 + c] = v;
+            }
         }
     }
 }
@@ -221,7 +261,7 @@ int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t 
     const int nt4 = ceil_div(ceil_div(8 * a.tp, 4), 64) * 64;
     // (its workgroups are short -- (8 Tp / 4) threads walking a few utterances -- so it needs many of them: DS-CNN-L, 276 channels:
     //  -3 % on the step; TC-ResNet's 16-48 channels leave it ~1500 waves for 256 CUs: +8 % on the TCResNet8 step -> scalar kernel there)
-    const bool vec = !a.g_out && a.pos_per_block % a.t == 0 && nt4 <= 512 && ((int64_t)grid.x * grid.y * (nt4 / 64) >= 16 * 256 || tune_get(TCR_TUNE_BWD_MASK) == 4) && (8 * a.tp) % 4 == 0 && (a.c * a.tp) % 4 == 0 &&
+    const bool vec = mode != 2 && !a.g_out && a.pos_per_block % a.t == 0 && nt4 <= 512 && ((int64_t)grid.x * grid.y * (nt4 / 64) >= 16 * 256 || tune_get(TCR_TUNE_BWD_MASK) == 4) && (8 * a.tp) % 4 == 0 && (a.c * a.tp) % 4 == 0 &&
                      ((a.c % 8) * a.tp) % 4 == 0 && bn_vec4_ok(a.y, (mode == 1 && !a.bcast) ? a.da : nullptr, a.m1, a.m2, a.c * a.tp, true);
     if (vec) {
         if (mode == 0) hipLaunchKernelGGL((chan_reduce4_kernel<0>), grid, dim3(nt4), 0, s, a);
@@ -229,6 +269,7 @@ int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t 
         return check_launch("chan_reduce4_kernel");
     }
     if (mode == 0) hipLaunchKernelGGL((chan_reduce_kernel<0>), grid, dim3(256), 0, s, a);
+    else if (mode == 2) hipLaunchKernelGGL((chan_reduce_kernel<2>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((chan_reduce_kernel<1>), grid, dim3(256), 0, s, a);
     return check_launch("chan_reduce_kernel");
 }

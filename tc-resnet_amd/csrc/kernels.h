@@ -388,6 +388,15 @@ struct ChanReduceArgs {
     const float* self_shift;
     float* g_out;           // MODE 1 (scalar kernel): also store dz at the element's place ([B][C][Tp] interior) -- the lazy backward's last block,
                             // whose pooled, broadcast gradient becomes a masked tensor on the way; or nullptr
+    // MODE 2 (scalar kernel; the lazy backward's last block, round 6): a SECOND unit's sums in the same pass -- the block's shortcut
+    // unit takes the same dz under its own mask [fmaf(y2, self_scale2, self_shift2) > 0] with xhat from y2: what a second launch
+    // reading g_out back computes, one launch earlier in the step's dependency chain
+    const float* y2;
+    const float* mean2;
+    const float* invstd2;
+    const float* self_scale2;
+    const float* self_shift2;
+    float* partial2;
 };
 
 struct BnFinalizeArgs {

@@ -1522,7 +1522,9 @@ static int lazy_wgrad(const TrainCtx& c, int li, hipStream_t ws) {
 
 // Sums of the last block's units.  conv_b's reduction reads the head's pooled gradient (broadcast over time) under the block's ReLU
 // mask and WRITES that masked tensor on the way (the gz every later reader takes); the shortcut's reads it back with its own mask.
-static int lazy_last_block_sums(const TrainCtx& c, int li, hipStream_t st) {
+// with_down (round 6): both units in ONE pass (chan_reduce_kernel<2>: the shortcut's sums from the dz in registers instead of from a
+// second launch that reads it back) -- bitwise the two launches' rows, one launch less at the head of the backward's chain.
+static int lazy_last_block_sums(const TrainCtx& c, int li, hipStream_t st, bool with_down = false) {
     const tcr_net& net = *c.net;
     const ConvLayer& l = net.layers[li];
     const Block& lastb = net.blocks.back();
@@ -1538,6 +1540,13 @@ static int lazy_last_block_sums(const TrainCtx& c, int li, hipStream_t st) {
     r.partial = c.base + (is_down_unit(net, li) ? c.w.partial2 : c.w.partial);
     r.npos = c.batch * l.tout; r.c = l.cout; r.t = l.tout; r.tp = tcr_padded_len(l.tout);
     int nchunk = 0;
+    if (with_down) {
+        TCR_REQUIRE(li == lastb.b && lastb.down >= 0, "tcr_net_backward: the two-unit reduction is the last block's");
+        const LazySrc sd = lazy_src_of(c, lastb.down);
+        r.y2 = sd.raw; r.mean2 = sd.mean; r.invstd2 = c.base + c.w.invstd[lastb.down];
+        r.self_scale2 = sd.self_scale; r.self_shift2 = sd.self_shift; r.partial2 = c.base + c.w.partial2;
+        return launch_chan_reduce(2, r, &nchunk, st);
+    }
     return launch_chan_reduce(1, r, &nchunk, st);
 }
 
@@ -1607,8 +1616,10 @@ static int backward_lazy(const TrainCtx& c, float* grads, const LevelPlan* plan)
                                      sums_of(c, li), c.s));
         }
     } else {
-        TCR_TRY(lazy_last_block_sums(c, lastb.b, c.s));
-        if (lastb.down >= 0) TCR_TRY(lazy_last_block_sums(c, lastb.down, c.s));
+        const ConvLayer& lb = net->layers[lastb.b];
+        const bool both = lastb.down >= 0 && net->layers[lastb.down].cout == lb.cout && net->layers[lastb.down].tout == lb.tout && tune_get(TCR_TUNE_BWD_MASK) != 5;
+        TCR_TRY(lazy_last_block_sums(c, lastb.b, c.s, both));
+        if (lastb.down >= 0 && !both) TCR_TRY(lazy_last_block_sums(c, lastb.down, c.s));
         // A fork (event record on the main chain) per BN unit.  An event record between two kernels costs ~6 us of dispatch gap (the
         // forward, which records none, shows none), so ONE fork per block was tried -- the fork behind (conv_b, shortcut)'s finalize also
         // releasing the previous block's conv_a filter gradient: TCResNet8 975 vs 949 us per step, 98 frames 1492 vs 1443 -- SLOWER: the
