@@ -679,3 +679,9 @@ def test_wide_bn_backward_apply_loop_is_bitwise(hip_lib, name, width, batch):
             Cm.check_backward_knob_variants(hip_lib, 29, (1,), True, name=name, width=width, batch=batch, t=49)
         finally:
             hip_lib.tcr_tune(9, 0); hip_lib.tcr_tune(12, 0)
+
+
+@pytest.mark.gpu
+def test_last_block_two_unit_reduction_is_bitwise(hip_lib):
+    Cm.check_backward_knob_variants(hip_lib, 12, (5,), True, batch=4096)
+    Cm.check_backward_knob_variants(hip_lib, 12, (5,), True, batch=517, t=98)
