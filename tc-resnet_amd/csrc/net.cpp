@@ -1091,8 +1091,10 @@ enum { BWD_BN = 1, BWD_WGRAD = 2, BWD_DGRAD = 4, BWD_ALL = 7 };
 static bool down_dgrad_first(const TrainCtx& c, const Block& b) {
     // Measured (batch 4096, scripts/ab_down_dgrad.py): TCResNet8 -0.8 % at 49 frames, -3 % at 98; TCResNet14-1.5 +1 % (its side stream is
     // the longer one already) -- so by width, like the front-end's submit point: nets of <= 48 channels.  Knob 2 forces it on.
+    // Round 6 (filter gradients ~25 % faster: the side stream is no longer the longer one): TCResNet14-1.5 at 98 frames 4027 -> 3936 us
+    // with it, at 49 frames 2493 -> 2499 -- so for the wide nets from 64 frames up.
     const int knob = tune_get(TCR_TUNE_DOWN_DGRAD);
-    if (b.down < 0 || c.sync_bn || c.side == c.s || knob == 1 || (knob == 0 && c.net->feat_c > 48)) return false;
+    if (b.down < 0 || c.sync_bn || c.side == c.s || knob == 1 || (knob == 0 && c.net->feat_c > 48 && c.net->layers[0].tin < 64)) return false;
     const ConvLayer& ld = c.net->layers[b.down];
     const ConvLayer& la = c.net->layers[b.a];
     return ld.in_act >= 0 && conv_dgrad_mfma_covers(ld.k, ld.stride, ld.cout) && conv_dgrad_mfma_covers(la.k, la.stride, la.cout);

@@ -463,7 +463,10 @@ static bool configure_phase(TrainPhaseArgs& a, size_t* lds_out, int* grid_out) {
     // Utterances per group: as many as keep the LDS footprint <= 40 KB (3-4 workgroups per CU), at most 8 -- and few enough
     // that the grid still has >= 512 workgroups (one partial row each).
     const size_t stat_bytes = (size_t)NW * max(a.n_layers, 1) * 2 * cstat * sizeof(float);
-    int group = knob % 100 > 0 ? knob % 100 : 8;
+    // (Round 6: 4 instead of 8 for phases of more than 64 output channels -- TCResNet14-1.5's 72-channel blocks: twice the workgroups, four
+    //  per CU in different parts of a phase instead of two -- 98 frames: 4027 -> 3924 us per step, 49 frames 2494 -> 2494; 4 for EVERY
+    //  phase: 3934 / 2472, i.e. the gain is the wide phases'; 3 / 5 / 6: slower.  TCResNet8: 8 stays -- 4: 806 vs 785 us.)
+    int group = knob % 100 > 0 ? knob % 100 : (cstat >= 80 ? 4 : 8);
     while (group > 1 && ((size_t)group * in_sz + 64) * sizeof(float) + stat_bytes > 40 * 1024) --group;
     while (group > 1 && ceil_div(a.batch, group) < 512) --group;
     const size_t lds = ((size_t)group * in_sz + 64) * sizeof(float) + stat_bytes;
