@@ -417,7 +417,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_FE_GRID = 13,    /* front-end: cap on the number of persistent workgroups (0: two per CU). 256 = one per CU, which leaves half of every CU's LDS and registers to a co-resident network kernel on another stream */
        TCR_TUNE_FUSED_GRID = 14, /* fused eval network: cap on the number of persistent workgroups (0: as many as the LDS allows per CU) */
        TCR_TUNE_DS_TRAIN = 15,   /* DS-CNN training: 0 normalised activations never materialised where every consumer has the form (172 / 276-channel nets): consumers apply BN + ReLU to the raw conv outputs, batch statistics and backward sums come from conv / data-gradient epilogues (default); 1 the materialising path (statistics reduce -> finalize -> normalise, backward reduce); 2: as 0, but every unit's BN backward by a bn_bwd_apply pass (default 0: conv_1's filter gradient computes dy where it reads it); 3: as 0, the depthwise units' kernels too; 4: as 0, and the pointwise units' data-gradient kernel applies the BN backward while staging and writes dy for the filter gradient instead of a bn_bwd_apply pass (measured slower) */
-       TCR_TUNE_WGRAD_TILES = 16, /* 9-tap filter gradients (16-byte-load kernel): output-channel tiles per launch (0: default 3; a layer of more tiles is split into launches that share one slab) */
+       TCR_TUNE_WGRAD_TILES = 16, /* 9-tap filter gradients (16-byte-load kernel): output-channel tiles per launch (0: default 2 since round 6, 3 before; a layer of more tiles is split into launches that share one slab) */
        TCR_TUNE_DOWN_DGRAD = 17,  /* TC-ResNet backward, a block's 1x1 shortcut conv: 0 its data gradient runs early on the side stream and writes the block-input gradient first, conv_a's adds onto it (default for nets of <= 48 channels and, since round 6, for wider nets from 64 frames up, where it measured faster; 2: for every net); 1 conv_a's first, the shortcut's added behind it on the main stream (bitwise the same sums: one addition, commuted) */
        TCR_TUNE_BWD_LAZY_CFG = 18, /* lazy backward geometry: utterances per group + 100 * waves per job (0: cost model) + 10000 * (out channels * 10 + layers) to address one kernel of the net */
        TCR_TUNE_PHASE_STATIC = 19, /* training forward phases of TCResNet8-1.0 / TCResNet14-1.5 at 49 / 98 frames: 0 compile-time-shaped kernels, utterance stride in LDS padded to the bank pattern (default); bit 0: generic layer walk; bit 1: unpadded stride (A/B arms, all bitwise) */

@@ -2406,7 +2406,9 @@ int launch_conv_wgrad_partial(int k, int stride, int pad_lo, const float* x, con
     // launch: 5 -> 3255 us, 3 -> 3012, 2 -> 2960, 1 -> 3116; TCResNet8 (<= 3 tiles per layer): 1048 / 1048 / 1054 / 1118 -- so only
     // layers of more than three tiles are split (TCR_TUNE_WGRAD_TILES overrides).
     const int tk = tune_get(TCR_TUNE_WGRAD_TILES);
-    const int tiles_per_launch = (k == 9 && wgrad4_covers(k, stride, x_slack)) ? (tk > 0 ? min(tk, nco) : (nco > 3 ? 2 : nco)) : nco;
+    // Round 6 (software-pipelined kernel): three-tile layers split 2 + 1 as well -- 27 accumulator tiles + two operand sets are two waves per
+    // SIMD, 18 are three: TCResNet8 step 810 -> 781 us (98 frames 1252 -> 1229), TCResNet14-1.5 2484 -> 2483 / 3857 -> 3875.
+    const int tiles_per_launch = (k == 9 && wgrad4_covers(k, stride, x_slack)) ? (tk > 0 ? min(tk, nco) : (nco > 2 ? 2 : nco)) : nco;
     for (int t0 = 0; t0 < nco; t0 += tiles_per_launch) {
         WgradArgs b = a;
         const int nt = min(tiles_per_launch, nco - t0);
