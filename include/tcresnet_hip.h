@@ -422,7 +422,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_BWD_LAZY_CFG = 18, /* lazy backward geometry: utterances per group + 100 * waves per job (0: cost model) + 10000 * (out channels * 10 + layers) to address one kernel of the net */
        TCR_TUNE_PHASE_STATIC = 19, /* training forward phases of TCResNet8-1.0 / TCResNet14-1.5 at 49 / 98 frames: 0 compile-time-shaped kernels, utterance stride in LDS padded to the bank pattern (default); bit 0: generic layer walk; bit 1: unpadded stride (A/B arms, all bitwise) */
        TCR_TUNE_WGRAD_WAVES = 20, /* on-the-fly 9-tap filter gradients: waves per workgroup (0: policy; 4, 8, 12, 16) */
-       TCR_TUNE_WGRAD_LDS = 21,  /* first conv's filter gradient: 0 the LDS-staged nine-wave kernel (default), 1 the 16-byte-load kernel */
+       TCR_TUNE_WGRAD_LDS = 21,  /* first conv's filter gradient: 0 the LDS-staged nine-wave kernel (default), 1 the 16-byte-load kernel; per-layer chain, round 6 A/B arms (bitwise the default): 2 the first conv's dy written by an apply pass instead of built where the filter gradient loads it, 3 every layer's split-K slabs summed in one pass at the step's end instead of the first half of the units early */
        TCR_TUNE_LAZY_STAGE = 22, /* lazy backward: 0 the group's rows staged with 16-byte loads (default), 1 a dword gather per interior element (bitwise the same) */
        TCR_TUNE_FE_KERNEL = 23,  /* packed-FP32 front-end: 0 the three-waves-per-SIMD kernel (frontend_pk3.hip: wave-local LDS regions, <= 168 registers; default), 1 the two-waves kernel of rounds 2-4 (frontend_pk.hip; also what filterbanks with more work items than the unrolled trips fall back to). Bitwise the same features. */
        TCR_TUNE_FE_STAGGER = 24, /* three-waves front-end: one-off start-up delay of (workgroup generation * 4 + wave) * value * 64 cycles that de-phases the twelve waves of a CU (0: none) */

@@ -1109,7 +1109,7 @@ static int bwd_unit_post(const TrainCtx& c, const BwdUnit& u, float* grads, cons
     float* dy = c.base + c.w.dyb[u.li];
     // (see BWD_BN below; needs this call to do both halves, the unit's own mask recomputed from raw, and a kernel that takes WgradFly)
     const bool fly_first = l.in_act < 0 && (parts & BWD_BN) && (parts & BWD_WGRAD) && !u.da_bcast && u.m1 == nullptr && u.m2 == nullptr && u.self_ss != nullptr &&
-                           conv_wgrad_deferrable(l.k, l.cin, l.cout) && conv_wgrad_fly_covers(l.k, l.stride, false);
+                           conv_wgrad_deferrable(l.k, l.cin, l.cout) && conv_wgrad_fly_covers(l.k, l.stride, false) && tune_get(TCR_TUNE_WGRAD_LDS) != 2;
 #if defined(TCR_NET_WHATIF_ENV)
     if (whatif_bwd() & 4) parts &= ~BWD_BN;
     if (whatif_bwd() & 2) parts &= ~BWD_WGRAD;
@@ -1712,9 +1712,27 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
     // gradients when the main chain has finished), so the FIRST conv's filter gradient runs on the main stream (bwd_unit_post) and the
     // slabs are summed where their producers ran: the first conv's on the main stream, all others behind the side stream's last
     // kernel; then the join.
+    // Round 6: the slabs of the units of the first half of `order` are summed when that half's filter gradients have been launched (same
+    // stream, behind them) instead of with everything else at the step's end, where the 40 us pass over ~200 MB of slabs ran beside the
+    // first conv's tail chain on the main stream.  A layer's sum does not depend on when it is taken: bitwise the one-pass result.
+    const bool all_on_side = c.side != c.s && !down_on_second && tune_get(TCR_TUNE_WGRAD_STREAM) == 0;
+    const int mid = (all_on_side && !bwd_phases && !plan && nu >= 8 && tune_get(TCR_TUNE_WGRAD_LDS) != 3) ? nu / 2 : -1;      // order[0 .. mid]: the early pass
+    auto reduce_range = [&](int lo, int hi, bool first_conv, hipStream_t st) -> int {     // units order[lo .. hi] (the first conv only when asked)
+        WgradReduceMulti rm;
+        rm.n = 0;
+        for (int oi = lo; oi <= hi; ++oi) {
+            const int li = order[oi];
+            const ConvLayer& l = net->layers[li];
+            if (!conv_wgrad_deferrable(l.k, l.cin, l.cout) || (li == 0) != first_conv) continue;
+            if (rm.n == kMultiMax) { TCR_TRY(launch_wgrad_reduce_multi(rm, st)); rm.n = 0; }
+            rm.e[rm.n++] = conv_wgrad_entry(l.k, l.cin, l.cout, batch, c.base + c.w.wg[li], grads + l.w_off, wgrad_fine(l));
+        }
+        return rm.n ? launch_wgrad_reduce_multi(rm, st) : TCR_OK;
+    };
     auto reduce_slabs = [&]() -> int {
         const bool split = c.side != c.s;
         auto run = [&](int which, hipStream_t st) -> int {      // 0: every layer but the first conv, 1: the first conv, 2: all
+            if (which == 0 && mid >= 0) return reduce_range(mid + 1, nu - 1, false, st);        // (the early pass took order[0 .. mid])
             WgradReduceMulti rm;
             rm.n = 0;
             for (int li : order) {
@@ -1830,6 +1848,7 @@ static int backward_stages(const tcr_net* net, const float* params, const float*
             } else {
                 TCR_TRY(bwd_unit_post(c, bwd_unit_of(c, li, dpool), grads, dpool, BWD_ALL, c.s, partial, kc));
             }
+            if (st - 1 == mid) TCR_TRY(reduce_range(0, mid, false, c.side));        // (behind the filter gradients launched so far)
         }
         if (st < nu) {
             const int li = order[st];
