@@ -409,7 +409,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_FUSED_WAVES = 5, /* fused kernel: waves per workgroup (4, 8, 16) + 100 * weight-ring depth (4, 8, 16); 0: default */
        TCR_TUNE_CONV_KSPLIT = 6, /* train-mode conv / data-gradient: waves sharing one 32-position group's reduction (0 auto, 1, 2, 4) */
        TCR_TUNE_WGRAD_STREAM = 7,/* backward: 0 weight-gradient kernels on the library's internal streams (one set per device and process; default), 1 everything on the caller's stream, 2: as 0 with the TC-ResNet shortcut units (BN backward, data and filter gradient) on the second internal stream instead of behind the other units' filter gradients (measured: -1 % at 49 frames, +7 % for TCResNet8 at 98); 3: lazy backward with one stream fork per block instead of one per BN unit (measured slower: +3 %) */
-       TCR_TUNE_TRAIN_FWD = 8,   /* train-mode forward: 0 group-resident phases (train_fused.hip; BN affine / ReLU / residual applied while the next conv stages its input, statistics from the conv epilogue), 1 per-layer kernels (conv -> statistics -> finalize -> normalise) */
+       TCR_TUNE_TRAIN_FWD = 8,   /* train-mode forward: 0 group-resident phases (train_fused.hip; BN affine / ReLU / residual applied while the next conv stages its input, statistics from the conv epilogue), 1 per-layer kernels (conv -> statistics -> finalize -> normalise), 2: as 0 with the head walking the block output's rows for its pooling instead of starting from the sums over time the closing phase leaves (round 6; bitwise the same) */
        TCR_TUNE_TRAIN_BWD = 9,   /* TC-ResNet backward: 0 "lazy" BN backward (bwd_lazy.hip: dy never written -- the data-gradient kernel applies BN backward while it stages a group of utterances into LDS, runs every stride phase and the block's shortcut conv from that image and leaves the next unit's sums from its epilogue; the filter-gradient kernels compute dy where they load it; default for nets of <= 48 channels, where it measured faster; 3: for every net it covers), 1 the group-resident phases of round 2 (train_fused_bwd.hip), 2 the per-layer chain (reduce -> finalize + bn_bwd_apply -> data gradient per phase; the default until round 3) */
        TCR_TUNE_PHASE_CFG = 10,  /* training phases: waves per workgroup * 100 + utterances per group (0: default) */
        TCR_TUNE_BWD_BN_FUSED = 11, /* BN backward: 0 finalize folded into the apply pass (one launch, ~512 workgroups; round 6: for every layer width -- rounds 3-5: <= 48 channels, 1024 workgroups), 1 finalize + apply kernels, >= 2: folded, that many workgroups aimed at */

@@ -54,6 +54,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
                 afv[j][m] = af;
             }
         }
+        if (a.pool_sum) {           // the sums over time are given (the closing training phase's; frames added in the order of the loop below)
+#pragma unroll
+            for (int j = 0; j < CQ; ++j) sum[j] = a.pool_sum[(size_t)n * a.c + min(c0 + 4 * j + q, a.c - 1)];
+        } else
         for (int t0 = 0; t0 < a.t; t0 += 8) {
             float v[CQ][8];
 #pragma unroll

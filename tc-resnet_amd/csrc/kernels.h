@@ -232,6 +232,7 @@ struct TrainPhaseArgs {
     int n_layers;           // 0: staging only (materialise X / S)
     PhaseLayer layer[2];
     int batch;
+    float* pool_sum = nullptr;      // closing phase (n_layers == 0): also [B][c] sums over time of the staged activation, frames in order -- the head's pooling
     int group, n_groups, in_sz, cstat, stat_off, nw; // (set by the launcher)
 };
 // rows_out: partial rows written per layer (= workgroups).  Returns 1 when the phase does not fit (nothing launched).
@@ -504,6 +505,7 @@ struct HeadArgs {
     float inv_global_batch;
     float label_smoothing;
     float pool_scale;           // (train) overrides 1/t in dscale when feat is an already pooled [B][C] map (DS-CNN), or 0
+    const float* pool_sum = nullptr;    // [B][C] sums over time of feat, frames in order (the closing training phase leaves them): the head skips its walk over the rows
 };
 
 int launch_head_fwd(const HeadArgs& a, bool train, hipStream_t s);

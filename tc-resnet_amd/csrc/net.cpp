@@ -842,9 +842,17 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
             }
         }
         if (!plan->last) return TCR_OK;
-        if (phases) TCR_TRY(launch_train_phase(phase_of_unit(c, -1, &first), nullptr, c.s));       // the head's input + the last shortcut
+        // (round 6: the closing phase also leaves the block output's sums over time -- in the workspace's dpool slot, which the
+        //  backward's first launch rewrites later -- and the head starts from them; TCR_TUNE_TRAIN_FWD = 2: the head walks the rows)
+        const bool pooled = phases && tune_get(TCR_TUNE_TRAIN_FWD) != 2;
+        if (phases) {
+            TrainPhaseArgs pc = phase_of_unit(c, -1, &first);
+            if (pooled) pc.pool_sum = c.base + c.w.dpool;
+            TCR_TRY(launch_train_phase(pc, nullptr, c.s));       // the head's input + the last shortcut
+        }
         HeadArgs h;
         std::memset(&h, 0, sizeof(h));
+        if (pooled) h.pool_sum = c.base + c.w.dpool;
         h.feat = c.base + c.w.act[net->units[nu - 1]];
         h.wfc = params + net->layers[net->fc].w_off;
         h.wfc2 = params + net->layers[net->fc2].w_off;
@@ -888,9 +896,13 @@ static int forward_train_stages(const tcr_net* net, const float* params, float* 
             if (first) TCR_TRY(launch_train_phase(pa, &rows, c.s));
             if (c.sync_bn) TCR_TRY(launch_chan_sums(partial_of(li), rows, net->layers[li].cout, sums_of(c, li), c.s));
         } else {
-            TCR_TRY(launch_train_phase(phase_of_unit(c, -1, &first), nullptr, c.s));       // the head's input + the last shortcut
+            const bool pooled = tune_get(TCR_TUNE_TRAIN_FWD) != 2;      // (see the level path above)
+            TrainPhaseArgs pc = phase_of_unit(c, -1, &first);
+            if (pooled) pc.pool_sum = c.base + c.w.dpool;
+            TCR_TRY(launch_train_phase(pc, nullptr, c.s));       // the head's input + the last shortcut
             HeadArgs h;
             std::memset(&h, 0, sizeof(h));
+            if (pooled) h.pool_sum = c.base + c.w.dpool;
             h.feat = c.base + c.w.act[net->units[nu - 1]];
             h.wfc = params + net->layers[net->fc].w_off;
             h.wfc2 = params + net->layers[net->fc2].w_off;

@@ -358,7 +358,22 @@ __global__ __launch_bounds__(NW * 64) void train_phase_kernel(const TrainPhaseAr
         const int ng = min(a.group, a.batch - n0);
         __syncthreads();                                   // (previous group's convolutions are done with the LDS rows)
         phase_stage<NT>(a, lds, n0, ng, tid, tp, row);
-        if (a.n_layers == 0) continue;
+        if (a.n_layers == 0) {
+            // Closing phase, round 6: the block output sits in LDS -- its sums over time, frames in order (the head's own order: bitwise its
+            // pooling), leave with it, so that head_fwd_kernel starts from [B][C] instead of walking C x T scattered rows per utterance
+            // on 64 workgroups (22-29 us at the joint of forward and backward).
+            if (a.pool_sum) {
+                __syncthreads();
+                for (int i = tid; i < ng * S.c; i += NT) {
+                    const int g = i / S.c, ch = i - g * S.c;
+                    const float* rowp = lds + g * a.in_sz + ch * tp + kHalo;
+                    float sum = 0.f;
+                    for (int t = 0; t < S.t; ++t) sum += rowp[t];
+                    a.pool_sum[(size_t)(n0 + g) * S.c + ch] = sum;
+                }
+            }
+            continue;
+        }
         __syncthreads();
         for (int li = 0; li < a.n_layers; ++li)
             phase_layer<NW, R>(a, a.layer[li], lds, stat + (wave * a.n_layers + li) * 2 * a.cstat, n0, ng, wave, r, q);

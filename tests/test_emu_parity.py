@@ -329,3 +329,10 @@ def test_last_block_two_unit_reduction_is_bitwise(emu_lib):
     against two launches, the second reading the masked gradient back (TCR_TUNE_BWD_MASK = 5): the same rows, gradients bitwise."""
     Cm.check_backward_knob_variants(emu_lib, 12, (5,), True, batch=9)
     Cm.check_backward_knob_variants(emu_lib, 12, (5,), True, batch=3, t=98)
+
+
+def test_head_from_the_closing_phase_sums_is_bitwise(emu_lib):
+    """The training forward's head starting from the sums over time that the closing phase leaves (round 6; default) against the head walking
+    the block output's rows itself (TCR_TUNE_TRAIN_FWD = 2): the same frames added in the same order -- gradients bitwise."""
+    Cm.check_backward_knob_variants(emu_lib, 8, (2,), True, batch=9)
+    Cm.check_backward_knob_variants(emu_lib, 8, (2,), True, name="TCResNet14", width=1.5, batch=3, t=98)

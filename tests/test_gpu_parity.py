@@ -685,3 +685,9 @@ def test_wide_bn_backward_apply_loop_is_bitwise(hip_lib, name, width, batch):
 def test_last_block_two_unit_reduction_is_bitwise(hip_lib):
     Cm.check_backward_knob_variants(hip_lib, 12, (5,), True, batch=4096)
     Cm.check_backward_knob_variants(hip_lib, 12, (5,), True, batch=517, t=98)
+
+
+@pytest.mark.gpu
+def test_head_from_the_closing_phase_sums_is_bitwise(hip_lib):
+    Cm.check_backward_knob_variants(hip_lib, 8, (2,), True, batch=4096)
+    Cm.check_backward_knob_variants(hip_lib, 8, (2,), True, name="TCResNet14", width=1.5, batch=1031, t=98)
