@@ -382,6 +382,36 @@ class TCResNet(_Base):
         self._note_fold_reader()
         return (logits, probs, ranges) if want_ranges else (logits, probs)
 
+    def waveform_call(self, frontend: "Frontend", wav: torch.Tensor, out, feat: Optional[torch.Tensor] = None):
+        """A PREPARED `tcr_forward_waveform` call for a fixed set of buffers (the latency regime: one utterance at a time into the same
+        tensors): validates, folds BN and allocates once -- through one ordinary `forward_waveform` -- and returns a zero-argument callable
+        that issues the single C-ABI call with the pointers bound, on the stream that was current when it was prepared.  What a C / C++
+        host of the ABI does per utterance; `forward_waveform` itself spends more time in Python than the GPU spends on the utterance.
+        The callable refuses to run once the variables or moving statistics have changed (prepare again) -- the folded table it bound
+        belongs to the weights it was prepared for."""
+        logits, probs = out
+        self.forward_waveform(frontend, wav, out=out, feat=feat)
+        if wav.dim() == 3:
+            wav = wav[..., 0]
+        b = wav.shape[0]
+        if feat is None:
+            feat = self._wave_feat[(b, frontend.cfg.n_coef, frontend.cfg.n_frames)]
+        ws = self.workspace(b, False)
+        ss = self._fold_ss
+        keep = (frontend, wav, feat, ws, ss, logits, probs, self.params, self.stats)        # (the bound pointers stay alive with the callable)
+        args = (C.byref(frontend.cfg), frontend.plan.data_ptr(), self._h, self.params.data_ptr(), self.stats.data_ptr(), ss.data_ptr(), 0,
+                wav.data_ptr(), b, feat.data_ptr(), ws.data_ptr(), ws.numel() * 4, logits.data_ptr(), probs.data_ptr(), None, self._stream())
+        fn, check = self.lib.tcr_forward_waveform, self.lib.check
+        params, stats, kver = self.params, self.stats, (self.params._version, self.stats._version, self._kver)
+
+        def call(_keep=keep):
+            if (params._version, stats._version, self._kver) != kver:
+                raise TcrError("waveform_call: the variables / moving statistics changed since the call was prepared; prepare it again")
+            rc = fn(*args)
+            if rc:
+                check(rc, "tcr_forward_waveform")
+        return call
+
     def fold_bn(self) -> torch.Tensor:
         """Eval-mode BN of every layer folded to per-channel (scale, shift) constants: the table a frozen export stores."""
         ss = torch.zeros(self.lib.tcr_net_frozen_floats(self._h), dtype=torch.float32, device=self.device)

@@ -691,3 +691,32 @@ def test_last_block_two_unit_reduction_is_bitwise(hip_lib):
 def test_head_from_the_closing_phase_sums_is_bitwise(hip_lib):
     Cm.check_backward_knob_variants(hip_lib, 8, (2,), True, batch=4096)
     Cm.check_backward_knob_variants(hip_lib, 8, (2,), True, name="TCResNet14", width=1.5, batch=1031, t=98)
+
+
+@pytest.mark.gpu
+def test_prepared_waveform_call(hip_lib):
+    """TCResNet.waveform_call: the single C-ABI call with its pointers bound once (the latency regime) == forward_waveform, bitwise, call
+    after call into the same buffers; it refuses to run once the weights it was prepared for have changed."""
+    lib = hip_lib
+    fx = Cm.load("tcresnet8_1.0_4020.npz")
+    arch, p, s = Cm.fixture_params(fx, "TCResNet8", 1.0)
+    fe = Cm.make_frontend(lib, fx["win"], fx["hop"])
+    net = Cm.make_net(lib, "TCResNet8", 1.0, fe.n_frames, p, s)
+    wav = Cm.to_dev(lib, fx["wav"][:1])
+    ref = [t.clone() for t in net.forward_waveform(fe, wav)]
+    out = (torch.zeros_like(ref[0]), torch.zeros_like(ref[1]))
+    call = net.waveform_call(fe, wav, out)
+    for _ in range(3):
+        out[0].zero_(); out[1].zero_()
+        lib.tcr_tune(0, 0)          # (any host work between calls)
+        # zero_() bumps neither params nor stats: the prepared call stays valid
+        call()
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    assert np.abs(out[0].cpu().numpy() - fx["eval_logits"][:1]).max() < Cm.LOGIT_TOL
+    lab = Cm.to_dev(lib, fx["labels"])
+    net.forward_train(fe(Cm.to_dev(lib, fx["wav"])), lab, keep_prob=1.0); net.backward(); net.sgd_momentum_step(0.1, 0.9, 0.001)
+    with pytest.raises(T.TcrError):
+        call()
+    call2 = net.waveform_call(fe, wav, out)
+    call2()
+    assert torch.equal(out[0], net.forward_waveform(fe, wav)[0]) and not torch.equal(out[0], ref[0])
