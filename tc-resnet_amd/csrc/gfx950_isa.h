@@ -40,6 +40,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_wave_base))), 16, 0, 0);
 }
 
+// Buffer-descriptor loads: `buffer_load_dword v, v_offset, s[rsrc], s_offset offen` -- the address is a wave-uniform 128-bit descriptor
+// (base pointer in scalar registers) + a per-lane 32-bit byte offset + a wave-uniform 32-bit byte offset, i.e. NO 64-bit vector address
+// arithmetic in front of a load whose lane part never changes and whose running part is uniform (flat / global loads of that shape
+// compile to a v_lshl_add_u64 per load once the zero-extension of the lane offset has been hoisted out of the loop).  The base must be
+// provably wave-uniform (kernel arguments / blockIdx-derived scalars), else the compiler wraps every load in a waterfall loop.  The
+// compiler counts these loads on vmcnt like plain ones.  Bounds: 2 GB behind `base` (reads past it return 0).
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(buf_rsrc r, unsigned lane_off_bytes, unsigned uniform_off_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off_bytes, (int)uniform_off_bytes, 0));
+}
+
 // waits for this wave's outstanding glds16 copies (and any other vector-memory load): s_waitcnt vmcnt(0)
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -895,17 +895,24 @@ __global__ __launch_bounds__(64 * KS) void conv_mfma_ksplit_kernel(const ConvArg
     // Per-lane operand pointers at (tap 0, channel quad 0); a K-step adds a wave-uniform offset.  Out-of-range output
     // channels / channel quads are CLAMPED, not predicated: the products land in rows that are never stored or in steps
     // that are never multiplied, and the loop stays free of per-load masks.
-    const float* xp[2];
+    // Round 6: operands through buffer descriptors (gfx950_isa.h: buf_load_f32) -- a wave-uniform base, a per-lane 32-bit byte offset
+    // that never changes, a wave-uniform running offset.  As per-lane 64-bit pointers + a uniform offset (rounds 2-5) every load was
+    // preceded by a 64-bit vector add (v_lshl_add_u64) and half a dozen scalar instructions: ~4 VALU + ~4 SALU instructions per MFMA in
+    // the PMC counts of this kernel (profiles/r06_train14_pmc.csv), on a chip where VALU issue adds to the matrix pipe's time.  (Uniform
+    // base + zero-extended lane offset as plain global loads did NOT get there: the compiler hoists the zero-extension out of the loop
+    // and adds the 64-bit pair to the scalar base with the same vector instruction.)
+    const buf_rsrc xr = make_rsrc(a.x + (size_t)n0 * row), wr = make_rsrc(a.w), wdr = make_rsrc(DOWN ? d.w : a.w);
+    unsigned xo[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int p = min(p_base + nt * 16 + r, wg_p1 - 1);
         const int n = p / a.tout, t = p - n * a.tout;
-        xp[nt] = a.x + (size_t)n * row + t * S + a.xoff + q * a.tpi;
+        xo[nt] = (unsigned)((n - n0) * row + t * S + a.xoff + q * a.tpi) * 4u;
     }
     const int cot0 = blockIdx.y * MT;
-    const float* wp[MT];
+    unsigned wo[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) wp[m] = a.w + q * a.cout + min((cot0 + m) * 16 + r, a.cout - 1);
+    for (int m = 0; m < MT; ++m) wo[m] = (unsigned)(q * a.cout + min((cot0 + m) * 16 + r, a.cout - 1)) * 4u;
     f32x4 acc[MT][2];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -915,14 +922,15 @@ __global__ __launch_bounds__(64 * KS) void conv_mfma_ksplit_kernel(const ConvArg
     const int step_stride = 4 * a.cout;
     const int xq = 4 * a.tpi;
     // chunk = CH consecutive channel quads of one tap; woff / xoff: uniform float offsets of its first K-step
-    auto load_chunk = [&](const float* const (&wq)[MT], int woff, int xoff, int c0, float (&af)[CH][MT + 2]) {
+    auto load_chunk = [&](const buf_rsrc wu, int woff, int xoff, int c0, float (&af)[CH][MT + 2]) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int ci = min(c0 + i, C4 - 1) - c0;                // (tail: re-read the last quad; not multiplied)
+            const unsigned ws = (unsigned)(woff + ci * step_stride) * 4u, xs = (unsigned)(xoff + ci * xq) * 4u;     // (uniform)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[i][m] = wq[m][woff + ci * step_stride];
-            af[i][MT] = xp[0][xoff + ci * xq];
-            af[i][MT + 1] = xp[1][xoff + ci * xq];
+            for (int m = 0; m < MT; ++m) af[i][m] = buf_load_f32(wu, wo[m], ws);
+            af[i][MT] = buf_load_f32(xr, xo[0], xs);
+            af[i][MT + 1] = buf_load_f32(xr, xo[1], xs);
         }
     };
     auto mma_chunk = [&](int c0, const float (&af)[CH][MT + 2], f32x4 (&ac)[MT][2]) {
@@ -967,15 +975,15 @@ __global__ __launch_bounds__(64 * KS) void conv_mfma_ksplit_kernel(const ConvArg
     auto norm = [&]() { while (cq >= cpj) { cq -= cpj; ++j; } };
     norm();
     float afA[CH][MT + 2], afB[CH][MT + 2];
-    if (ks < nchunks) load_chunk(wp, j * tap_stride + cq * CH * step_stride, j + cq * CH * xq, cq * CH, afA);
+    if (ks < nchunks) load_chunk(wr, j * tap_stride + cq * CH * step_stride, j + cq * CH * xq, cq * CH, afA);
     for (int ch = ks; ch < nchunks; ch += 2 * KS) {
         const int cqa = cq;
         cq += KS; norm();
         const int cqb = cq;
-        if (ch + KS < nchunks) load_chunk(wp, j * tap_stride + cq * CH * step_stride, j + cq * CH * xq, cq * CH, afB);
+        if (ch + KS < nchunks) load_chunk(wr, j * tap_stride + cq * CH * step_stride, j + cq * CH * xq, cq * CH, afB);
         mma_chunk(cqa * CH, afA, acc);
         cq += KS; norm();
-        if (ch + 2 * KS < nchunks) load_chunk(wp, j * tap_stride + cq * CH * step_stride, j + cq * CH * xq, cq * CH, afA);
+        if (ch + 2 * KS < nchunks) load_chunk(wr, j * tap_stride + cq * CH * step_stride, j + cq * CH * xq, cq * CH, afA);
         if (ch + KS < nchunks) mma_chunk(cqb * CH, afB, acc);
     }
     reduce(acc);
@@ -989,11 +997,8 @@ __global__ __launch_bounds__(64 * KS) void conv_mfma_ksplit_kernel(const ConvArg
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc2[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* wd[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) wd[m] = d.w + q * a.cout + min((cot0 + m) * 16 + r, a.cout - 1);
         for (int cc = ks * CH; cc < C4; cc += KS * CH) {
-            load_chunk(wd, cc * step_stride, d.tap + cc * xq, cc, afA);
+            load_chunk(wdr, cc * step_stride, d.tap + cc * xq, cc, afA);
             mma_chunk(cc, afA, acc2);
         }
         reduce(acc2);

@@ -24,6 +24,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 __device__ __forceinline__ void wait_dma() {}
 
+// (host stand-in of the buffer-descriptor loads: base + lane offset + uniform offset, in bytes)
+typedef const char* buf_rsrc;
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* base) { return static_cast<const char*>(base); }
+__device__ __forceinline__ float buf_load_f32(buf_rsrc r, unsigned lane_off_bytes, unsigned uniform_off_bytes) {
+    float v;
+    memcpy(&v, r + lane_off_bytes + uniform_off_bytes, 4);
+    return v;
+}
+
 // a - i b = (a.x + b.y, a.y - b.x)
 __device__ __forceinline__ v2 c_submi(v2 a, v2 b) {
     return (v2){a.x + b.y, a.y - b.x};
