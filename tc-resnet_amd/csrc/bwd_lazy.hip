@@ -211,10 +211,12 @@ __global__ __launch_bounds__(kLzNW * 64) void bwd_lazy_kernel(const BwdLazyArgs 
                     for (int nt = 0; nt < 2; ++nt) xo[nt] = (gg[nt] * S.c + q) * tp + uu[nt] + kHalo + a.dmin[li][ph];
                     // A[row = ci][k = co]: wt entry [tap][co][ci]; lane (r, q) reads row m * 16 + r (clamped: rows past out_c are never
                     // stored), k = q of the step's channel quad
-                    const float* wl = a.layer[li].wt + a.wbase[li][ph];
-                    int wq[MT];
+                    // (round 6: the weights through a buffer descriptor -- uniform base, constant lane offset, uniform running offset: no
+                    //  64-bit vector address arithmetic in front of the CH x MT loads of a chunk; gfx950_isa.h: buf_load_f32)
+                    const buf_rsrc wl = make_rsrc(a.layer[li].wt + a.wbase[li][ph]);
+                    unsigned wq[MT];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) wq[m] = q * a.out_c + min(m * 16 + r, a.out_c - 1);
+                    for (int m = 0; m < MT; ++m) wq[m] = (unsigned)(q * a.out_c + min(m * 16 + r, a.out_c - 1)) * 4u;
                     const int tap_stride = S.c * a.out_c, step_stride = 4 * a.out_c, xq = 4 * tp;
                     const int cpj = (C4 + CH - 1) / CH;
                     const int nch = cnt * cpj;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(kLzNW * 64) void bwd_lazy_kernel(const BwdLazyArgs 
                         for (int i = 0; i < CH; ++i) {
                             const int c4 = min(c0 + i, C4 - 1);                 // (tail: re-read the last quad; not multiplied)
 #pragma unroll
-                            for (int m = 0; m < MT; ++m) af[i][m] = (TCR_LAZY_WHATIF & 1) ? 1.0f : wl[wq[m] + j * tap_stride + c4 * step_stride];
+                            for (int m = 0; m < MT; ++m) af[i][m] = (TCR_LAZY_WHATIF & 1) ? 1.0f : buf_load_f32(wl, wq[m], (unsigned)(j * tap_stride + c4 * step_stride) * 4u);
                         }
                     };
                     auto mma_chunk = [&](int j, int c0, const float (&af)[CH][MT]) {

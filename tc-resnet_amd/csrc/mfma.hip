@@ -804,16 +804,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a, const 
 
     // Weights stream from L1/L2 with a one-chunk (4 K-steps = 4*MT loads) lookahead so that their latency
     // hides behind the previous chunk's 8*MT MFMAs; activations come from the LDS image.
-    auto load_chunk = [&](const float* w, int j, int c0, float (&af)[CH][MT + 2]) {
+    // (round 6: buffer-descriptor loads as in conv_mfma_ksplit_kernel -- uniform base, constant lane offset, uniform running offset;
+    //  channel quads past C4 and output channels past Cout read a clamped address and are zeroed by the selects, as before)
+    const buf_rsrc wr = make_rsrc(a.w), wdr = make_rsrc(DOWN ? d.w : a.w), xrs = make_rsrc(a.x + (size_t)n0 * row);
+    auto load_chunk = [&](const buf_rsrc w, int j, int c0, float (&af)[CH][MT + 2]) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int c4 = c0 + i;
+            const int c4c = min(c4, C4 - 1);
+            const unsigned ws = (unsigned)(j * tap_stride + c4c * step_stride) * 4u, xs = (unsigned)(4 * c4c * a.tpi + j) * 4u;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                af[i][m] = (c4 < C4 && wv[m]) ? w[(size_t)j * tap_stride + (size_t)c4 * step_stride + wofs[m]] : 0.f;
+            for (int m = 0; m < MT; ++m) {
+                const float v = buf_load_f32(w, (unsigned)wofs[m] * 4u, ws);
+                af[i][m] = (c4 < C4 && wv[m]) ? v : 0.f;
+            }
             if (!LDSB) {
-                af[i][MT] = (c4 < C4) ? xb[xo[0] + 4 * c4 * a.tpi + j] : 0.f;
-                af[i][MT + 1] = (c4 < C4) ? xb[xo[1] + 4 * c4 * a.tpi + j] : 0.f;
+                const float v0 = buf_load_f32(xrs, (unsigned)xo[0] * 4u, xs), v1 = buf_load_f32(xrs, (unsigned)xo[1] * 4u, xs);
+                af[i][MT] = (c4 < C4) ? v0 : 0.f;
+                af[i][MT + 1] = (c4 < C4) ? v1 : 0.f;
             }
         }
     };
@@ -836,15 +844,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a, const 
     const int nchunks = K * cpj;
     float afA[CH][MT + 2], afB[CH][MT + 2];
     int j = 0, c0 = 0;
-    load_chunk(a.w, 0, 0, afA);
+    load_chunk(wr, 0, 0, afA);
     for (int ch = 0; ch < nchunks; ch += 2) {
         int j1 = j, c1 = c0 + CH;
         if (c1 >= C4) { c1 = 0; ++j1; }
-        if (ch + 1 < nchunks) load_chunk(a.w, j1, c1, afB);
+        if (ch + 1 < nchunks) load_chunk(wr, j1, c1, afB);
         mma_chunk(j, c0, afA, acc);
         int j2 = j1, c2 = c1 + CH;
         if (c2 >= C4) { c2 = 0; ++j2; }
-        if (ch + 2 < nchunks) load_chunk(a.w, j2, c2, afA);
+        if (ch + 2 < nchunks) load_chunk(wr, j2, c2, afA);
         if (ch + 1 < nchunks) mma_chunk(j1, c1, afB, acc);
         j = j2;
         c0 = c2;
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a, const 
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc2[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int cc = 0; cc < C4; cc += CH) {
-            load_chunk(d.w, 0, cc, afA);
+            load_chunk(wdr, 0, cc, afA);
             if (!LDSB) {
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {      // B of the centre tap (load_chunk fetched tap 0)
