@@ -420,7 +420,7 @@ enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the sh
        TCR_TUNE_WGRAD_TILES = 16, /* 9-tap filter gradients (16-byte-load kernel): output-channel tiles per launch (0: default 2 since round 6, 3 before; a layer of more tiles is split into launches that share one slab) */
        TCR_TUNE_DOWN_DGRAD = 17,  /* TC-ResNet backward, a block's 1x1 shortcut conv: 0 its data gradient runs early on the side stream and writes the block-input gradient first, conv_a's adds onto it (default for nets of <= 48 channels and, since round 6, for wider nets from 64 frames up, where it measured faster; 2: for every net); 1 conv_a's first, the shortcut's added behind it on the main stream (bitwise the same sums: one addition, commuted) */
        TCR_TUNE_BWD_LAZY_CFG = 18, /* lazy backward geometry: utterances per group + 100 * waves per job (0: cost model) + 10000 * (out channels * 10 + layers) to address one kernel of the net */
-       TCR_TUNE_PHASE_STATIC = 19, /* training forward phases of TCResNet8-1.0 / TCResNet14-1.5 at 49 / 98 frames: 0 compile-time-shaped kernels, utterance stride in LDS padded to the bank pattern (default); bit 0: generic layer walk; bit 1: unpadded stride (A/B arms, all bitwise) */
+       TCR_TUNE_PHASE_STATIC = 19, /* training forward phases of TCResNet8-1.0 / TCResNet14-1.5 at 49 / 98 frames: 0 compile-time-shaped kernels, utterance stride in LDS padded to the bank pattern (default); bit 0: generic layer walk; bit 1: unpadded stride; bit 2: the phases' staging one element at a time with its coefficients gathered from global memory (rounds 2-5) instead of float4 accesses + an LDS coefficient table (round 6) (A/B arms, all bitwise) */
        TCR_TUNE_WGRAD_WAVES = 20, /* on-the-fly 9-tap filter gradients: waves per workgroup (0: policy; 4, 8, 12, 16) */
        TCR_TUNE_WGRAD_LDS = 21,  /* first conv's filter gradient: 0 the LDS-staged nine-wave kernel (default), 1 the 16-byte-load kernel; per-layer chain, round 6 A/B arms (bitwise the default): 2 the first conv's dy written by an apply pass instead of built where the filter gradient loads it, 3 every layer's split-K slabs summed in one pass at the step's end instead of the first half of the units early */
        TCR_TUNE_LAZY_STAGE = 22, /* lazy backward: 0 the group's rows staged with 16-byte loads (default), 1 a dword gather per interior element (bitwise the same) */

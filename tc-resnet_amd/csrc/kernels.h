@@ -234,6 +234,7 @@ struct TrainPhaseArgs {
     int batch;
     float* pool_sum = nullptr;      // closing phase (n_layers == 0): also [B][c] sums over time of the staged activation, frames in order -- the head's pooling
     int group, n_groups, in_sz, cstat, stat_off, nw; // (set by the launcher)
+    int vec_stage = 0, tab_off = 0;                  // (launcher) staging with 16-byte accesses and the per-channel coefficients in an LDS table at tab_off
 };
 // rows_out: partial rows written per layer (= workgroups).  Returns 1 when the phase does not fit (nothing launched).
 int launch_train_phase(TrainPhaseArgs a, int* rows_out, hipStream_t s);

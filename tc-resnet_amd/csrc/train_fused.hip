@@ -207,6 +207,94 @@ __device__ __forceinline__ void phase_stage(const TrainPhaseArgs& a, float* lds,
     }
 }
 
+// The same staging with 16-byte accesses (round 6).  The group's source rows are ONE contiguous block of the planar layout and the LDS
+// image keeps an utterance's rows contiguous too, so a thread moves four consecutive elements at a time: one float4 load per source
+// tensor, one 16-byte LDS store, one float4 store per materialised tensor -- against a load, 2-4 coefficient gathers from global memory
+// and 2-3 stores PER ELEMENT in phase_stage (the staging was 148 of TCResNet14-1.5's 858 us of training forward with its loads worth
+// 17).  The per-channel coefficients (scale / shift of the source's and of the shortcut's BN) come from an LDS table, two 16-byte rows
+// per float4 (its channel and the next: tp >= 9, so four elements touch at most two rows).  Same expression per element: bitwise.
+template <int NT>
+__device__ __forceinline__ void phase_stage_v4(const TrainPhaseArgs& a, float* lds, const int n0, const int ng, const int tid, const int tp, const int row) {
+    const PhaseSrc& S = a.src;
+    const float inv_tp = 1.0f / (float)tp, inv_row = 1.0f / (float)row;
+    const size_t gbase = (size_t)n0 * row;
+    const int tot4 = ng * row / 4;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(S.a + gbase);
+    const f32x4* s4 = S.kind == 2 ? reinterpret_cast<const f32x4*>(S.s + gbase) : nullptr;
+    f32x4* ox4 = S.out_x ? reinterpret_cast<f32x4*>(S.out_x + gbase) : nullptr;
+    f32x4* os4 = (S.kind == 2 && S.s_kind == 1 && S.out_s) ? reinterpret_cast<f32x4*>(S.out_s + gbase) : nullptr;
+    const float* tab = lds + a.tab_off;
+    const bool lds_v4 = (a.in_sz & 3) == 0;
+    constexpr int SV = 2;
+    for (int f0 = tid; f0 < tot4; f0 += NT * SV) {
+        f32x4 va[SV], vs[SV];
+#pragma unroll
+        for (int u = 0; u < SV; ++u) {
+            const int f = min(f0 + u * NT, tot4 - 1);
+            va[u] = TCR_PWHATIF(4) ? (f32x4){1.f, 1.f, 1.f, 1.f} : a4[f];
+            vs[u] = (s4 && !TCR_PWHATIF(4)) ? s4[f] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < SV; ++u) {
+            const int f = f0 + u * NT;
+            if (f >= tot4) break;
+            const int i0 = 4 * f;
+            const int g = fast_div(i0, row, inv_row);
+            const int rem = i0 - g * row;                       // (row % 4 == 0: the four elements stay inside one utterance)
+            const int ch = fast_div(rem, tp, inv_tp);
+            f32x4 ka = (f32x4){0.f, 0.f, 0.f, 0.f}, kb = ka;
+            if (S.kind != 0) {
+                ka = *reinterpret_cast<const f32x4*>(tab + ch * 4);
+                kb = *reinterpret_cast<const f32x4*>(tab + min(ch + 1, S.c - 1) * 4);
+            }
+            f32x4 xo, so;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool nx = rem + e >= (ch + 1) * tp;
+                const int tt = rem + e - (nx ? ch + 1 : ch) * tp - kHalo;
+                const bool inside = tt >= 0 && tt < S.t;
+                const float sc_a = nx ? kb[0] : ka[0], sh_a = nx ? kb[1] : ka[1], sc_s = nx ? kb[2] : ka[2], sh_s = nx ? kb[3] : ka[3];
+                float x = 0.f, sv = 0.f;
+                if (S.kind == 0) {
+                    x = va[u][e];                               // plain rows (their halo is already zero)
+                } else if (inside) {
+                    x = fmaf(va[u][e], sc_a, sh_a);
+                    if (S.kind == 2) {
+                        sv = S.s_kind == 1 ? fmaxf(fmaf(vs[u][e], sc_s, sh_s), 0.f) : vs[u][e];
+                        x += sv;
+                    }
+                    x = fmaxf(x, 0.f);
+                }
+                xo[e] = x;
+                so[e] = sv;
+            }
+            if (lds_v4) {
+                *reinterpret_cast<f32x4*>(lds + g * a.in_sz + rem) = xo;
+            } else {                                            // (an utterance pitch padded to the bank pattern is not always a multiple of 4 floats)
+                float* dl = lds + g * a.in_sz + rem;
+                dl[0] = xo[0]; dl[1] = xo[1]; dl[2] = xo[2]; dl[3] = xo[3];
+            }
+            if (ox4 && !(TCR_PWHATIF(8) && xo[0] != 12345.f)) ox4[f] = xo;
+            if (os4 && !(TCR_PWHATIF(8) && xo[0] != 12345.f)) os4[f] = so;
+        }
+    }
+}
+
+// the staging table of phase_stage_v4: [c][4] = scale / shift of the source's BN, scale / shift of the shortcut's BN
+template <int NT>
+__device__ __forceinline__ void phase_fill_table(const TrainPhaseArgs& a, float* lds, const int tid) {
+    const PhaseSrc& S = a.src;
+    if (!a.vec_stage || S.kind == 0) return;
+    float* tab = lds + a.tab_off;
+    const bool sbn = S.kind == 2 && S.s_kind == 1;
+    for (int i = tid; i < S.c; i += NT) {
+        tab[i * 4 + 0] = S.ss_a[i];
+        tab[i * 4 + 1] = S.ss_a[S.c_pad_a + i];
+        tab[i * 4 + 2] = sbn ? S.ss_s[i] : 0.f;
+        tab[i * 4 + 3] = sbn ? S.ss_s[S.c_pad_s + i] : 0.f;
+    }
+}
+
 // The same layer with its shape known at COMPILE time (the phases of TCResNet8-1.0 and TCResNet14-1.5 at 49 / 98 frames), the K loop
 // of the eval kernel's static layer (fused.hip: fused_layer_s): taps rolled, a tap's weight fragments in two half-tap register sets that
 // are refilled for the next tap behind the other half's MFMAs, LDS operands at immediate offsets, division by constants.  Same job ->
@@ -352,12 +440,14 @@ __global__ __launch_bounds__(NW * 64) void train_phase_kernel(const TrainPhaseAr
     const int row = S.c * tp;                              // floats per utterance of the source rows
     const int nstat = NW * a.n_layers * 2 * a.cstat;
     for (int i = tid; i < nstat; i += NT) stat[i] = 0.f;
+    phase_fill_table<NT>(a, lds, tid);
 
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
-        __syncthreads();                                   // (previous group's convolutions are done with the LDS rows)
-        phase_stage<NT>(a, lds, n0, ng, tid, tp, row);
+        __syncthreads();                                   // (previous group's convolutions are done with the LDS rows; the tables are staged)
+        if (a.vec_stage) phase_stage_v4<NT>(a, lds, n0, ng, tid, tp, row);
+        else phase_stage<NT>(a, lds, n0, ng, tid, tp, row);
         if (a.n_layers == 0) {
             // Closing phase, round 6: the block output sits in LDS -- its sums over time, frames in order (the head's own order: bitwise its
             // pooling), leave with it, so that head_fwd_kernel starts from [B][C] instead of walking C x T scattered rows per utterance
@@ -407,11 +497,15 @@ __global__ __launch_bounds__(NW * 64) void train_phase_s_kernel(const TrainPhase
     const int r = lane & 15, q = lane >> 4;
     const int nstat = NW * NL * 2 * a.cstat;
     for (int i = tid; i < nstat; i += NT) stat[i] = 0.f;
+    phase_fill_table<NT>(a, lds, tid);
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
         __syncthreads();
-        if (!TCR_PWHATIF(128)) phase_stage<NT>(a, lds, n0, ng, tid, tp, row);
+        if (!TCR_PWHATIF(128)) {
+            if (a.vec_stage) phase_stage_v4<NT>(a, lds, n0, ng, tid, tp, row);
+            else phase_stage<NT>(a, lds, n0, ng, tid, tp, row);
+        }
         __syncthreads();
         if (TCR_PWHATIF(64)) continue;
         phase_layer_s<NW, K0, S0, CIN, CO0, TIN>(a, a.layer[0], lds, stat + (wave * NL + 0) * 2 * a.cstat, n0, ng, wave, r, q);
@@ -484,10 +578,17 @@ static bool configure_phase(TrainPhaseArgs& a, size_t* lds_out, int* grid_out) {
     int group = knob % 100 > 0 ? knob % 100 : (cstat >= 80 ? 4 : 8);
     while (group > 1 && ((size_t)group * in_sz + 64) * sizeof(float) + stat_bytes > 40 * 1024) --group;
     while (group > 1 && ceil_div(a.batch, group) < 512) --group;
-    const size_t lds = ((size_t)group * in_sz + 64) * sizeof(float) + stat_bytes;
+    const size_t tab_bytes = (size_t)(S.c * 4 + 4) * sizeof(float);                 // phase_stage_v4's coefficient table, behind the statistics
+    const size_t lds = ((size_t)group * in_sz + 64) * sizeof(float) + stat_bytes + tab_bytes;
     if (lds > 160 * 1024) return false;
     a.group = group; a.n_groups = ceil_div(a.batch, group); a.in_sz = in_sz; a.cstat = cstat;
     a.stat_off = group * in_sz + 64;
+    a.tab_off = (a.stat_off + NW * max(a.n_layers, 1) * 2 * cstat + 3) / 4 * 4;
+    auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    // 16-byte staging: an utterance's rows are whole float4s and every tensor it touches starts on one (TCR_TUNE_PHASE_STATIC bit 2: the
+    // one-element loop, A/B arm)
+    a.vec_stage = ((S.c * tp) % 4 == 0 && tp >= 9 && al16(S.a) && al16(S.kind == 2 ? S.s : nullptr) && al16(S.out_x) &&
+                   al16((S.kind == 2 && S.s_kind == 1) ? S.out_s : nullptr) && !(tune_get(TCR_TUNE_PHASE_STATIC) & 4)) ? 1 : 0;
     *lds_out = lds;
     *grid_out = min(a.n_groups, kPhaseMaxRows);
     return true;

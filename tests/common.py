@@ -707,7 +707,9 @@ def check_dscnn_mask_paths_agree(lib, size, batch, seed=5):
 
 def check_phase_kernel_variants(lib, name, width, batch, t=49, seed=8):
     """Training forward: the compile-time-shaped phase kernels with the bank-aligned utterance stride (default) are BITWISE the generic
-    layer walk and the unpadded stride (TCR_TUNE_PHASE_STATIC bits 0 / 1): same jobs, same accumulation and statistics order."""
+    layer walk and the unpadded stride (TCR_TUNE_PHASE_STATIC bits 0 / 1): same jobs, same accumulation and statistics order; the
+    phases' staging with float4 accesses + an LDS coefficient table (round 6; default) is bitwise the one-element loop (bit 2), alone
+    and on top of the generic walk / the unpadded stride (the LDS image's 16-byte stores need a pitch that is a multiple of 4)."""
     import tcresnet_amd as T
     dev = device_of(lib)
     rng = np.random.RandomState(seed)
@@ -718,7 +720,7 @@ def check_phase_kernel_variants(lib, name, width, batch, t=49, seed=8):
     ch = R.tcresnet_channels(name, float(width))
     outs = []
     try:
-        for v in (0, 1, 2, 3):
+        for v in (0, 1, 2, 3, 4, 6):
             lib.tcr_tune(19, v)
             net = T.TCResNet(name, ch, f, t, 12, lib=lib, device=dev)
             net.init_xavier(1)
