@@ -12,12 +12,15 @@ wav = synth_batch(4096, dev, 1234)
 fe = T.Frontend(window_size_samples=640, window_stride_samples=320, lib=lib, device=dev)
 net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, fe.n_frames, 12, lib=lib, device=dev); net.init_xavier(0)
 feat = fe(wav)
-for _ in range(20): lg, pr = net.forward_infer(feat)
-torch.cuda.synchronize()
-lg, pr = net.forward_infer(feat)
-torch.cuda.synchronize()
-v = pr.cpu().numpy().reshape(-1, 8, 12)[:, 0, :]          # first utterance of every group of 8
 names = ["conv0", "down0+conv0_0", "conv0_1", "down1+conv1_0", "conv1_1", "down2+conv2_0", "conv2_1", "head", "-", "-", "-", "-"]
-print("groups:", v.shape[0], " total cycles per group (median): %.0f" % np.median(v[:, :8].sum(1)))
-for i in range(8):
-    print(f"{names[i]:16s} median {np.median(v[:, i]):8.0f}  p10 {np.percentile(v[:, i], 10):8.0f}  p90 {np.percentile(v[:, i], 90):8.0f} cycles")
+for knob in (int(x) for x in os.environ.get("TS_KNOBS", "0").split(",")):          # arms of TCR_TUNE_NET_FUSED (0: jobs of two tiles, 8: units)
+    lib.tcr_tune(3, knob)
+    for _ in range(20): lg, pr = net.forward_infer(feat)
+    torch.cuda.synchronize()
+    lg, pr = net.forward_infer(feat)
+    torch.cuda.synchronize()
+    v = pr.cpu().numpy().reshape(-1, 8, 12)[:, 0, :]          # first utterance of every group of 8
+    print(f"knob {knob}: groups:", v.shape[0], " total cycles per group (median): %.0f" % np.median(v[:, :8].sum(1)))
+    for i in range(8):
+        print(f"{names[i]:16s} median {np.median(v[:, i]):8.0f}  p10 {np.percentile(v[:, i], 10):8.0f}  p90 {np.percentile(v[:, i], 90):8.0f} cycles")
+lib.tcr_tune(3, 0)

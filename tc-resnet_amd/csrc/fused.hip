@@ -240,6 +240,157 @@ __device__ __forceinline__ void fused_layer_t(const FusedArgs& a, const FusedLay
 // per layer): 17.5 M instead of 21.3 M VALU and 4.9 M instead of 11 M SALU instructions per launch, bitwise the same results.
 // (Tried with it and dropped: the taps fully unrolled into a software pipeline -- weight fragments two / three stages ahead in a
 // register ring, LDS operands one stage ahead, a scheduling barrier per stage: 131 / 133 us vs 125 us, SQ_WAIT_INST_ANY UP 11 %.)
+// One job of the static-shape layer: NTJ 16-position tiles x 16 output channels (row tile m); cc[nt] = the position index of this lane's
+// column in tile nt (>= npos: an empty column -- computed on a clamped address, stored into the pad).
+// AHEAD: 0 the rolled tap loop with two half-tap weight sets; 1 a whole tap of weight lookahead.  (Measured and removed, round 6: a ring
+// of three full-tap sets running on ACROSS the jobs of a wave -- two taps of lookahead, the next job's first two taps requested behind
+// this job's last two: 98.9 us against 95.3 for the one-tap form, 128 registers + 124 B of scratch.)
+template <int K, int S, int CIN, int COUT, int TIN, bool HAS_RES, int NTJ, bool WLDS, int AHEAD = 0>
+__device__ __forceinline__ void fused_job_s(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
+                                            float* yout, const float* res, const float* w, const int npos, const int m, const int (&cc)[NTJ],
+                                            const int r, const int q) {
+    constexpr int TOUT = (TIN + S - 1) / S;
+    constexpr int PADT = ((TOUT - 1) * S + K - TIN) > 0 ? ((TOUT - 1) * S + K - TIN) : 0;
+    constexpr int PADLO = PADT / 2;
+    constexpr int TPI = TIN + 2 * kHalo, TPO = TOUT + 2 * kHalo;
+    constexpr int C4 = CIN / 4;
+    constexpr int WSTEP = 4 * COUT, XSTEP = 4 * TPI;
+    const int out_sz = L.out_sz;
+    const int res_sz = L.res_sz;
+    const float* scale = a.ss + L.ss_off;
+    const float* shift = scale + L.c_pad;
+    int gg[NTJ], tt[NTJ];
+    const float* xp[NTJ];
+#pragma unroll
+    for (int nt = 0; nt < NTJ; ++nt) {
+        const int p = min(cc[nt], npos - 1);
+        gg[nt] = p / TOUT;
+        tt[nt] = p - gg[nt] * TOUT;
+        xp[nt] = xin + gg[nt] * in_sz + q * TPI + tt[nt] * S + kHalo - PADLO;
+    }
+    const float* wp = w + q * COUT + min(m * 16 + r, COUT - 1);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int co = min(m * 16 + q * 4 + reg, COUT - 1);
+        sc[reg] = scale[co];
+        sh[reg] = shift[co];
+    }
+    f32x4 acc[NTJ];
+#pragma unroll
+    for (int nt = 0; nt < NTJ; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (AHEAD == 1) {
+        // A whole tap of lookahead for the narrow layers (round 6): in the loop below the compiler sinks a half-tap's refill loads to the
+        // END of the tap body (ISA: four global_load_dword behind the last MFMA, `s_waitcnt vmcnt(3)` in front of the next tap's first), so
+        // with 8 - 12 MFMAs per tap (16 / 24 input channels) every tap waits out an L1 / L2 round trip.  Two full-tap register sets that
+        // trade roles (taps unrolled by two: no copies): the NEXT tap's fragments are requested -- through a buffer descriptor: uniform
+        // base + constant lane offset + uniform tap offset, no vector address arithmetic -- before this tap's LDS reads and MFMAs.  Same
+        // accumulation order: bitwise.
+        const buf_rsrc wr = make_rsrc(w);
+        const unsigned wl = (unsigned)(q * COUT + min(m * 16 + r, COUT - 1)) * 4u;
+        float w0[C4], w1[C4];
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) w0[c4] = buf_load_f32(wr, wl, (unsigned)(c4 * WSTEP) * 4u);
+        auto tap = [&](const int j, const float (&wu)[C4], float (&wf)[C4], const bool fill) {
+            if (fill) {
+#pragma unroll
+                for (int c4 = 0; c4 < C4; ++c4) wf[c4] = buf_load_f32(wr, wl, (unsigned)(((j + 1) * C4 + c4) * WSTEP) * 4u);
+            }
+            float b[NTJ][C4];
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4)
+#pragma unroll
+                for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = xp[nt][c4 * XSTEP + j];
+            __builtin_amdgcn_sched_barrier(0);                  // (the requests stay in front of the tap's MFMAs)
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4)
+#pragma unroll
+                for (int nt = 0; nt < NTJ; ++nt) acc[nt] = TCR_MFMA(wu[c4], b[nt][c4], acc[nt]);
+        };
+#pragma unroll 1
+        for (int j = 0; j + 2 < K; j += 2) {
+            tap(j, w0, w1, true);
+            tap(j + 1, w1, w0, true);
+        }
+        if constexpr (K % 2 == 1) {
+            tap(K - 1, w0, w1, false);
+        } else {
+            tap(K - 2, w0, w1, true);
+            tap(K - 1, w1, w0, false);
+        }
+    } else {
+    // rolled taps, two half-tap weight sets refilled for the next tap (the round-2 loop)
+    constexpr int H0 = C4 / 2, H1 = C4 - H0;
+    float wa[H0 > 0 ? H0 : 1], wb[H1];
+#pragma unroll
+    for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[c4 * WSTEP];
+#pragma unroll
+    for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(H0 + c4) * WSTEP];
+    // (throughput kernels: rolled taps -- 128-register budget; small-batch kernel: unrolled, the LDS operand and weight reads of the
+    //  following taps move ahead of the MFMAs)
+    constexpr int kTapUnroll = WLDS ? K : 1;
+#pragma unroll kTapUnroll
+    for (int j = 0; j < K; ++j) {
+        const int jn = TCR_WHATIF(2) ? 0 : min(j + 1, K - 1);
+        const int jx = TCR_WHATIF(4) ? 0 : j;
+        {
+            float b[NTJ][H0 > 0 ? H0 : 1];
+#pragma unroll
+            for (int c4 = 0; c4 < H0; ++c4)
+#pragma unroll
+                for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = xp[nt][c4 * XSTEP + jx];
+#pragma unroll
+            for (int c4 = 0; c4 < H0; ++c4)
+#pragma unroll
+                for (int nt = 0; nt < NTJ; ++nt) acc[nt] = TCR_MFMA(wa[c4], b[nt][c4], acc[nt]);
+#pragma unroll
+            for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[(jn * C4 + c4) * WSTEP];
+        }
+        {
+            float b[NTJ][H1];
+#pragma unroll
+            for (int c4 = 0; c4 < H1; ++c4)
+#pragma unroll
+                for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = xp[nt][(H0 + c4) * XSTEP + jx];
+#pragma unroll
+            for (int c4 = 0; c4 < H1; ++c4)
+#pragma unroll
+                for (int nt = 0; nt < NTJ; ++nt) acc[nt] = TCR_MFMA(wb[c4], b[nt][c4], acc[nt]);
+#pragma unroll
+            for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(jn * C4 + H0 + c4) * WSTEP];
+        }
+    }
+    }
+    // ---- epilogue: folded BN (+ shortcut) (+ ReLU) -> LDS rows ----
+    const int dump = a.buf_off[2] + a.group * a.buf_sz[2] + (q * 16 + r);
+    const float lo = L.relu ? 0.f : -3.4e38f;
+    float rv[NTJ][4];
+    if (HAS_RES) {
+#pragma unroll
+        for (int nt = 0; nt < NTJ; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = min(m * 16 + q * 4 + reg, COUT - 1);
+                rv[nt][reg] = res[gg[nt] * res_sz + co * TPO + kHalo + tt[nt]];
+            }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTJ; ++nt) {
+        const bool pv = cc[nt] < npos;
+        const f32x4 ac = acc[nt];
+        const int base = gg[nt] * out_sz + kHalo + tt[nt];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int co = m * 16 + q * 4 + reg;
+            float v = fmaf(ac[reg], sc[reg], sh[reg]);
+            if (HAS_RES) v = fmaxf(v + rv[nt][reg], 0.f);       // tc_resnet.py:40-41
+            else v = fmaxf(v, lo);
+            const bool ok = pv && (COUT % 16 == 0 || co < COUT) && !(TCR_WHATIF(32) && v != 12345.f);
+            yout[ok ? base + co * TPO : dump - a.buf_off[L.out_buf]] = v;
+        }
+    }
+}
+
 template <int NW, int K, int S, int CIN, int COUT, int TIN, bool HAS_RES, int NTJ = 2, bool WLDS = false>
 __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
                                               float* lds, const int ng, const int wave, const int r_in, const int q_in,
@@ -249,23 +400,15 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
     const int oz = opaque_zero();
     const int r = r_in + oz, q = q_in + oz;
     constexpr int TOUT = (TIN + S - 1) / S;
-    constexpr int PADT = ((TOUT - 1) * S + K - TIN) > 0 ? ((TOUT - 1) * S + K - TIN) : 0;
-    constexpr int PADLO = PADT / 2;
-    constexpr int TPI = TIN + 2 * kHalo, TPO = TOUT + 2 * kHalo;
-    constexpr int C4 = CIN / 4, NRT = (COUT + 15) / 16;
-    constexpr int WSTEP = 4 * COUT, XSTEP = 4 * TPI;
+    constexpr int NRT = (COUT + 15) / 16;
     constexpr int JP = 16 * NTJ;            // positions per job
     static_assert(CIN % 4 == 0, "channel quads");
     static_assert(NTJ == 1 || NTJ == 2 || NTJ == 4, "one, two or four 16-position tiles per job");
     float* yout = lds + a.buf_off[L.out_buf];
     const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
-    const int out_sz = L.out_sz;
-    const int res_sz = L.res_sz;
     const int npos = ng * TOUT;
     const int ncp = (npos + JP - 1) / JP;
     const float* w = WLDS ? lds + w_lds : a.params + L.w_off;
-    const float* scale = a.ss + L.ss_off;
-    const float* shift = scale + L.c_pad;
     // Which of a job's positions a lane's tile columns hold (the columns of the implicit GEMM are independent: any assignment
     // gives the same sums).  One ds_read_b32 serves lanes (q, q + 1) x 16 columns against 32 banks: with stride 2 consecutive columns
     // are 2 floats apart and the odd row pitch puts row q + 1 on the other bank parity; with stride 1 the columns of a tile are every
@@ -279,95 +422,53 @@ __device__ __forceinline__ void fused_layer_s(const FusedArgs& a, const FusedLay
     constexpr bool IL = S == 1;
     for (int job = wave; job < ncp * NRT; job += NW) {
         const int cp = job / NRT, m = job - cp * NRT;
-        int cc[NTJ], gg[NTJ], tt[NTJ];
-        const float* xp[NTJ];
+        int cc[NTJ];
 #pragma unroll
-        for (int nt = 0; nt < NTJ; ++nt) {
-            cc[nt] = (IL && NTJ > 1) ? cp * JP + 32 * (nt >> 1) + 2 * r + (nt & 1) : cp * JP + 16 * nt + r;
-            const int p = min(cc[nt], npos - 1);
-            gg[nt] = p / TOUT;
-            tt[nt] = p - gg[nt] * TOUT;
-            xp[nt] = xin + gg[nt] * in_sz + q * TPI + tt[nt] * S + kHalo - PADLO;
-        }
-        const float* wp = w + q * COUT + min(m * 16 + r, COUT - 1);
-        float sc[4], sh[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int co = min(m * 16 + q * 4 + reg, COUT - 1);
-            sc[reg] = scale[co];
-            sh[reg] = shift[co];
-        }
-        f32x4 acc[NTJ];
-#pragma unroll
-        for (int nt = 0; nt < NTJ; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // rolled taps, two half-tap weight sets refilled for the next tap (the round-2 loop)
-        constexpr int H0 = C4 / 2, H1 = C4 - H0;
-        float wa[H0 > 0 ? H0 : 1], wb[H1];
-#pragma unroll
-        for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[c4 * WSTEP];
-#pragma unroll
-        for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(H0 + c4) * WSTEP];
-        // (throughput kernels: rolled taps -- 128-register budget; small-batch kernel: unrolled, the LDS operand and weight reads of the
-        //  following taps move ahead of the MFMAs)
-        constexpr int kTapUnroll = WLDS ? K : 1;
-#pragma unroll kTapUnroll
-        for (int j = 0; j < K; ++j) {
-            const int jn = TCR_WHATIF(2) ? 0 : min(j + 1, K - 1);
-            const int jx = TCR_WHATIF(4) ? 0 : j;
-            {
-                float b[NTJ][H0 > 0 ? H0 : 1];
-#pragma unroll
-                for (int c4 = 0; c4 < H0; ++c4)
-#pragma unroll
-                    for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = xp[nt][c4 * XSTEP + jx];
-#pragma unroll
-                for (int c4 = 0; c4 < H0; ++c4)
-#pragma unroll
-                    for (int nt = 0; nt < NTJ; ++nt) acc[nt] = TCR_MFMA(wa[c4], b[nt][c4], acc[nt]);
-#pragma unroll
-                for (int c4 = 0; c4 < H0; ++c4) wa[c4] = wp[(jn * C4 + c4) * WSTEP];
-            }
-            {
-                float b[NTJ][H1];
-#pragma unroll
-                for (int c4 = 0; c4 < H1; ++c4)
-#pragma unroll
-                    for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = xp[nt][(H0 + c4) * XSTEP + jx];
-#pragma unroll
-                for (int c4 = 0; c4 < H1; ++c4)
-#pragma unroll
-                    for (int nt = 0; nt < NTJ; ++nt) acc[nt] = TCR_MFMA(wb[c4], b[nt][c4], acc[nt]);
-#pragma unroll
-                for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(jn * C4 + H0 + c4) * WSTEP];
-            }
-        }
-        // ---- epilogue: folded BN (+ shortcut) (+ ReLU) -> LDS rows ----
-        const int dump = a.buf_off[2] + a.group * a.buf_sz[2] + (q * 16 + r);
-        const float lo = L.relu ? 0.f : -3.4e38f;
-        float rv[NTJ][4];
-        if (HAS_RES) {
-#pragma unroll
-            for (int nt = 0; nt < NTJ; ++nt)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int co = min(m * 16 + q * 4 + reg, COUT - 1);
-                    rv[nt][reg] = res[gg[nt] * res_sz + co * TPO + kHalo + tt[nt]];
-                }
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTJ; ++nt) {
-            const bool pv = cc[nt] < npos;
-            const f32x4 ac = acc[nt];
-            const int base = gg[nt] * out_sz + kHalo + tt[nt];
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int co = m * 16 + q * 4 + reg;
-                float v = fmaf(ac[reg], sc[reg], sh[reg]);
-                if (HAS_RES) v = fmaxf(v + rv[nt][reg], 0.f);       // tc_resnet.py:40-41
-                else v = fmaxf(v, lo);
-                const bool ok = pv && (COUT % 16 == 0 || co < COUT) && !(TCR_WHATIF(32) && v != 12345.f);
-                yout[ok ? base + co * TPO : dump - a.buf_off[L.out_buf]] = v;
-            }
+        for (int nt = 0; nt < NTJ; ++nt) cc[nt] = (IL && NTJ > 1) ? cp * JP + 32 * (nt >> 1) + 2 * r + (nt & 1) : cp * JP + 16 * nt + r;
+        fused_job_s<K, S, CIN, COUT, TIN, HAS_RES, NTJ, WLDS>(a, L, xin, in_sz, yout, res, w, npos, m, cc, r, q);
+    }
+}
+
+// The same layer with its work dealt in UNITS of one 16-position tile x 16 output channels (round 6).  fused_layer_s deals whole jobs of
+// two tiles round-robin: 14 jobs on 8 waves in block 0 (a SIMD hosts waves w and w + 4 of the workgroup: 4 / 4 / 3 / 3 jobs), 6 jobs in
+// block 2 (2 / 2 / 1 / 1: two SIMDs carry twice the matrix work of the other two), and the positions of a group are padded to 32.  Here a
+// wave owns a contiguous run of units, as even as units allow -- the first U mod 8 waves one more, so the SIMDs differ by at most one unit
+// (block 0: 7 / 7 / 6 / 6 of 26 units instead of 8 / 8 / 6 / 6 of 28; block 1: 14 units instead of 16; block 2: 3 / 3 / 3 / 3 instead of
+// 4 / 4 / 2 / 2) --, and walks it two units at a time where both lie in the same row tile (one weight fragment feeds both), one otherwise.
+// Columns of the implicit GEMM are independent: bitwise the job form.  Stride-1 layers keep "a tile = every other position of a run of
+// 32" (the bank picture above); a last run of <= 16 positions is one tile of consecutive positions.
+template <int NW, int K, int S, int CIN, int COUT, int TIN, bool HAS_RES, int AHEAD = 0>
+__device__ __forceinline__ void fused_layer_u(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
+                                              float* lds, const int ng, const int wave, const int r_in, const int q_in) {
+    const int oz = opaque_zero();
+    const int r = r_in + oz, q = q_in + oz;
+    constexpr int TOUT = (TIN + S - 1) / S;
+    constexpr int NRT = (COUT + 15) / 16;
+    constexpr bool IL = S == 1;
+    float* yout = lds + a.buf_off[L.out_buf];
+    const float* res = L.res_buf >= 0 ? lds + a.buf_off[L.res_buf] : nullptr;
+    const int npos = ng * TOUT;
+    const int full = npos >> 5, rem = npos & 31;
+    const int nt16 = IL ? 2 * full + (rem == 0 ? 0 : (rem <= 16 ? 1 : 2)) : (npos + 15) >> 4;
+    const int il_end = (IL && rem > 0 && rem <= 16) ? 2 * full : nt16;          // tiles from il_end on: consecutive positions
+    const int U = NRT * nt16;
+    const int per = U / NW, extra = U - per * NW;
+    // (measured and removed: the two workgroups of a CU handing their spare units to different SIMDs -- waves rotated by two in every
+    //  other workgroup, by blockIdx bit 8 or bit 3: 96.5 / 95.9 us against 95.9)
+    int u = wave * per + min(wave, extra);
+    const int end = u + per + (wave < extra ? 1 : 0);
+    const float* w = a.params + L.w_off;
+    auto col = [&](int c) { return (IL && c < il_end) ? (c >> 1) * 32 + 2 * r + (c & 1) : (IL ? full * 32 + r : c * 16 + r); };
+    while (u < end) {
+        const int m = u / nt16, c = u - m * nt16;
+        if (c + 1 < nt16 && u + 1 < end) {
+            const int cc[2] = {col(c), col(c + 1)};
+            fused_job_s<K, S, CIN, COUT, TIN, HAS_RES, 2, false, AHEAD>(a, L, xin, in_sz, yout, res, w, npos, m, cc, r, q);
+            u += 2;
+        } else {
+            const int cc[1] = {col(c)};
+            fused_job_s<K, S, CIN, COUT, TIN, HAS_RES, 1, false, AHEAD>(a, L, xin, in_sz, yout, res, w, npos, m, cc, r, q);
+            u += 1;
         }
     }
 }
@@ -594,7 +695,9 @@ __device__ __forceinline__ void fused_layer_sel(const FusedArgs& a, const FusedL
     if constexpr (WD < 0) fused_layer_t<NW, K, S, CIN, COUT, TIN>(a, L, xin, in_sz, lds, ng, wave, r, q);
     else {
         if constexpr (HALO) fused_zero_halo<NW * 64, COUT, (TIN + S - 1) / S>(lds + a.buf_off[L.out_buf], L.out_sz, ng, (int)threadIdx.x);
-        fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES, NTJ, WLDS>(a, L, xin, in_sz, lds, ng, wave, r, q, w_lds);
+        if constexpr (NTJ == 0) fused_layer_u<NW, K, S, CIN, COUT, TIN, HAS_RES>(a, L, xin, in_sz, lds, ng, wave, r, q);      // (units: see fused_layer_u)
+        else if constexpr (NTJ == 3) fused_layer_u<NW, K, S, CIN, COUT, TIN, HAS_RES, (CIN <= 24 ? 1 : 0)>(a, L, xin, in_sz, lds, ng, wave, r, q);   // (+ a whole tap of weight lookahead in the narrow layers)
+        else fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES, NTJ, WLDS>(a, L, xin, in_sz, lds, ng, wave, r, q, w_lds);
     }
 }
 
@@ -619,7 +722,8 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
 #define TCR_TC8_BARRIER __syncthreads()
 #endif
     // (tiles per job: two; NTJ0 = 4: four for block 0's layers -- 16 / 24 channels at T0 / 2 frames --, the TCR_TUNE_NET_FUSED = 5 arm)
-#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9), (K_ != 1 && LI != 9), ((LI >= 1 && LI <= 3 && NTJ0 == 4) ? 4 : 2)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, ng, wave, r, q)
+    // (NTJ0 = 0: the nine-tap layers' work dealt in 16-position units, fused_layer_u)
+#define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9), (K_ != 1 && LI != 9), ((LI >= 1 && LI <= 3 && NTJ0 == 4) ? 4 : (((NTJ0 == 0 || NTJ0 == 3) && K_ == 9) ? NTJ0 : 2))>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, ng, wave, r, q)
     for (int grp = blockIdx.x; grp < (TCR_WHATIF(512) ? 0 : a.n_groups); grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
@@ -767,7 +871,7 @@ __global__ __launch_bounds__(NW * 64) void net_small_tc8_kernel(const FusedArgs 
 // frames: the same static layer (`fused_layer_s`), first conv (`fused_conv0_g`: 24 output channels = two row tiles) and head as the
 // TCResNet8 instance.  Blocks 1 / 3 / 5 have identity shortcuts: their second conv adds the block input, which lives in its own output
 // buffer (each lane reads the residual of exactly the elements it then writes).
-template <int NW, int T0>
+template <int NW, int T0, int NTJ0 = 3>       // NTJ0: the nine-tap layers as in net_fused_tc8_kernel (3: units + lookahead, 0: units, 2: jobs of two tiles)
 __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc14w_kernel(const FusedArgs a) {
     constexpr int NT = NW * 64;
     constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2, T3 = (T2 + 1) / 2;
@@ -777,7 +881,7 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc14w_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int row = a.in_c * a.in_tp;
-#define TCR_L(LI, K_, S_, CI_, CO_, T_, RES_, HALO_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, 0, RES_, HALO_>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, ng, wave, r, q)
+#define TCR_L(LI, K_, S_, CI_, CO_, T_, RES_, HALO_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, 0, RES_, HALO_, (K_ == 9 ? NTJ0 : 2)>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, ng, wave, r, q)
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
         const int n0 = grp * a.group;
         const int ng = min(a.group, a.batch - n0);
@@ -1068,12 +1172,17 @@ int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, 
     }
     // TCR_TUNE_NET_FUSED: 0 branch-free epilogue (default); 4: the round-2 static-shape kernel (A/B arm)
     const bool r2 = tune_get(TCR_TUNE_NET_FUSED) == 4;
+    // Round 6 default: the nine-tap layers' work dealt in 16-position units (fused_layer_u) + a whole tap of weight lookahead in the layers of
+    // <= 24 input channels (fused_job_s AHEAD): 105.1 -> 98.6 -> 95.3 us at 49 frames, 182 -> 178 -> 175 at 98, bitwise.  A/B arms: 8 the jobs of
+    // two tiles dealt round-robin (rounds 3-5), 9 units without the lookahead.
+    const bool j2 = tune_get(TCR_TUNE_NET_FUSED) == 8;
+    const bool ju = tune_get(TCR_TUNE_NET_FUSED) == 9;
     const bool j4 = tune_get(TCR_TUNE_NET_FUSED) == 5;         // 5: four 16-position tiles per job in block 0's layers (A/B arm, bitwise; measured 103.6 vs 103.2 us at 49 frames, 184.9 vs 181.2 at 98: no gain)
-#define TCR_FS(NW_, T_) if (tc8 == T_ && waves == NW_) kern = r2 ? net_fused_tc8_kernel<NW_, T_, -1> : (j4 ? net_fused_tc8_kernel<NW_, T_, 0, 4> : net_fused_tc8_kernel<NW_, T_, 0, 2>);
+#define TCR_FS(NW_, T_) if (tc8 == T_ && waves == NW_) kern = r2 ? net_fused_tc8_kernel<NW_, T_, -1> : (j4 ? net_fused_tc8_kernel<NW_, T_, 0, 4> : (ju ? net_fused_tc8_kernel<NW_, T_, 0, 0> : (j2 ? net_fused_tc8_kernel<NW_, T_, 0, 2> : net_fused_tc8_kernel<NW_, T_, 0, 3>)));
     TCR_FS(4, 49) TCR_FS(8, 49) TCR_FS(16, 49) TCR_FS(4, 98) TCR_FS(8, 98) TCR_FS(16, 98)
 #undef TCR_FS
     const int tc14 = (kern || tune_get(TCR_TUNE_NET_FUSED) == 3 || tune_get(TCR_TUNE_NET_FUSED) == 4) ? 0 : fused_tc14w_frames(a);
-#define TCR_F14(NW_, T_) if (tc14 == T_ && waves == NW_) kern = net_fused_tc14w_kernel<NW_, T_>;
+#define TCR_F14(NW_, T_) if (tc14 == T_ && waves == NW_) kern = ju ? net_fused_tc14w_kernel<NW_, T_, 0> : (j2 ? net_fused_tc14w_kernel<NW_, T_, 2> : net_fused_tc14w_kernel<NW_, T_, 3>);
     TCR_F14(8, 49) TCR_F14(16, 49) TCR_F14(8, 98) TCR_F14(16, 98)
 #undef TCR_F14
     if (kern) ring = 0;

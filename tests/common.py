@@ -790,3 +790,27 @@ def check_backward_knob_variants(lib, knob, values, bitwise, name="TCResNet8", w
             assert torch.equal(grads[0], g), float((grads[0] - g).abs().max())
         else:
             assert float((grads[0] - g).abs().max()) <= rtol * scale, (float((grads[0] - g).abs().max()), scale)
+
+
+def check_fused_eval_job_forms(lib, name, width, batch, t=49, seed=9):
+    """Static fused eval kernels (fused.hip), the nine-tap layers' three job forms: work dealt in 16-position units + a whole tap of weight
+    lookahead in the narrow layers (round-6 default), units without the lookahead (TCR_TUNE_NET_FUSED = 9), jobs of two tiles dealt
+    round-robin (8: rounds 3-5).  The columns of the implicit GEMM are independent and every form accumulates tap-major, channel quads
+    inner: BITWISE, for whole and ragged groups; the per-layer kernels (1) agree within the logit tolerance."""
+    import tcresnet_amd as T
+    dev = device_of(lib)
+    rng = np.random.RandomState(seed)
+    x = T.features_to_planar(torch.from_numpy(rng.uniform(-2, 2, (batch, t, 40)).astype(np.float32)).to(dev), lib=lib)
+    net = T.TCResNet(name, R.tcresnet_channels(name, float(width)), 40, t, 12, lib=lib, device=dev)
+    net.init_xavier(3)
+    outs = {}
+    try:
+        for knob in (0, 8, 9, 1):
+            lib.tcr_tune(3, knob)
+            lg, pr = net.forward_infer(x)
+            outs[knob] = (lg.clone(), pr.clone())
+    finally:
+        lib.tcr_tune(3, 0)
+    for knob in (8, 9):
+        assert torch.equal(outs[knob][0], outs[0][0]) and torch.equal(outs[knob][1], outs[0][1]), (name, batch, t, knob)
+    assert float((outs[1][0] - outs[0][0]).abs().max()) < LOGIT_TOL, (name, batch, t)

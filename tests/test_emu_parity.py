@@ -290,6 +290,11 @@ def test_static_phase_kernels_are_bitwise_the_generic_walk(emu_lib, name, width,
     Cm.check_phase_kernel_variants(emu_lib, name, width, batch, t)
 
 
+@pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 11, 49), ("TCResNet14", 1.5, 9, 49)])
+def test_fused_eval_job_forms_are_bitwise(emu_lib, name, width, batch, t):
+    Cm.check_fused_eval_job_forms(emu_lib, name, width, batch, t)
+
+
 @pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 13, 49), ("TCResNet14", 1.5, 6, 98)])
 def test_first_conv_filter_gradient_kernels_agree(emu_lib, name, width, batch, t):
     Cm.check_first_conv_wgrad_kernels_agree(emu_lib, name, width, batch, t)

@@ -369,7 +369,11 @@ def test_every_kernel_path_agrees(hip_lib):
                             ("fused, generic walk, 4 waves", {3: 3, 5: 404}),
                             ("fused, utterance strides not padded to the bank pattern", {3: 7}),
                             ("fused, four tiles per job in block 0's layers", {3: 5}),
-                            ("fused, four tiles per job in block 0, 3 utterances per group", {3: 5, 4: 3})):
+                            ("fused, four tiles per job in block 0, 3 utterances per group", {3: 5, 4: 3}),
+                            ("fused, nine-tap layers as jobs of two tiles dealt round-robin (rounds 3-5)", {3: 8}),
+                            ("fused, jobs of two tiles, 3 utterances per group", {3: 8, 4: 3}),
+                            ("fused, units without the weight lookahead", {3: 9}), ("fused, units without lookahead, 5 utterances, 4 waves", {3: 9, 4: 5, 5: 404}),
+                            ("fused, 5 utterances, 4 waves", {4: 5, 5: 404}), ("fused, 7 utterances", {4: 7})):
             for k, v in knobs.items():
                 hip_lib.tcr_tune(k, v)
             results[name] = net.forward_infer(feat0)[0].clone()
@@ -395,6 +399,12 @@ def test_every_kernel_path_agrees(hip_lib):
     finally:
         for k in range(7):
             hip_lib.tcr_tune(k, 0)
+
+
+@pytest.mark.parametrize("name,width,batch,t", [("TCResNet8", 1.0, 4096, 49), ("TCResNet8", 1.0, 131, 98), ("TCResNet8", 1.0, 517, 49),
+                                                ("TCResNet14", 1.5, 203, 49), ("TCResNet14", 1.5, 1024, 98)])
+def test_fused_eval_job_forms_are_bitwise(hip_lib, name, width, batch, t):
+    Cm.check_fused_eval_job_forms(hip_lib, name, width, batch, t)
 
 
 def test_feature_prefetch_matches_sequential(hip_lib):
