@@ -721,6 +721,8 @@ __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc8_ke
 #else
 #define TCR_TC8_BARRIER __syncthreads()
 #endif
+    // (Measured and removed, round 6: the upper half of the waves running a block's first conv BEFORE its shortcut conv -- both read the same rows --
+    //  so that a SIMD's two waves are not in the shortcut's load / store-bound jobs together: 96.5 vs 95.6 us at 49 frames, 173.9 vs 176.1 at 98.)
     // (tiles per job: two; NTJ0 = 4: four for block 0's layers -- 16 / 24 channels at T0 / 2 frames --, the TCR_TUNE_NET_FUSED = 5 arm)
     // (NTJ0 = 0: the nine-tap layers' work dealt in 16-position units, fused_layer_u)
 #define TCR_TC8(LI, K_, S_, CI_, CO_, T_) fused_layer_sel<NW, K_, S_, CI_, CO_, T_, WD, (LI == 3 || LI == 6 || LI == 9), (K_ != 1 && LI != 9), ((LI >= 1 && LI <= 3 && NTJ0 == 4) ? 4 : (((NTJ0 == 0 || NTJ0 == 3) && K_ == 9) ? NTJ0 : 2))>(a, a.layer[LI], lds + a.buf_off[a.layer[LI].in_buf], a.layer[LI].in_sz, lds, ng, wave, r, q)
