@@ -478,7 +478,10 @@ __device__ __forceinline__ void fused_layer_u(const FusedArgs& a, const FusedLay
 // exposed L1 / L2 / HBM latencies per job -- the layer took 25 us of the kernel's 125 (timing what-if, scripts/whatif_net.py) for
 // 10 % of its MFMAs.  Here a job requests ALL its operands up front (per lane 10 channel quads x 3 taps = three consecutive
 // floats each, and the 30 weight fragments; a job is 16 positions so that this fits the register budget), then runs its 30 MFMAs:
-// one exposed latency per job.  Same accumulation order.
+// one exposed latency per job.  Same accumulation order.  (Measured and removed, round 6: the next job's activations requested a whole job
+// ahead -- 90 operand registers, 128 + 200 B of scratch: 103.7 us against 95.4 -- and half a job ahead in two sets of 15 -- less scratch
+// than this form, 96.4 against 95.3: the phase reads the whole feature tensor, 37 MB at batch 4096, with every wave of the chip asking at
+// the same moment; it is not a per-job latency.)
 template <int NW, int T0, bool WLDS = false>
 __device__ __forceinline__ void fused_conv0_s(const FusedArgs& a, const FusedLayer& L, const float* __restrict__ xin, const int in_sz,
                                               float* lds, const int ng, const int wave, const int r_in, const int q_in,
