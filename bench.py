@@ -289,7 +289,7 @@ def main():
         "roofline": roof,
         # the co-running pair: algorithmic flops of BOTH kernels of a step / the step time of the timed region
         "pair_roofline": {"bound": "mfma", "achieved": round(whole_tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(whole_tf / FP32_PEAK_TFLOPS, 4),
-                          "kernels": ["frontend_pk3_kernel<512, 10, false>", "net_fused_tc8_kernel<8, 49, 0>"],
+                          "kernels": ["frontend_pk3_kernel<512, 10, false>", "net_fused_tc8_kernel<8, 49, 0, 3>"],
                           "algorithmic_flops_per_step": B * (w["mfcc_flops"] + w["net_flops"])},
         "phases_ms": {"frontend": round(fe_ms, 4), "net": round(net_ms, 4), "frontend_in_timed_region": round(fe_in, 4), "net_in_timed_region": round(net_in, 4)},
         "sequential": {"ms_per_step": round(dt_seq / nseq * 1e3, 4) if nseq else None, "steps": nseq,
