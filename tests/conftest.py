@@ -11,8 +11,8 @@ if ROOT not in sys.path:
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """The CPU suite (`-m "not gpu"`) spends its time in the wave-64 emulator, one test at a time: ~14 min serially, ~2.5 min over
-    the host's cores.  When pytest-xdist is importable and the caller chose no `-n` itself, run that suite on min(8, cores) workers
+    """The CPU suite (`-m "not gpu"`) spends its time in the wave-64 emulator, one test at a time: ~10 min serially, ~1.5 min over
+    the host's cores (round 6; the fiber switch is a dozen instructions, tests/emu/hip/hip_runtime.h).  When pytest-xdist is importable and the caller chose no `-n` itself, run that suite on min(8, cores) workers
     (`-n 0` or TCR_TEST_SERIAL=1 keeps it serial).  GPU runs (`-m gpu`) stay in one process: one device, one set of streams."""
     if hasattr(config, "workerinput") or os.environ.get("TCR_TEST_SERIAL") == "1":
         return None

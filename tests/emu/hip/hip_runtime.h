@@ -88,8 +88,44 @@ constexpr size_t STACK_BYTES = 512 * 1024;
 
 enum State { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
 
+// Fiber switch: the callee-saved registers and the stack pointer, nothing else.  (glibc's swapcontext also saves and restores the signal
+// mask -- two rt_sigprocmask system calls per switch, and every emulated wave-level operation is a switch: a third of the CPU suite's
+// time was spent in the kernel.)  x86-64 System V only; other hosts keep ucontext.
+#if defined(__x86_64__) && !defined(TCR_EMU_UCONTEXT)
+#define TCR_EMU_ASM_SWITCH 1
+extern "C" void tcr_emu_switch(void** save_sp, void* load_sp);
+__asm__(R"(
+    .text
+    .weak tcr_emu_switch
+    .type tcr_emu_switch,@function
+tcr_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size tcr_emu_switch, .-tcr_emu_switch
+)");
+#else
+#define TCR_EMU_ASM_SWITCH 0
+#endif
+
 struct Fiber {
+#if TCR_EMU_ASM_SWITCH
+    void* sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     char* stack = nullptr;
     State state = DONE;
     dim3 tid;
@@ -97,7 +133,11 @@ struct Fiber {
 
 struct Runtime {
     std::vector<Fiber> fibers;
+#if TCR_EMU_ASM_SWITCH
+    void* main_sp = nullptr;
+#else
     ucontext_t main_ctx;
+#endif
     int cur = -1;
     int nthreads = 0;
     const std::function<void()>* body = nullptr;
@@ -115,14 +155,23 @@ inline void fiber_entry() {
     Runtime& r = rt();
     (*r.body)();
     r.fibers[r.cur].state = DONE;
+#if TCR_EMU_ASM_SWITCH
+    tcr_emu_switch(&r.fibers[r.cur].sp, r.main_sp);
+    __builtin_trap();                       // (a finished fiber is never resumed)
+#else
     swapcontext(&r.fibers[r.cur].ctx, &r.main_ctx);
+#endif
 }
 
 inline void yield_as(State s) {
     Runtime& r = rt();
     int me = r.cur;
     r.fibers[me].state = s;
+#if TCR_EMU_ASM_SWITCH
+    tcr_emu_switch(&r.fibers[me].sp, r.main_sp);
+#else
     swapcontext(&r.fibers[me].ctx, &r.main_ctx);
+#endif
 }
 
 inline void block_barrier() { yield_as(WAIT_BLOCK); }
@@ -139,11 +188,21 @@ inline void run_block() {
     for (int i = 0; i < n; ++i) {
         Fiber& f = r.fibers[i];
         if (!f.stack) f.stack = (char*)malloc(STACK_BYTES);
+#if TCR_EMU_ASM_SWITCH
+        // initial frame: six zeroed callee-saved registers, the entry point as the return address, a null return address for the entry
+        // (16-byte aligned top - 64: the entry point starts with rsp = 8 mod 16, as after a call)
+        uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + STACK_BYTES) & ~uintptr_t(15);
+        void** frame = reinterpret_cast<void**>(top - 64);
+        for (int k = 0; k < 8; ++k) frame[k] = nullptr;
+        frame[6] = reinterpret_cast<void*>(&fiber_entry);
+        f.sp = frame;
+#else
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = STACK_BYTES;
         f.ctx.uc_link = &r.main_ctx;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#endif
         f.state = READY;
         f.tid = dim3(i % bd.x, (i / bd.x) % bd.y, i / (bd.x * bd.y));
     }
@@ -155,7 +214,11 @@ inline void run_block() {
             if (f.state != READY) continue;
             r.cur = i;
             tidx() = f.tid;
+#if TCR_EMU_ASM_SWITCH
+            tcr_emu_switch(&r.main_sp, f.sp);
+#else
             swapcontext(&r.main_ctx, &f.ctx);
+#endif
             progressed = true;
             if (f.state == DONE) ++done;
         }
