@@ -404,7 +404,7 @@ const char* tcr_kernel_name(int index);
 enum { TCR_TUNE_CONV_PATH = 0,   /* 0 auto: implicit-GEMM MFMA conv where the shape fits, 1: scalar-fed VALU conv, 2: as 0 */
        TCR_TUNE_FRONTEND = 1,    /* 0 / 5: packed-FP32 kernel (default); 1..4: scalar-FP32 kernel, variant (v-1): bit0 wave-local phase ordering, bit1 sample prefetch */
        TCR_TUNE_CONV_B = 2,      /* MFMA conv activations: 0 straight from global/L1 (default), 1 via an LDS image; 3: wide 1x1 convs on the register-fed kernel instead of the LDS-tiled one, DS-CNN conv_1 not fused with the first depthwise layer */
-       TCR_TUNE_NET_FUSED = 3,   /* eval forward: 0 one fused LDS-resident kernel for the whole net (default; layers of the flagship shapes run compile-time-specialised), 1 per-layer kernels, 2 fused with the features copied to LDS, 3 fused, generic layer walk only, 4 the round-2 static-shape layer, 5 the static kernel with four 16-position tiles per job in block 0's layers instead of two (round 5 experiment: bitwise, no faster), 7 fused without the bank-aligned utterance strides (A/B arm); the static kernels' nine-tap layers (round 6): 0 work dealt in 16-position units, as even over the waves as units allow, + a whole tap of weight lookahead in the layers of <= 24 input channels (default), 8 jobs of two tiles dealt round-robin (rounds 3-5), 9 units without the lookahead (all bitwise) */
+       TCR_TUNE_NET_FUSED = 3,   /* eval forward: 0 one fused LDS-resident kernel for the whole net (default; layers of the flagship shapes run compile-time-specialised), 1 per-layer kernels, 2 fused with the features copied to LDS, 3 fused, generic layer walk only, 4 the round-2 static-shape layer, 5 the static kernel with four 16-position tiles per job in block 0's layers instead of two (round 5 experiment: bitwise, no faster), 7 fused without the bank-aligned utterance strides (A/B arm); the static kernels' nine-tap layers (round 6): 0 work dealt in 16-position units, as even over the waves as units allow, + a whole tap of weight lookahead in the layers of <= 32 input channels (TCResNet14-1.5: <= 48) (default), 8 jobs of two tiles dealt round-robin (rounds 3-5), 9 units without the lookahead (all bitwise) */
        TCR_TUNE_FUSED_GROUP = 4, /* utterances per workgroup group of the fused kernel (0: largest that fits 64 KB of LDS) */
        TCR_TUNE_FUSED_WAVES = 5, /* fused kernel: waves per workgroup (4, 8, 16) + 100 * weight-ring depth (4, 8, 16); 0: default */
        TCR_TUNE_CONV_KSPLIT = 6, /* train-mode conv / data-gradient: waves sharing one 32-position group's reduction (0 auto, 1, 2, 4) */

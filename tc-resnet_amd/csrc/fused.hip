@@ -699,7 +699,8 @@ __device__ __forceinline__ void fused_layer_sel(const FusedArgs& a, const FusedL
     else {
         if constexpr (HALO) fused_zero_halo<NW * 64, COUT, (TIN + S - 1) / S>(lds + a.buf_off[L.out_buf], L.out_sz, ng, (int)threadIdx.x);
         if constexpr (NTJ == 0) fused_layer_u<NW, K, S, CIN, COUT, TIN, HAS_RES>(a, L, xin, in_sz, lds, ng, wave, r, q);      // (units: see fused_layer_u)
-        else if constexpr (NTJ == 3) fused_layer_u<NW, K, S, CIN, COUT, TIN, HAS_RES, (CIN <= 24 ? 1 : 0)>(a, L, xin, in_sz, lds, ng, wave, r, q);   // (+ a whole tap of weight lookahead in the narrow layers)
+        else if constexpr (NTJ == 3) fused_layer_u<NW, K, S, CIN, COUT, TIN, HAS_RES, (CIN <= 32 ? 1 : 0)>(a, L, xin, in_sz, lds, ng, wave, r, q);   // (+ a whole tap of weight lookahead in the layers of <= 32 input channels)
+        else if constexpr (NTJ == 13) fused_layer_u<NW, K, S, CIN, COUT, TIN, HAS_RES, (CIN <= 48 ? 1 : 0)>(a, L, xin, in_sz, lds, ng, wave, r, q);   // (TCResNet14-1.5's kernel: <= 48)
         else fused_layer_s<NW, K, S, CIN, COUT, TIN, HAS_RES, NTJ, WLDS>(a, L, xin, in_sz, lds, ng, wave, r, q, w_lds);
     }
 }
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(NW * 64) void net_small_tc8_kernel(const FusedArgs 
 // frames: the same static layer (`fused_layer_s`), first conv (`fused_conv0_g`: 24 output channels = two row tiles) and head as the
 // TCResNet8 instance.  Blocks 1 / 3 / 5 have identity shortcuts: their second conv adds the block input, which lives in its own output
 // buffer (each lane reads the residual of exactly the elements it then writes).
-template <int NW, int T0, int NTJ0 = 3>       // NTJ0: the nine-tap layers as in net_fused_tc8_kernel (3: units + lookahead, 0: units, 2: jobs of two tiles)
+template <int NW, int T0, int NTJ0 = 13>      // NTJ0: the nine-tap layers as in net_fused_tc8_kernel (13: units + weight lookahead up to 48 input channels, 0: units, 2: jobs of two tiles)
 __global__ __launch_bounds__(NW * 64) TCR_WAVES_PER_SIMD_4 void net_fused_tc14w_kernel(const FusedArgs a) {
     constexpr int NT = NW * 64;
     constexpr int T1 = (T0 + 1) / 2, T2 = (T1 + 1) / 2, T3 = (T2 + 1) / 2;
@@ -1177,9 +1178,10 @@ int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, 
     }
     // TCR_TUNE_NET_FUSED: 0 branch-free epilogue (default); 4: the round-2 static-shape kernel (A/B arm)
     const bool r2 = tune_get(TCR_TUNE_NET_FUSED) == 4;
-    // Round 6 default: the nine-tap layers' work dealt in 16-position units (fused_layer_u) + a whole tap of weight lookahead in the layers of
-    // <= 24 input channels (fused_job_s AHEAD): 105.1 -> 98.6 -> 95.3 us at 49 frames, 182 -> 178 -> 175 at 98, bitwise.  A/B arms: 8 the jobs of
-    // two tiles dealt round-robin (rounds 3-5), 9 units without the lookahead.
+    // Round 6 default: the nine-tap layers' work dealt in 16-position units (fused_layer_u) + a whole tap of weight lookahead (fused_job_s AHEAD) in
+    // the layers of <= 24 input channels: 105.1 -> 98.6 -> 95.3 us at 49 frames, 182 -> 178 -> 175 at 98, bitwise; <= 32: 96.4 -> 95.3 / 178.3 -> 173.4;
+    // every width: 96.5 (128 registers + 156 B of scratch).  TCResNet14-1.5's kernel: <= 48 input channels (98 frames 837 -> 804 us, 49 frames
+    // 423.6 -> 421.7; 224 B of scratch).  A/B arms: 8 the jobs of two tiles dealt round-robin (rounds 3-5), 9 units without the lookahead.
     const bool j2 = tune_get(TCR_TUNE_NET_FUSED) == 8;
     const bool ju = tune_get(TCR_TUNE_NET_FUSED) == 9;
     const bool j4 = tune_get(TCR_TUNE_NET_FUSED) == 5;         // 5: four 16-position tiles per job in block 0's layers (A/B arm, bitwise; measured 103.6 vs 103.2 us at 49 frames, 184.9 vs 181.2 at 98: no gain)
@@ -1187,7 +1189,7 @@ int launch_net_fused(const FusedArgs& a, size_t lds_bytes, int grid, int waves, 
     TCR_FS(4, 49) TCR_FS(8, 49) TCR_FS(16, 49) TCR_FS(4, 98) TCR_FS(8, 98) TCR_FS(16, 98)
 #undef TCR_FS
     const int tc14 = (kern || tune_get(TCR_TUNE_NET_FUSED) == 3 || tune_get(TCR_TUNE_NET_FUSED) == 4) ? 0 : fused_tc14w_frames(a);
-#define TCR_F14(NW_, T_) if (tc14 == T_ && waves == NW_) kern = ju ? net_fused_tc14w_kernel<NW_, T_, 0> : (j2 ? net_fused_tc14w_kernel<NW_, T_, 2> : net_fused_tc14w_kernel<NW_, T_, 3>);
+#define TCR_F14(NW_, T_) if (tc14 == T_ && waves == NW_) kern = ju ? net_fused_tc14w_kernel<NW_, T_, 0> : (j2 ? net_fused_tc14w_kernel<NW_, T_, 2> : net_fused_tc14w_kernel<NW_, T_, 13>);
     TCR_F14(8, 49) TCR_F14(16, 49) TCR_F14(8, 98) TCR_F14(16, 98)
 #undef TCR_F14
     if (kern) ring = 0;
