@@ -285,6 +285,7 @@ int launch_chan_reduce(int mode, ChanReduceArgs a, int* nchunk_out, hipStream_t 
 #define TCR_BN_CB 16
 #endif
 constexpr int kBnCB = TCR_BN_CB;
+static_assert(kBnCB <= 64, "the finalize kernels give a channel of the block to one thread");
 // Conv epilogues (EpiSums) leave one row per workgroup / per utterance -- thousands, not <= 512: four channels per workgroup
 // there (8 columns = one 32-byte sector of a row x 64 slices, eight times the workgroups), so that a thread adds ~65 rows, sixteen
 // loads in flight: 17 us per finalize over 4160 rows.  (Measured: the 32-channel geometry 47 us, in the backward's dependency chain;
@@ -308,6 +309,13 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int nchunk
             const float* src = partial + (size_t)which * nc + ch;
             const size_t rstride = (size_t)2 * nc;
             int k = part;
+            for (; k + 31 * nparts < nchunk; k += 32 * nparts) {       // (round 6: 512 rows in 16 slices = ONE trip of 32 loads instead of two of 16)
+                float v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = src[(size_t)(k + u * nparts) * rstride];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) acc += (double)v[u];
+            }
             for (; k + 15 * nparts < nchunk; k += 16 * nparts) {
                 float v[16];
 #pragma unroll
@@ -364,25 +372,29 @@ __global__ __launch_bounds__(512) void bn_finalize_kernel(const BnFinalizeArgs a
     __shared__ double s_slices[512];
     __shared__ double s_tot[2 * kBnCB];
     const int c0 = blockIdx.x * a.cbw, cb = min(a.cbw, a.c - c0);
+    // The channel's inputs are requested BEFORE the reduction (their round trip hides behind the partial rows'), every store comes last:
+    // the pointers may alias as far as the compiler knows, and a load behind a store waits for both round trips (round 6: the old order
+    // was a chain of four).  One channel per thread (cb <= kBnCB < the workgroup).
+    const int i = threadIdx.x, c = c0 + min(i, cb - 1);
+    const float gamma_c = a.gamma ? a.gamma[c] : 1.0f, beta_c = a.beta[c], mm_c = a.moving_mean[c], mv_c = a.moving_var[c];
     reduce_partials(a.partial, a.nchunk, a.sums, a.c, c0, cb, s_slices, s_tot);
-    for (int i = threadIdx.x; i < cb; i += blockDim.x) {
-        const int c = c0 + i;
+    if (i < cb) {
         const double s1 = s_tot[i], s2 = s_tot[cb + i];
         const double m = s1 / a.count;
         double var = s2 / a.count - m * m;
         if (var < 0.0) var = 0.0;
         const float meanf = (float)m, varf = (float)var;
         const float inv = 1.0f / sqrtf(varf + a.eps);
-        const float sc = a.gamma ? a.gamma[c] * inv : inv;         // DS-CNN: scale=False (ds_cnn.py:104-118)
+        const float sc = a.gamma ? gamma_c * inv : inv;            // DS-CNN: scale=False (ds_cnn.py:104-118)
         a.scale[c] = sc;
-        a.shift[c] = fmaf(-meanf, sc, a.beta[c]);
+        a.shift[c] = fmaf(-meanf, sc, beta_c);
         a.mean[c] = meanf;
         a.invstd[c] = inv;
         // assign_moving_average: v -= (1 - decay) * (v - value); variance is Bessel-corrected
         const float unbiased = (float)(var * (a.count / (a.count > 1.0 ? a.count - 1.0 : 1.0)));
         const float om = 1.0f - a.decay;
-        a.moving_mean[c] -= om * (a.moving_mean[c] - meanf);
-        a.moving_var[c] -= om * (a.moving_var[c] - unbiased);
+        a.moving_mean[c] = mm_c - om * (mm_c - meanf);
+        a.moving_var[c] = mv_c - om * (mv_c - unbiased);
     }
 }
 
@@ -393,24 +405,28 @@ __global__ __launch_bounds__(512) void bn_finalize2_kernel(const BnFinalizeArgs 
     const BnFinalizeArgs& u = blockIdx.y == 0 ? a : b;
     const int c0 = blockIdx.x * u.cbw, cb = min(u.cbw, u.c - c0);
     if (cb <= 0) return;
+    // The channel's inputs are requested BEFORE the reduction (their round trip hides behind the partial rows'), every store comes last:
+    // the pointers may alias as far as the compiler knows, and a load behind a store waits for both round trips (round 6: the old order
+    // was a chain of four).  One channel per thread (cb <= kBnCB < the workgroup).
+    const int i = threadIdx.x, c = c0 + min(i, cb - 1);
+    const float gamma_c = u.gamma ? u.gamma[c] : 1.0f, beta_c = u.beta[c], mm_c = u.moving_mean[c], mv_c = u.moving_var[c];
     reduce_partials(u.partial, u.nchunk, u.sums, u.c, c0, cb, s_slices, s_tot);
-    for (int i = threadIdx.x; i < cb; i += blockDim.x) {
-        const int c = c0 + i;
+    if (i < cb) {
         const double s1 = s_tot[i], s2 = s_tot[cb + i];
         const double m = s1 / u.count;
         double var = s2 / u.count - m * m;
         if (var < 0.0) var = 0.0;
         const float meanf = (float)m, varf = (float)var;
         const float inv = 1.0f / sqrtf(varf + u.eps);
-        const float sc = u.gamma ? u.gamma[c] * inv : inv;
+        const float sc = u.gamma ? gamma_c * inv : inv;
         u.scale[c] = sc;
-        u.shift[c] = fmaf(-meanf, sc, u.beta[c]);
+        u.shift[c] = fmaf(-meanf, sc, beta_c);
         u.mean[c] = meanf;
         u.invstd[c] = inv;
         const float unbiased = (float)(var * (u.count / (u.count > 1.0 ? u.count - 1.0 : 1.0)));
         const float om = 1.0f - u.decay;
-        u.moving_mean[c] -= om * (u.moving_mean[c] - meanf);
-        u.moving_var[c] -= om * (u.moving_var[c] - unbiased);
+        u.moving_mean[c] = mm_c - om * (mm_c - meanf);
+        u.moving_var[c] = mv_c - om * (mv_c - unbiased);
     }
 }
 
@@ -502,19 +518,28 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const BnBwdFinaliz
     __shared__ double s_slices[512];
     __shared__ double s_tot[2 * kBnCB];
     const int c0 = blockIdx.x * a.cbw, cb = min(a.cbw, a.c - c0);
+    // The channel's inputs are requested BEFORE the reduction (their round trip hides behind the partial rows'), every store comes last:
+    // the pointers may alias as far as the compiler knows, and a load behind a store waits for both round trips (round 6: the old order
+    // -- k1 stored, read back for the table, ... -- was a chain of eight).  One channel per thread (cb <= kBnCB < the workgroup).
+    const int i = threadIdx.x, c = c0 + min(i, cb - 1);
+    const float invstd_c = a.invstd[c], gamma_c = a.gamma ? a.gamma[c] : 1.0f;
+    const float mean_c = a.tab ? a.mean[c] : 0.f;
+    const float ssc_c = (a.tab && a.self_scale) ? a.self_scale[c] : 0.f, ssh_c = (a.tab && a.self_scale) ? a.self_shift[c] : 1.f;
     reduce_partials(a.partial, a.nchunk, a.sums, a.c, c0, cb, s_slices, s_tot);
-    for (int i = threadIdx.x; i < cb; i += blockDim.x) {
-        const int c = c0 + i;
+    if (i < cb) {
         const float db = (float)s_tot[i], dg = (float)s_tot[cb + i];
+        const float k1 = a.gamma ? gamma_c * invstd_c : invstd_c;
+        const float k2 = (float)((double)db / a.count);
+        const float k3 = (float)((double)invstd_c * (double)dg / a.count);
         a.dbeta[c] = db * a.grad_scale;
         if (a.dgamma) a.dgamma[c] = dg * a.grad_scale;
-        a.k1[c] = a.gamma ? a.gamma[c] * a.invstd[c] : a.invstd[c];
-        a.k2[c] = (float)((double)db / a.count);
-        a.k3[c] = (float)((double)a.invstd[c] * (double)dg / a.count);
+        a.k1[c] = k1;
+        a.k2[c] = k2;
+        a.k3[c] = k3;
         if (a.tab) {
             float* t = a.tab + (size_t)c * 8;
-            t[0] = a.k1[c]; t[1] = a.k2[c]; t[2] = a.k3[c]; t[3] = a.mean[c];
-            t[4] = a.self_scale ? a.self_scale[c] : 0.f; t[5] = a.self_scale ? a.self_shift[c] : 1.f; t[6] = 0.f; t[7] = 0.f;
+            t[0] = k1; t[1] = k2; t[2] = k3; t[3] = mean_c;
+            t[4] = ssc_c; t[5] = ssh_c; t[6] = 0.f; t[7] = 0.f;
         }
     }
 }
@@ -527,19 +552,28 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize2_kernel(const BnBwdFinali
     const BnBwdFinalizeArgs& u = blockIdx.y == 0 ? a : b;
     const int c0 = blockIdx.x * u.cbw, cb = min(u.cbw, u.c - c0);
     if (cb <= 0) return;
+    // The channel's inputs are requested BEFORE the reduction (their round trip hides behind the partial rows'), every store comes last:
+    // the pointers may alias as far as the compiler knows, and a load behind a store waits for both round trips (round 6: the old order
+    // -- k1 stored, read back for the table, ... -- was a chain of eight).  One channel per thread (cb <= kBnCB < the workgroup).
+    const int i = threadIdx.x, c = c0 + min(i, cb - 1);
+    const float invstd_c = u.invstd[c], gamma_c = u.gamma ? u.gamma[c] : 1.0f;
+    const float mean_c = u.tab ? u.mean[c] : 0.f;
+    const float ssc_c = (u.tab && u.self_scale) ? u.self_scale[c] : 0.f, ssh_c = (u.tab && u.self_scale) ? u.self_shift[c] : 1.f;
     reduce_partials(u.partial, u.nchunk, u.sums, u.c, c0, cb, s_slices, s_tot);
-    for (int i = threadIdx.x; i < cb; i += blockDim.x) {
-        const int c = c0 + i;
+    if (i < cb) {
         const float db = (float)s_tot[i], dg = (float)s_tot[cb + i];
+        const float k1 = u.gamma ? gamma_c * invstd_c : invstd_c;
+        const float k2 = (float)((double)db / u.count);
+        const float k3 = (float)((double)invstd_c * (double)dg / u.count);
         u.dbeta[c] = db * u.grad_scale;
         if (u.dgamma) u.dgamma[c] = dg * u.grad_scale;
-        u.k1[c] = u.gamma ? u.gamma[c] * u.invstd[c] : u.invstd[c];
-        u.k2[c] = (float)((double)db / u.count);
-        u.k3[c] = (float)((double)u.invstd[c] * (double)dg / u.count);
+        u.k1[c] = k1;
+        u.k2[c] = k2;
+        u.k3[c] = k3;
         if (u.tab) {
             float* t = u.tab + (size_t)c * 8;
-            t[0] = u.k1[c]; t[1] = u.k2[c]; t[2] = u.k3[c]; t[3] = u.mean[c];
-            t[4] = u.self_scale ? u.self_scale[c] : 0.f; t[5] = u.self_scale ? u.self_shift[c] : 1.f; t[6] = 0.f; t[7] = 0.f;
+            t[0] = k1; t[1] = k2; t[2] = k3; t[3] = mean_c;
+            t[4] = ssc_c; t[5] = ssh_c; t[6] = 0.f; t[7] = 0.f;
         }
     }
 }
@@ -723,12 +757,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFina
         const int nparts = 512 / (2 * cb);                      // reduce_partials' slicing of this channel block (512-thread finalize)
         const int col = threadIdx.x & (2 * kFG - 1);            // which * kFG + channel
         const int which = col / kFG, ch = g0 + col % kFG;
+        // (the coefficients' inputs are requested before the reduction, the stores of slab 0 come last: see bn_bwd_finalize_kernel)
+        const int cpre = min(g0 + (int)threadIdx.x, a.c - 1);
+        const float gamma_c = f.gamma ? f.gamma[cpre] : 1.0f, invstd_c = f.invstd[cpre];
         if (ch < a.c) {
             const float* src = f.partial + (size_t)which * a.c + ch;
             const size_t rstride = (size_t)2 * a.c;
             for (int part = threadIdx.x / (2 * kFG); part < nparts; part += 256 / (2 * kFG)) {
                 double acc = 0.0;
                 int k = part;
+                for (; k + 23 * nparts < f.nchunk; k += 24 * nparts) {      // (round 6: 384 rows in 16 slices = one trip instead of three)
+                    float v[24];
+#pragma unroll
+                    for (int u = 0; u < 24; ++u) v[u] = src[(size_t)(k + u * nparts) * rstride];
+#pragma unroll
+                    for (int u = 0; u < 24; ++u) acc += (double)v[u];
+                }
                 for (; k + 7 * nparts < f.nchunk; k += 8 * nparts) {
                     float v[8];
 #pragma unroll
@@ -746,16 +790,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const BnBwdFina
             double db = 0.0, dg = 0.0;
             for (int p = 0; p < nparts; ++p) { db += s_slices[p * 2 * kFG + threadIdx.x]; dg += s_slices[p * 2 * kFG + kFG + threadIdx.x]; }
             const float dbf = (float)db, dgf = (float)dg;
+            const float k1 = f.gamma ? gamma_c * invstd_c : invstd_c;
+            const float k2 = (float)((double)dbf / f.count);
+            const float k3 = (float)((double)invstd_c * (double)dgf / f.count);
+            s_k[0][threadIdx.x] = k1;
+            s_k[1][threadIdx.x] = k2;
+            s_k[2][threadIdx.x] = k3;
             if (blockIdx.x == 0) {
                 f.dbeta[c] = dbf * f.grad_scale;
                 if (f.dgamma) f.dgamma[c] = dgf * f.grad_scale;
-                f.k1[c] = f.gamma ? f.gamma[c] * f.invstd[c] : f.invstd[c];
-                f.k2[c] = (float)((double)dbf / f.count);
-                f.k3[c] = (float)((double)f.invstd[c] * (double)dgf / f.count);
+                f.k1[c] = k1;
+                f.k2[c] = k2;
+                f.k3[c] = k3;
             }
-            s_k[0][threadIdx.x] = f.gamma ? f.gamma[c] * f.invstd[c] : f.invstd[c];
-            s_k[1][threadIdx.x] = (float)((double)dbf / f.count);
-            s_k[2][threadIdx.x] = (float)((double)f.invstd[c] * (double)dgf / f.count);
         }
         __syncthreads();
     }
