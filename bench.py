@@ -394,6 +394,21 @@ def main():
                                                   "utterance (through_the_python_wrapper_us: the same via TCResNet.forward_waveform, as rounds 1-5 reported): "
                                                   "front-end ~9 us + small-batch network kernel ~21 us (weights DMA-copied into LDS a phase ahead; "
                                                   "bitwise the throughput kernel) back to back, ~12 us of host launch + synchronisation latency"}
+            # the same prepared call at batch 64 (the serving regime between one utterance and the throughput batch)
+            n64 = min(64, B)
+            w64 = wav[:n64].contiguous()
+            o64 = (torch.empty((n64, 12), device=dev), torch.empty((n64, 12), device=dev))
+            call64 = net.waveform_call(fe, w64, o64)
+            for _ in range(50):
+                call64()
+                sync()
+            t0 = time.perf_counter()
+            for _ in range(400):
+                call64()
+                sync()
+            lat64 = (time.perf_counter() - t0) / 400 * 1e6
+            out["latency_batch_64"] = {"value": round(lat64, 1), "unit": "us", "higher_is_better": False, "utterances_per_s": round(n64 * 1e6 / lat64, 1),
+                                       "workload": f"{n64} utterances, waveform -> softmax: one prepared tcr_forward_waveform call + device synchronisation per batch"}
         if "train" in legs:
             # ---------------- training step (configs[2]) ----------------
             out["train"] = train_leg(fe, net, tsteps, twarm)

@@ -13,7 +13,7 @@ fe = T.Frontend(window_size_samples=640, window_stride_samples=320, lib=lib, dev
 net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, fe.n_frames, 12, lib=lib, device=dev); net.init_xavier(0)
 feat = fe(wav)
 names = ["conv0", "down0+conv0_0", "conv0_1", "down1+conv1_0", "conv1_1", "down2+conv2_0", "conv2_1", "head", "-", "-", "-", "-"]
-for knob in (int(x) for x in os.environ.get("TS_KNOBS", "0").split(",")):          # arms of TCR_TUNE_NET_FUSED (0: jobs of two tiles, 8: units)
+for knob in (int(x) for x in os.environ.get("TS_KNOBS", "0").split(",")):          # arms of TCR_TUNE_NET_FUSED (8: jobs of two tiles dealt round-robin = rounds 3-5, 9: 16-position units, 0: units + a tap of weight lookahead = round 6)
     lib.tcr_tune(3, knob)
     for _ in range(20): lg, pr = net.forward_infer(feat)
     torch.cuda.synchronize()
