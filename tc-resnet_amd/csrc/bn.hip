@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ChanReduceArgs a
 }
 
 int chan_reduce_chunks(int npos) {      // upper bound of the partial rows (workspace sizing)
-    int n = ceil_div(npos, 512);        // >= 2 positions per thread; many short workgroups hide the load latency
+#ifndef TCR_CHAN_REDUCE_POS
+#define TCR_CHAN_REDUCE_POS 512
+#endif
+    int n = ceil_div(npos, TCR_CHAN_REDUCE_POS);        // >= 2 positions per thread; many short workgroups hide the load latency
     if (n > 512) n = 512;               // (round 6, re-measured with the faster apply pass: 128 / 256 / 384 rows are within noise of 512)
     if (n < 1) n = 1;
     return n;

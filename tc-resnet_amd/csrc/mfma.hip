@@ -2114,8 +2114,11 @@ __global__ __launch_bounds__(576) void conv_wgrad_lds_kernel(const WgradLdsArgs 
     const int nstages = (n_end - n_begin + a.ub - 1) / a.ub;
     const float inv_dsz = 1.0f / (float)dsz, inv_tpo = 1.0f / (float)a.tpo;
 
-    f32x4 xr[XI], gr[XI], rr[XI];
-    auto load_stage = [&](int st) {
+    // Staging registers in TWO sets (round 6, LA2 below): stage st + 2 is requested before stage st's MFMAs, so a stage's HBM round trip has
+    // two MFMA phases to hide behind (one workgroup of nine waves per CU: nothing else covers it).  The stage loop is unrolled by two so
+    // that the sets are compile-time indices.
+    f32x4 xr2[2][XI], gr2[2][XI], rr2[2][XI];
+    auto load_stage = [&](int st, f32x4 (&xr)[XI], f32x4 (&gr)[XI], f32x4 (&rr)[XI]) {
         const int n0 = n_begin + st * a.ub;
         const int nu = min(a.ub, n_end - n0);
         const f32x4* xs = reinterpret_cast<const f32x4*>(a.x + (size_t)n0 * xsz);
@@ -2130,7 +2133,7 @@ __global__ __launch_bounds__(576) void conv_wgrad_lds_kernel(const WgradLdsArgs 
             if (FLY) rr[i] = rs[min(ix, nd4 - 1)];
         }
     };
-    auto store_stage = [&](int st, int buf) {
+    auto store_stage = [&](int st, int buf, const f32x4 (&xr)[XI], const f32x4 (&gr)[XI], const f32x4 (&rr)[XI]) {
         const int n0 = n_begin + st * a.ub;
         const int nu = min(a.ub, n_end - n0);
         const int nx4 = nu * xsz / 4, nd4 = nu * dsz / 4;
@@ -2180,13 +2183,20 @@ __global__ __launch_bounds__(576) void conv_wgrad_lds_kernel(const WgradLdsArgs 
 #pragma unroll
     for (int m = 0; m < NCO; ++m) drow[m] = min(m * 16 + r, a.cout - 1) * a.tpo + kHalo + q;
 
-    if (nstages > 0) load_stage(0);
+    if (nstages > 0) load_stage(0, xr2[0], gr2[0], rr2[0]);
+    // (LA2: the 16-channel first conv of TCResNet8-1.0, which runs alone at the step's tail -- 49 frames 739 -> 726 us with two utterances per
+    //  stage and this lookahead, 98 frames 1156 -> 1143; the 24-channel instance of TCResNet14-1.5 runs beside the data-gradient chain, and
+    //  there the deeper lookahead costs: 98 frames 3611 -> 3656 us per step, 49 frames neutral -- it keeps one stage)
+    constexpr bool LA2 = NCO == 1;
+    if (LA2 && nstages > 1) load_stage(1, xr2[1], gr2[1], rr2[1]);
     __syncthreads();                                            // (the coefficient table)
-    if (nstages > 0) store_stage(0, 0);
+    if (nstages > 0) store_stage(0, 0, xr2[0], gr2[0], rr2[0]);
     __syncthreads();
-    for (int st = 0; st < nstages; ++st) {
+    auto stage = [&](const int st, f32x4 (&xa)[XI], f32x4 (&ga)[XI], f32x4 (&ra)[XI], const f32x4 (&xb_)[XI], const f32x4 (&gb_)[XI], const f32x4 (&rb_)[XI]) {
+        // (xa / ga / ra: this stage's set -- already in LDS, free for stage st + 2; xb_ / gb_ / rb_: stage st + 1's, stored behind the MFMAs)
         const int buf = st & 1;
-        if (st + 1 < nstages) load_stage(st + 1);
+        if (LA2) { if (st + 2 < nstages) load_stage(st + 2, xa, ga, ra); }
+        else if (st + 1 < nstages) load_stage(st + 1, const_cast<f32x4 (&)[XI]>(xb_), const_cast<f32x4 (&)[XI]>(gb_), const_cast<f32x4 (&)[XI]>(rb_));
         const int nu = min(a.ub, n_end - (n_begin + st * a.ub));
         const float* xb = lds + buf * bufsz;
         const float* db = xb + a.ub * xsz;
@@ -2205,8 +2215,16 @@ __global__ __launch_bounds__(576) void conv_wgrad_lds_kernel(const WgradLdsArgs 
                     for (int m = 0; m < NCO; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[m], acc[i][m], 0, 0, 0);
             }
         }
-        if (st + 1 < nstages) store_stage(st + 1, buf ^ 1);
+        if (st + 1 < nstages) store_stage(st + 1, buf ^ 1, xb_, gb_, rb_);
         __syncthreads();
+    };
+    if constexpr (LA2) {
+        for (int st = 0; st < nstages; st += 2) {
+            stage(st, xr2[0], gr2[0], rr2[0], xr2[1], gr2[1], rr2[1]);
+            if (st + 1 < nstages) stage(st + 1, xr2[1], gr2[1], rr2[1], xr2[0], gr2[0], rr2[0]);
+        }
+    } else {
+        for (int st = 0; st < nstages; ++st) stage(st, xr2[0], gr2[0], rr2[0], xr2[0], gr2[0], rr2[0]);      // (one set: the round-4 loop)
     }
     float* dst = a.partial + (size_t)blockIdx.x * K * a.cin_pad * a.cout_pad + (size_t)j * a.cin_pad * a.cout_pad;
 #pragma unroll
@@ -2238,8 +2256,11 @@ static int wgrad_nchunk(int k, int cin, int cout, int batch, bool fine) {
     //  102 for five -- measured +90 us per TCResNet14-1.5 step, half as many chunks +-0: the filter gradients are the main chain's
     //  neighbours, and more of their waves on a CU cost the data-gradient chain more than they gain)
     if (!wgrad_lds_shape(k, cin, cout)) return wgrad_chunks_for(batch, fine);
+#ifndef TCR_WGRAD_LDS_CHUNKS
+#define TCR_WGRAD_LDS_CHUNKS 256
+#endif
     int n = ceil_div(batch, 4);
-    if (n > 256) n = 256;
+    if (n > TCR_WGRAD_LDS_CHUNKS) n = TCR_WGRAD_LDS_CHUNKS;
     return n < 1 ? 1 : n;
 }
 
@@ -2258,7 +2279,10 @@ static int launch_wgrad_lds(int k, int stride, int pad_lo, const float* x, const
     a.utt_per_block = ceil_div(batch, nchunk);
     // utterances per stage: enough 4-position steps per barrier (>= 8), within two 16-byte loads per thread and tensor
     const int steps = ceil_div(tout, 4);
-    int ub = ceil_div(8, steps);
+#ifndef TCR_WGRAD_LDS_STEPS
+#define TCR_WGRAD_LDS_STEPS 16     // (round 6: two utterances per stage at 49 frames -- half the barriers, every staging thread loads real data: TCResNet8 step 739 -> 731 us, bitwise)
+#endif
+    int ub = ceil_div(TCR_WGRAD_LDS_STEPS, steps);
     if (ub > a.utt_per_block) ub = a.utt_per_block;
     while (ub > 1 && (ub * cin * tpi > 8 * 576 || ub * cout * tpo > 8 * 576)) --ub;
     if (ub < 1 || ub * cin * tpi > 8 * 576 || ub * cout * tpo > 8 * 576) return 1;
