@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch, tcresnet_amd as T
 from bench import synth_batch
 dev = torch.device("cuda")
-lib = T._lib.load_from(os.path.join(ROOT, "tc-resnet_amd", "lib", "whatif", "libtcr_w2048.so"), "hip")
+lib = T._lib.load_from(os.path.join(ROOT, "tc-resnet_amd", "lib", "whatif", os.environ.get("TS_LIB", "libtcr_w2048.so")), "hip")
 wav = synth_batch(4096, dev, 1234)
 fe = T.Frontend(window_size_samples=640, window_stride_samples=320, lib=lib, device=dev)
 net = T.TCResNet("TCResNet8", [16, 24, 32, 48], 40, fe.n_frames, 12, lib=lib, device=dev); net.init_xavier(0)

@@ -20,7 +20,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Timing what-ifs of the static-shape kernel (scripts/build_whatif.py compiles this file with -DTCR_FUSED_WHATIF=<mask> into
 // side libraries; WRONG results, never part of the product build): 1 no MFMAs, 2 weights of tap 0 only, 4 LDS operands of tap 0
-// only, 8 no barriers, 16 no head, 32 no epilogue stores, 64 no first conv, 512 empty kernel, 1024 no halo-zero passes.
+// only, 8 no barriers, 16 no head, 32 no epilogue stores, 64 no first conv, 512 empty kernel, 1024 no halo-zero passes, 2048 phase stamps
+// (scripts/fused_ts.py), 4096 / 8192 the lookahead layers without their weight refills / without LDS operand reads after tap 0,
+// 16384 / 32768 (right results) s_setprio 2 around a tap's MFMA burst / around its operand requests: 110 / 101 us against 98 -- slower, not built in.
 #ifndef TCR_FUSED_WHATIF
 #define TCR_FUSED_WHATIF 0
 #endif
@@ -292,20 +294,31 @@ __device__ __forceinline__ void fused_job_s(const FusedArgs& a, const FusedLayer
 #pragma unroll
         for (int c4 = 0; c4 < C4; ++c4) w0[c4] = buf_load_f32(wr, wl, (unsigned)(c4 * WSTEP) * 4u);
         auto tap = [&](const int j, const float (&wu)[C4], float (&wf)[C4], const bool fill) {
-            if (fill) {
+            if (TCR_WHATIF(32768)) __builtin_amdgcn_s_setprio(2);
+            if (fill && !TCR_WHATIF(4096)) {
 #pragma unroll
                 for (int c4 = 0; c4 < C4; ++c4) wf[c4] = buf_load_f32(wr, wl, (unsigned)(((j + 1) * C4 + c4) * WSTEP) * 4u);
             }
             float b[NTJ][C4];
+            if (TCR_WHATIF(8192) && j > 0) {
+#pragma unroll
+                for (int c4 = 0; c4 < C4; ++c4)
+#pragma unroll
+                    for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = wu[c4] + (float)nt;       // (timing what-if: no LDS operand reads after tap 0)
+            } else {
 #pragma unroll
             for (int c4 = 0; c4 < C4; ++c4)
 #pragma unroll
                 for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = xp[nt][c4 * XSTEP + j];
+            }
             __builtin_amdgcn_sched_barrier(0);                  // (the requests stay in front of the tap's MFMAs)
+            if (TCR_WHATIF(16384)) __builtin_amdgcn_s_setprio(2);
+            if (TCR_WHATIF(32768)) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int c4 = 0; c4 < C4; ++c4)
 #pragma unroll
                 for (int nt = 0; nt < NTJ; ++nt) acc[nt] = TCR_MFMA(wu[c4], b[nt][c4], acc[nt]);
+            if (TCR_WHATIF(16384)) __builtin_amdgcn_s_setprio(0);
         };
 #pragma unroll 1
         for (int j = 0; j + 2 < K; j += 2) {
@@ -520,10 +533,12 @@ __device__ __forceinline__ void fused_conv0_s(const FusedArgs& a, const FusedLay
             sh[reg] = shift[q * 4 + reg];
         }
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (TCR_WHATIF(16384)) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
             for (int c4 = 0; c4 < C4; ++c4) acc0 = TCR_MFMA(wf[j][c4], b0[c4][j], acc0);
+        if (TCR_WHATIF(16384)) __builtin_amdgcn_s_setprio(0);
         const int dump = a.buf_off[2] + a.group * a.buf_sz[2] + (q * 16 + r) - a.buf_off[L.out_buf];
         const float lo = L.relu ? 0.f : -3.4e38f;
         const bool pv = job * 16 + r < npos;
