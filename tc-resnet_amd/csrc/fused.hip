@@ -467,7 +467,8 @@ __device__ __forceinline__ void fused_layer_u(const FusedArgs& a, const FusedLay
     const int U = NRT * nt16;
     const int per = U / NW, extra = U - per * NW;
     // (measured and removed: the two workgroups of a CU handing their spare units to different SIMDs -- waves rotated by two in every
-    //  other workgroup, by blockIdx bit 8 or bit 3: 96.5 / 95.9 us against 95.9)
+    //  other workgroup, by blockIdx bit 8 or bit 3: 96.5 / 95.9 us against 95.9; SIMD mates -- waves w and w + 4 -- walking an odd run single
+    //  unit first so that their prologues / epilogues do not coincide, also flipped per 256 workgroups: 97.4 / 96.8 against 96.3 - 97.6)
     int u = wave * per + min(wave, extra);
     const int end = u + per + (wave < extra ? 1 : 0);
     const float* w = a.params + L.w_off;
