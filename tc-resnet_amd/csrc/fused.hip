@@ -27,6 +27,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TCR_FUSED_WHATIF 0
 #endif
 #define TCR_WHATIF(bit) ((TCR_FUSED_WHATIF & (bit)) != 0)
+#if TCR_FUSED_WHATIF & (16384 | 32768)
+#define TCR_WHATIF_PRIO(bit, level) do { if (TCR_WHATIF(bit)) __builtin_amdgcn_s_setprio(level); } while (0)
+#else
+#define TCR_WHATIF_PRIO(bit, level) do { } while (0)       // (the host build of tests/emu has no such builtin)
+#endif
 #if TCR_FUSED_WHATIF & 1
 __device__ __forceinline__ f32x4 whatif_nomfma(float a, float b, f32x4 c) { c[0] += a; c[1] += b; return c; }
 #define TCR_MFMA(A, B, C) whatif_nomfma((A), (B), (C))
@@ -294,7 +299,7 @@ __device__ __forceinline__ void fused_job_s(const FusedArgs& a, const FusedLayer
 #pragma unroll
         for (int c4 = 0; c4 < C4; ++c4) w0[c4] = buf_load_f32(wr, wl, (unsigned)(c4 * WSTEP) * 4u);
         auto tap = [&](const int j, const float (&wu)[C4], float (&wf)[C4], const bool fill) {
-            if (TCR_WHATIF(32768)) __builtin_amdgcn_s_setprio(2);
+            TCR_WHATIF_PRIO(32768, 2);
             if (fill && !TCR_WHATIF(4096)) {
 #pragma unroll
                 for (int c4 = 0; c4 < C4; ++c4) wf[c4] = buf_load_f32(wr, wl, (unsigned)(((j + 1) * C4 + c4) * WSTEP) * 4u);
@@ -312,13 +317,13 @@ __device__ __forceinline__ void fused_job_s(const FusedArgs& a, const FusedLayer
                 for (int nt = 0; nt < NTJ; ++nt) b[nt][c4] = xp[nt][c4 * XSTEP + j];
             }
             __builtin_amdgcn_sched_barrier(0);                  // (the requests stay in front of the tap's MFMAs)
-            if (TCR_WHATIF(16384)) __builtin_amdgcn_s_setprio(2);
-            if (TCR_WHATIF(32768)) __builtin_amdgcn_s_setprio(0);
+            TCR_WHATIF_PRIO(16384, 2);
+            TCR_WHATIF_PRIO(32768, 0);
 #pragma unroll
             for (int c4 = 0; c4 < C4; ++c4)
 #pragma unroll
                 for (int nt = 0; nt < NTJ; ++nt) acc[nt] = TCR_MFMA(wu[c4], b[nt][c4], acc[nt]);
-            if (TCR_WHATIF(16384)) __builtin_amdgcn_s_setprio(0);
+            TCR_WHATIF_PRIO(16384, 0);
         };
 #pragma unroll 1
         for (int j = 0; j + 2 < K; j += 2) {
@@ -534,12 +539,12 @@ __device__ __forceinline__ void fused_conv0_s(const FusedArgs& a, const FusedLay
             sh[reg] = shift[q * 4 + reg];
         }
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (TCR_WHATIF(16384)) __builtin_amdgcn_s_setprio(2);
+        TCR_WHATIF_PRIO(16384, 2);
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
             for (int c4 = 0; c4 < C4; ++c4) acc0 = TCR_MFMA(wf[j][c4], b0[c4][j], acc0);
-        if (TCR_WHATIF(16384)) __builtin_amdgcn_s_setprio(0);
+        TCR_WHATIF_PRIO(16384, 0);
         const int dump = a.buf_off[2] + a.group * a.buf_sz[2] + (q * 16 + r) - a.buf_off[L.out_buf];
         const float lo = L.relu ? 0.f : -3.4e38f;
         const bool pv = job * 16 + r < npos;

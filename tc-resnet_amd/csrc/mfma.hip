@@ -2259,7 +2259,9 @@ static int wgrad_nchunk(int k, int cin, int cout, int batch, bool fine) {
 #ifndef TCR_WGRAD_LDS_CHUNKS
 #define TCR_WGRAD_LDS_CHUNKS 256
 #endif
-    int n = ceil_div(batch, 4);
+    // (TCR_TUNE_WGRAD_LDS = 4, test arm: 16 utterances per workgroup whatever the batch -- the geometry of batch 4096, i.e. eight stages of two
+    //  utterances per workgroup and the two-stage lookahead in its steady state, at the batch sizes the emulator tests can afford)
+    int n = ceil_div(batch, tune_get(TCR_TUNE_WGRAD_LDS) == 4 ? 16 : 4);
     if (n > TCR_WGRAD_LDS_CHUNKS) n = TCR_WGRAD_LDS_CHUNKS;
     return n < 1 ? 1 : n;
 }
