@@ -336,6 +336,47 @@ __device__ __forceinline__ void phase_layer_s(const TrainPhaseArgs& a, const Pha
         const float* x0 = xin + g0 * in_sz + q * TPI + t0 * S + kHalo - PADLO;
         const float* x1 = xin + g1 * in_sz + q * TPI + t1 * S + kHalo - PADLO;
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef TCR_PHASE_AHEAD
+#define TCR_PHASE_AHEAD 12          // input-channel quads up to which a layer's taps run with a whole tap of weight lookahead (0: never)
+#endif
+        if constexpr (K > 1 && C4 <= TCR_PHASE_AHEAD && !TCR_PWHATIF(2)) {
+            // A whole tap of weight lookahead (the eval kernel's round-6 form, fused.hip: fused_job_s AHEAD): in the rolled loop below the
+            // compiler sinks a half-tap's refill loads to the END of the tap body and waits for them in front of the next tap's first MFMA,
+            // so with 8 - 16 MFMAs per tap every tap waits out an L1 / L2 round trip.  Two full-tap register sets that trade roles, the
+            // next tap's fragments requested through a buffer descriptor (uniform base + constant lane offset + uniform tap offset) before
+            // this tap's LDS reads and MFMAs.  Same accumulation order (quads ascending, tile 0 then tile 1): bitwise the rolled loop.
+            const buf_rsrc wr = make_rsrc(w);
+            const unsigned wl = (unsigned)(q * COUT + min(m * 16 + r, COUT - 1)) * 4u;
+            float w0[C4], w1[C4];
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) w0[c4] = buf_load_f32(wr, wl, (unsigned)(c4 * WSTEP) * 4u);
+            auto tap = [&](const int j, const float (&wu)[C4], float (&wf)[C4], const bool fill) {
+                if (fill) {
+#pragma unroll
+                    for (int c4 = 0; c4 < C4; ++c4) wf[c4] = buf_load_f32(wr, wl, (unsigned)(((j + 1) * C4 + c4) * WSTEP) * 4u);
+                }
+                float b0[C4], b1[C4];
+#pragma unroll
+                for (int c4 = 0; c4 < C4; ++c4) { b0[c4] = x0[c4 * XSTEP + j]; b1[c4] = x1[c4 * XSTEP + j]; }
+                __builtin_amdgcn_sched_barrier(0);              // (the requests stay in front of the tap's MFMAs)
+#pragma unroll
+                for (int c4 = 0; c4 < C4; ++c4) {
+                    acc0 = TCR_PMFMA(wu[c4], b0[c4], acc0);
+                    acc1 = TCR_PMFMA(wu[c4], b1[c4], acc1);
+                }
+            };
+#pragma unroll 1
+            for (int j = 0; j + 2 < K; j += 2) {
+                tap(j, w0, w1, true);
+                tap(j + 1, w1, w0, true);
+            }
+            if constexpr (K % 2 == 1) {
+                tap(K - 1, w0, w1, false);
+            } else {
+                tap(K - 2, w0, w1, true);
+                tap(K - 1, w1, w0, false);
+            }
+        } else {
         constexpr int H0 = C4 / 2, H1 = C4 - H0;
         float wa[H0 > 0 ? H0 : 1], wb[H1];
 #pragma unroll
@@ -369,6 +410,7 @@ __device__ __forceinline__ void phase_layer_s(const TrainPhaseArgs& a, const Pha
 #pragma unroll
                 for (int c4 = 0; c4 < H1; ++c4) wb[c4] = wp[(jn * C4 + H0 + c4) * WSTEP];
             }
+        }
         }
         // ---- epilogue: raw output -> global (interior only), per-channel sums of this job's valid positions ----
         const bool v0 = c0 < npos, v1 = c1 < npos;
