@@ -337,9 +337,17 @@ __device__ __forceinline__ void phase_layer_s(const TrainPhaseArgs& a, const Pha
         const float* x1 = xin + g1 * in_sz + q * TPI + t1 * S + kHalo - PADLO;
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifndef TCR_PHASE_AHEAD
-#define TCR_PHASE_AHEAD 12          // input-channel quads up to which a layer's taps run with a whole tap of weight lookahead (0: never)
+#define TCR_PHASE_AHEAD 8           // input-channel quads up to which a nine-tap layer's taps run with a whole tap of weight lookahead (0: never)
 #endif
-        if constexpr (K > 1 && C4 <= TCR_PHASE_AHEAD && !TCR_PWHATIF(2)) {
+        // Which layers (measured on the bench's training LEGS, where the next batch's front-end -- 168 registers x 3 waves per SIMD --
+        // shares the CUs; scripts/ab_libs_train_leg.py): the nine-tap layers of <= 32 input channels (<= 81 registers: a phase workgroup
+        // still fits beside two front-end waves per SIMD): TCResNet8 at 49 frames 830 - 841 -> 812 - 817 us per step of the leg, 98 frames
+        // 1283 -> 1266, TCResNet14-1.5 within noise (2415 - 2425; 98 frames 3762 -> 3752 - 3760).  36 / 48 / 72 input channels: 76 - 92
+        // registers for no gain in any leg.  The three-tap first conv (40 channels) with the lookahead runs at 90 registers at 49 frames
+        // and costs the TCResNet8 leg 40 us there (857) although the step ALONE does not move; at 98 frames (82 registers) it is
+        // worth ~10 us to both nets' legs: kept for that shape only.
+        constexpr bool kAhead = (K >= 9 && C4 <= TCR_PHASE_AHEAD) || (K == 3 && TIN >= 98 && TCR_PHASE_AHEAD > 0);
+        if constexpr (kAhead && !TCR_PWHATIF(2)) {
             // A whole tap of weight lookahead (the eval kernel's round-6 form, fused.hip: fused_job_s AHEAD): in the rolled loop below the
             // compiler sinks a half-tap's refill loads to the END of the tap body and waits for them in front of the next tap's first MFMA,
             // so with 8 - 16 MFMAs per tap every tap waits out an L1 / L2 round trip.  Two full-tap register sets that trade roles, the
